@@ -1,0 +1,262 @@
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF (build container only).
+
+    python -B oracle/make_golden.py
+
+The reference ships no tests or fixtures, so parity is pinned by running its own
+classes here, on closed-form parameters (``acvae_oracle.closed_form_state`` — weights are never
+stored) and seeded synthetic inputs, and storing inputs + noise + outputs as small .npz files.
+Only data is written: no reference source text, in any encoding, leaves /root/reference.
+
+Noise (dropout masks, eps of both reparameterisations) is drawn by torch's CPU generator inside the
+reference; the oracle makes the identical generator calls in the identical order, so running it with
+the same seed yields the very same draws, which are what get stored ("noise_*" entries).  The stored
+outputs are always the REFERENCE's.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import acvae_oracle as O  # noqa: E402
+import ref_shim  # noqa: E402
+from check_oracle_vs_reference import load_state_into, ref_train_step  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def npy(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items() if v is not None})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def pack_masks(masks):
+    d = {}
+    for i, m in enumerate(masks):
+        d[f"noise_drop{i}_bits"] = np.packbits(npy(m).astype(np.uint8).reshape(-1))
+        d[f"noise_drop{i}_shape"] = np.array(m.shape)
+    return d
+
+
+def g1_attention(ref):
+    """G1: Seq2SeqAttention.forward (models/attn_model.py:20-46)."""
+    g = torch.Generator().manual_seed(101)
+    out = {}
+    for ci, (N, S, E, Hd, A) in enumerate([(3, 4, 32, 32, 32), (4, 31, 64, 48, 40), (5, 62, 512, 512, 512),
+                                           (2, 187, 512, 512, 512)]):
+        m = ref.attn_model.Seq2SeqAttention(E, Hd, A)
+        st = O.closed_form_state({"v": (A,), "h2attn.weight": (A, E + Hd), "h2attn.bias": (A,)})
+        m.load_state_dict(st)
+        h_dec = torch.randn(N, Hd, generator=g); h_enc = torch.randn(N, S, E, generator=g)
+        lens = torch.randint(1, S + 1, (N,), generator=g); lens[0] = S
+        if N > 2:
+            lens[1] = 1
+        with torch.no_grad():
+            ctx, w = m(h_dec, h_enc, lens)
+        out.update({f"c{ci}_h_dec": h_dec, f"c{ci}_h_enc": h_enc, f"c{ci}_lens": lens, f"c{ci}_ctx": ctx,
+                    f"c{ci}_weights": w, f"c{ci}_dims": np.array([N, S, E, Hd, A])})
+    out["ncases"] = np.array(4)
+    save("g1_attention", **out)
+
+
+def g2_reparam_kl(ref):
+    """G2: eps*exp(.5*logvar)+mu (models/text_encoder.py:196-197,259-262) and Normal_kl_loss
+    (utils/train_util.py:259-266) incl. the unmasked padded rows (F8)."""
+    g = torch.Generator().manual_seed(102)
+    N, T, E = 5, 7, 96
+    mu_q = torch.randn(N, T, E, generator=g); lv_q = 0.5 * torch.randn(N, T, E, generator=g)
+    mu_p = torch.randn(N, T, E, generator=g); lv_p = 0.5 * torch.randn(N, T, E, generator=g)
+    eps = torch.randn(N, T, E, generator=g)
+    z = eps * torch.exp(.5 * lv_q) + mu_q
+    kl = ref.train_util.Normal_kl_loss(device="cpu")(mu_q, lv_q, mu_p, lv_p)
+    save("g2_reparam_kl", mu_q=mu_q, lv_q=lv_q, mu_p=mu_p, lv_p=lv_p, eps=eps, z=z, kl=kl)
+
+
+def g3_ce(ref):
+    """G3: LabelSmoothingLoss (utils/train_util.py:243-251) on packed rows and torch CrossEntropyLoss
+    (runner :222-227); ragged cap_lens.  The masked [bs,max_len,C] forms of losses/loss.py:18-70 cannot
+    be imported here (ignite absent) - their expected values below come from stock torch ops following
+    that source text and are flagged 'restated'."""
+    g = torch.Generator().manual_seed(103)
+    N, T, V = 6, 9, 257
+    logits = 3 * torch.randn(N, T, V, generator=g)
+    lens1 = torch.tensor([9, 9, 7, 4, 2, 1])
+    targets = torch.randint(0, V, (N, T), generator=g)
+    pk = torch.nn.utils.rnn.pack_padded_sequence(logits, lens1, batch_first=True).data
+    tg = torch.nn.utils.rnn.pack_padded_sequence(targets.float(), lens1, batch_first=True).data
+    ls = ref.train_util.LabelSmoothingLoss(V, smoothing=0.1, device="cpu")(pk, tg)
+    ls0 = ref.train_util.LabelSmoothingLoss(V, smoothing=0.0, device="cpu")(pk, tg)
+    ce = torch.nn.CrossEntropyLoss()(pk, tg.long())
+    restated_mean = O.masked_ce(logits, targets, lens1, 0.1, "mean")
+    restated_none = O.masked_ce(logits, targets, lens1, 0.0, "none")
+    save("g3_ce", logits=logits, targets=targets, lens1=lens1, ls_packed=ls, ls0_packed=ls0, ce_packed=ce,
+         restated_masked_ls_mean=restated_mean, restated_masked_ce_none=restated_none)
+
+
+def g4_encoder(ref):
+    """G4: Cnn10.forward (models/encoder.py:672-707), train mode (batch-stat BN + dropout, running-stat
+    update) and eval mode, tiny T."""
+    out = {}
+    for ci, (B, T) in enumerate([(2, 32), (3, 64), (2, 80)]):
+        shapes = {k: v for k, v in O.state_shapes(10).items() if k.startswith("encoder.")}
+        full = O.closed_form_state(O.state_shapes(10))
+        st = {k[len("encoder."):]: full[k].clone() for k in shapes}
+        m = ref.encoder.Cnn10(64, 512)
+        m.load_state_dict(st)
+        g = torch.Generator().manual_seed(104 + ci)
+        feats = torch.randn(B, T, 64, generator=g) * 2 + 0.5
+        lens = np.array([T] + [int(T * 0.7)] * (B - 1))
+        m.train()
+        torch.manual_seed(40 + ci)
+        with torch.no_grad():
+            r = m(feats, lens.copy())
+        ost = {k: full[k].clone() for k in shapes}
+        rec = []
+        torch.manual_seed(40 + ci)
+        with torch.no_grad():
+            o = O.cnn10_forward(ost, feats, lens.copy(), True, None, rec)
+        assert (r["audio_embeds"] - o["audio_embeds"]).abs().max() < 1e-5
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        out.update({f"c{ci}_feats": feats, f"c{ci}_lens": lens, f"c{ci}_train_audio_embeds": r["audio_embeds"],
+                    f"c{ci}_train_pooled": r["audio_embeds_pooled"], f"c{ci}_train_lens": r["audio_embeds_lens"],
+                    f"c{ci}_bn0_running_mean": sd["bn0.running_mean"], f"c{ci}_bn0_running_var": sd["bn0.running_var"],
+                    f"c{ci}_b4bn2_running_mean": sd["conv_block4.bn2.running_mean"],
+                    f"c{ci}_b4bn2_running_var": sd["conv_block4.bn2.running_var"],
+                    f"c{ci}_b1bn1_running_var": sd["conv_block1.bn1.running_var"],
+                    f"c{ci}_nbt": sd["bn0.num_batches_tracked"]})
+        out.update({f"c{ci}_{k}": v for k, v in pack_masks(rec).items()})
+        m.load_state_dict(st)
+        m.eval()
+        with torch.no_grad():
+            r = m(feats, lens.copy())
+        out.update({f"c{ci}_eval_audio_embeds": r["audio_embeds"], f"c{ci}_eval_pooled": r["audio_embeds_pooled"]})
+    out["ncases"] = np.array(3)
+    save("g4_encoder", **out)
+
+
+def g5_rnn(ref):
+    """G5: single GRU / LSTM step as the decoder / prior use torch.nn.GRU / LSTM (models/decoder.py:39-44,
+    models/text_encoder.py:229-235) and the packed BiGRU posterior (text_encoder.py:182-216)."""
+    g = torch.Generator().manual_seed(105)
+    N, I, H = 5, 48, 32
+    gru = torch.nn.GRU(I, H, batch_first=True); lstm = torch.nn.LSTM(I, H, batch_first=True)
+    gs = O.closed_form_state({k: tuple(v.shape) for k, v in gru.state_dict().items()})
+    ls = O.closed_form_state({k: tuple(v.shape) for k, v in lstm.state_dict().items()})
+    gru.load_state_dict(gs); lstm.load_state_dict(ls)
+    x = torch.randn(N, 1, I, generator=g); h = torch.randn(1, N, H, generator=g); c = torch.randn(1, N, H, generator=g)
+    with torch.no_grad():
+        _, gh = gru(x, h)
+        _, (lh, lc) = lstm(x, (h, c))
+    V, E = 30, 32
+    q = ref.text_encoder.PosteriorRNN_hybrid(word_dim=E, embed_size=E, vocab_size=V, hidden_size=E, dropout=0.0)
+    qs = O.closed_form_state({k: tuple(v.shape) for k, v in q.state_dict().items()})
+    q.load_state_dict(qs)
+    cap_lens = np.array([9, 7, 7, 4, 2])
+    caps = torch.zeros(5, 9)
+    for b, n in enumerate(cap_lens):
+        caps[b, :n] = torch.randint(1, V, (int(n),), generator=g).float()
+    torch.manual_seed(55)
+    with torch.no_grad():
+        qo = q(caps, cap_lens)
+    torch.manual_seed(55)
+    eps = torch.randn(qo["q_means"].shape)
+    save("g5_rnn", x=x, h=h, c=c, gru_h=gh, lstm_h=lh, lstm_c=lc, caps=caps, cap_lens=cap_lens, eps=eps,
+         q_means=qo["q_means"], q_logs=qo["q_logs"], q_z=qo["q_z"], q_means_utt=qo["q_means_utt"],
+         dims=np.array([N, I, H, V, E]))
+
+
+GRAD_KEYS = ("encoder.bn0.weight", "encoder.conv_block1.conv1.weight", "encoder.conv_block2.conv2.weight",
+             "encoder.conv_block4.bn2.bias", "decoder.attn.v", "decoder.attn.h2attn.weight",
+             "decoder.model.weight_ih_l0", "decoder.classifier.bias", "decoder.word_embeddings.weight",
+             "pnet.mean_log_out.weight", "pnet.network.weight_hh_l0", "pnet.word_attn.h2attn.bias",
+             "qnet.network.weight_ih_l0_reverse", "qnet.token_mean_log.weight", "mean_log_out.weight", "ln.weight")
+OUT_KEYS = ("logits", "outputs", "seqs", "sampled_logprobs", "attn_weights", "p_means", "p_logs", "p_z",
+            "q_means", "q_logs", "q_z", "q_means_utt", "p_means_utt")
+
+
+def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True, keep_noise=True):
+    shapes = O.state_shapes(V, E, E, None, E, 512)
+    state = O.closed_form_state(shapes)
+    model = ref_shim.build_reference_model(ref, V, E, E)
+    load_state_into(model, state)
+    model.train()
+    feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, T, V, L, seed=seed, ragged=ragged)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    torch.manual_seed(seed); random.seed(seed)
+    rout, rl, rg = ref_train_step(ref, model, feats, feat_lens.copy(), caps, cap_lens, V, 1.0, dis, optimizer=opt)
+    ostate = {k: v.clone() for k, v in state.items()}
+    rec = {}
+    torch.manual_seed(seed); random.seed(seed)
+    res = O.OracleTrainer(ostate, V).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis, record=rec)
+    assert abs(float(res["loss"]) - float(rl["loss"])) < 1e-4 * max(1, abs(float(rl["loss"]))), (res["loss"], rl["loss"])
+    d = dict(dims=np.array([B, T, V, E, L]), seed=np.array(seed), ragged=np.array(int(ragged)), dis_ratio=np.array(float(dis)),
+             feat_lens=feat_lens, cap_lens=cap_lens, caps=caps,
+             loss=rl["loss"], ce=rl["ce"], kl=rl["kl"], mse=rl["mse"], grad_norm=rl["grad_norm"])
+    if keep_tensors:
+        d["feats"] = feats
+        d.update({"out_" + k: rout[k] for k in OUT_KEYS})
+        d.update({"grad_" + k: rg[k] for k in GRAD_KEYS if k in rg})
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        for k in ("encoder.conv_block1.conv1.weight", "decoder.attn.v", "pnet.mean_log_out.bias",
+                  "encoder.conv_block3.bn1.running_mean", "encoder.bn0.running_var"):
+            d["post_" + k] = sd[k]
+    if keep_noise:
+        d["noise_eps_q"] = rec["eps_q"]; d["noise_eps_p"] = rec["eps_p"]
+        d.update(pack_masks(rec["dropout"]))
+    save(name, **d)
+    return model, state, feats, feat_lens
+
+
+def g7_decode(ref):
+    """G7: greedy and N=5 z-samples-per-clip decode (models/vae_model.py:880-894,700-721; replication as
+    runners/pytorch_runner_vae.py:101-104), eval mode."""
+    V, E = 50, 64
+    shapes = O.state_shapes(V, E, E, None, E, 512)
+    state = O.closed_form_state(shapes)
+    model = ref_shim.build_reference_model(ref, V, E, E)
+    load_state_into(model, state)
+    model.eval()
+    feats, _, feat_lens, _ = O.synthetic_batch(3, 96, V, 8, seed=7, ragged=True)
+    d = dict(dims=np.array([3, 96, V, E]), feats=feats, feat_lens=feat_lens)
+    for tag, rep in (("greedy1", 1), ("greedy5", 5)):
+        f = feats.repeat(rep, 1, 1)
+        l_ = [int(x) for x in feat_lens for _ in range(rep)]                  # runner :102-104 (B>1 mismatch kept)
+        torch.manual_seed(70 + rep)
+        with torch.no_grad():
+            ro = model(f, list(l_), method="greedy", beam_size=rep)
+        rec = {}
+        torch.manual_seed(70 + rep)
+        with torch.no_grad():
+            oo = O.hybrid_forward({k: v.clone() for k, v in state.items()}, f, list(l_), training=False, record=rec)
+        assert torch.equal(ro["seqs"], oo["seqs"])
+        d[tag + "_seqs"] = ro["seqs"]; d[tag + "_lens"] = np.array(l_)
+        eps = rec["eps_p"]                                                    # [steps_run,N,E]; pad to max_length
+        full = torch.zeros(O.MAX_LENGTH, eps.shape[1], eps.shape[2]); full[:eps.shape[0]] = eps
+        d[tag + "_noise_eps_p"] = full; d[tag + "_steps_run"] = np.array(eps.shape[0])
+        d[tag + "_logits0"] = ro["logits"][:, 0]
+    save("g7_decode", **d)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_shim.load()
+    g1_attention(ref); g2_reparam_kl(ref); g3_ce(ref); g4_encoder(ref); g5_rnn(ref)
+    train_fixture(ref, "g6_train_step", 4, 64, 50, 64, 8, True, 0, seed=6)
+    train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)
+    train_fixture(ref, "g6c_train_step_e512", 2, 64, 300, 512, 7, False, 0, seed=26, keep_tensors=False)
+    g7_decode(ref)
+    # G8: BASELINE config 1 shape; scalars only, noise re-drawn in the test from the stored seed.
+    train_fixture(ref, "g8_config1_scalars", 8, 500, 5000, 512, 22, False, 0, seed=8, keep_tensors=False,
+                  keep_noise=False)
+
+
+if __name__ == "__main__":
+    main()
