@@ -1,0 +1,95 @@
+"""ctypes binding of libacvae_hip.so, generated from include/acvae_hip.h at import time so that the
+Python side can never drift from the C ABI.  There is NO fallback: if the library is missing or a
+symbol declared in the header is not exported, importing/using the product path raises."""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "acvae_hip.h")
+LIB_PATH = os.path.join(_HERE, "libacvae_hip.so")
+
+_CT = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
+       "uint64_t": ctypes.c_uint64}
+ERRORS = {-1: "ACVAE_EINVAL (bad dims / null pointer)", -2: "ACVAE_EALIGN (alignment)",
+          -3: "ACVAE_EUNSUPPORTED", -4: "ACVAE_EWORKSPACE (workspace too small)"}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(argname, ctype)])} for every `int|int64_t acvae_*(...)` prototype, and {enum: value}."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|int64_t)\s+(acvae_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    alist.append((a.split("*")[-1].strip(), ctypes.c_void_p))
+                else:
+                    toks = a.replace("const ", "").split()
+                    alist.append((toks[-1], _CT[toks[0]]))
+        protos[name] = (_CT[ret], alist)
+    enums = {}
+    for m in re.finditer(r"enum\s+\w*\s*\{([^}]*)\}", src):
+        val = -1
+        for item in m.group(1).split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                k, v = item.split("=")
+                val = int(v.strip(), 0)
+                enums[k.strip()] = val
+            else:
+                val += 1
+                enums[item] = val
+    return protos, enums
+
+
+PROTOS, ENUMS = parse_header()
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the AC-VAE HIP path has no CPU fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in PROTOS.items():
+            fn = getattr(_lib, name)            # AttributeError if the header declares what the .so lacks
+            fn.restype = ret
+            fn.argtypes = [t for _, t in args]
+    return _lib
+
+
+def _conv(x):
+    if isinstance(x, torch.Tensor):
+        return x.data_ptr()
+    return x
+
+
+def current_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call an `int acvae_*` entry point; tensors are passed as device pointers; raises on non-zero."""
+    fn = getattr(lib(), name)
+    rc = fn(*[_conv(a) for a in args])
+    if PROTOS[name][0] is ctypes.c_int and rc != 0:
+        what = ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
+        raise RuntimeError(f"{name} failed: {what}")
+    return rc
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("acvae_amd: the HIP path needs tensors on an MI355X device (no CPU fallback)")

@@ -1,0 +1,91 @@
+// Shared device/host helpers for the AC-VAE gfx950 kernels.  CDNA4 only: 64-lane wavefronts are
+// hard-coded (cdna_hip_programming.md §1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ACVAE_OK 0
+#define ACVAE_EINVAL (-1)      // bad dims / null pointer
+#define ACVAE_EALIGN (-2)      // pointer or leading dimension not aligned as the kernel needs
+#define ACVAE_EUNSUPPORTED (-3)
+#define ACVAE_EWORKSPACE (-4)  // workspace too small
+
+// Launch check: never throws, never exits; returns the hipError_t as a positive code.
+#define ACVAE_LAUNCH_CHECK()                      \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+#define ACVAE_TRY(x)                 \
+  do {                               \
+    int r__ = (x);                   \
+    if (r__ != 0) return r__;        \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Counter-based RNG for dropout (Philox-4x32-10).  One call -> 4 uniform 32-bit words.
+__device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t ctr_lo, uint32_t ctr_hi) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = ctr_hi, c3 = 0x5eed5eedu;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+// keep-decision for element `idx` of dropout site `site` with keep-probability 1-p.
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, float p) {
+  const uint4 r = philox4x32(seed, idx >> 2, site);
+  const uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+  return (float)(w >> 8) * (1.0f / 16777216.0f) >= p;
+}
+#endif

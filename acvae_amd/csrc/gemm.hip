@@ -1,0 +1,190 @@
+// Dense fp32 products on MFMA for the Linear layers of the path (attention projections, recurrent
+// input/hidden projections, mean/log-variance heads, vocabulary classifier) and their gradients.
+// Replaces torch.nn.Linear / F.linear at models/attn_model.py:32, models/decoder.py:198,
+// models/text_encoder.py:192,255, models/vae_model.py:726 and the GEMMs inside nn.GRU / nn.LSTM.
+#include "mfma_tile.h"
+#include "../../include/acvae_hip.h"
+
+namespace {
+using namespace mfma;
+
+template <int BN, bool VEC4>
+__global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ A, long lda,
+                                                                const float* __restrict__ B, long ldb,
+                                                                const float* __restrict__ bias, float* __restrict__ C,
+                                                                long ldc, int M, int N, int K, int accumulate) {
+  __shared__ NtSmem<BN> sm;
+  PlainLoader<VEC4> al{A, lda, M, K}, bl{B, ldb, N, K};
+  PlainEpilogue ep{C, ldc, bias, accumulate};
+  // blockIdx.x walks M fastest so that consecutive blocks (dealt round-robin to XCDs) share the B panel
+  nt_block<BN>(al, bl, M, N, K, blockIdx.x, blockIdx.y, ep, sm);
+}
+
+template <int WM, int WN, bool VEC4>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float* __restrict__ A, long lda,
+                                                         const float* __restrict__ B, long ldb, float* __restrict__ C,
+                                                         long ldc, int M, int N, int K, int k_per, int accumulate,
+                                                         long slab_stride) {
+  __shared__ TnSmem<WM, WN> sm;
+  PlainKMajorLoader<VEC4> al{A, lda, M, K}, bl{B, ldb, N, K};
+  const int kb = blockIdx.z * k_per;
+  const int ke = min(K, kb + k_per);
+  float* out = C + (long)blockIdx.z * slab_stride;
+  tn_block<WM, WN>(al, bl, M, N, kb, ke, blockIdx.x, blockIdx.y, out, ldc, accumulate, sm);
+}
+
+// C[m][n] (+)= sum_z slab[z][m][n]   (fixed order: deterministic)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, long slab_stride, int nsplit, float* __restrict__ C,
+                                   long ldc, int M, int N, int accumulate) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    float acc = 0.f;
+    for (int z = 0; z < nsplit; ++z) acc += slab[z * slab_stride + i];
+    float* p = C + (long)m * ldc + n;
+    *p = accumulate ? *p + acc : acc;
+  }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const float* __restrict__ A1, long lda1,
+                                                                 const float* __restrict__ B1, long ldb1, int K1,
+                                                                 const float* __restrict__ A2, long lda2,
+                                                                 const float* __restrict__ B2, long ldb2, int K2,
+                                                                 const float* __restrict__ bias, float* __restrict__ C,
+                                                                 long ldc, int M, int N, int accumulate) {
+  __shared__ float red[SK_WAVES][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  sk_accumulate<VEC4>(acc, A1, lda1, B1, ldb1, M, N, K1, m0, n0, wave, li, lh);
+  if (A2) sk_accumulate<VEC4>(acc, A2, lda2, B2, ldb2, M, N, K2, m0, n0, wave, li, lh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += SK_THREADS) {
+    const int mm = e >> 5, nn = e & 31;
+    const int m = m0 + mm, n = n0 + nn;
+    if (m < M && n < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) v += red[w][mm][nn];
+      if (bias) v += bias[n];
+      float* p = C + (long)m * ldc + n;
+      if (accumulate) v += *p;
+      *p = v;
+    }
+  }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, long ld_in, float* __restrict__ out, long ld_out,
+                                 int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(long)c * ld_out + r] = tile[threadIdx.x][j];
+  }
+}
+
+inline bool vec_ok(const float* p, int64_t ld, int k) { return aligned16(p) && (ld & 3) == 0 && (k & 3) == 0; }
+
+}  // namespace
+
+// Internal C++ entry (also used by the composite encoder/decoder drivers).
+int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1, const float* A2,
+                       int64_t lda2, const float* B2, int64_t ldb2, int K2, const float* bias, float* C, int64_t ldc,
+                       int M, int N, int accumulate, hipStream_t st) {
+  if (!A1 || !B1 || !C || M <= 0 || N <= 0 || K1 <= 0) return ACVAE_EINVAL;
+  if (A2 && (!B2 || K2 <= 0)) return ACVAE_EINVAL;
+  bool vec = vec_ok(A1, lda1, K1) && vec_ok(B1, ldb1, K1);
+  if (A2) vec = vec && vec_ok(A2, lda2, K2) && vec_ok(B2, ldb2, K2);
+  if (M <= 64 || A2) {
+    dim3 grid(cdiv(N, 32), cdiv(M, 32));
+    if (vec)
+      hipLaunchKernelGGL(gemm_skinny_kernel<true>, grid, dim3(SK_THREADS), 0, st, A1, lda1, B1, ldb1, K1, A2, lda2, B2,
+                         ldb2, K2, bias, C, ldc, M, N, accumulate);
+    else
+      hipLaunchKernelGGL(gemm_skinny_kernel<false>, grid, dim3(SK_THREADS), 0, st, A1, lda1, B1, ldb1, K1, A2, lda2,
+                         B2, ldb2, K2, bias, C, ldc, M, N, accumulate);
+    ACVAE_LAUNCH_CHECK();
+    return ACVAE_OK;
+  }
+  const bool bn64 = (N <= 64);
+  dim3 grid(cdiv(M, BM), cdiv(N, bn64 ? 64 : 128));
+#define LAUNCH_NT(BN_, V_)                                                                                     \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN_, V_>), grid, dim3(NT_THREADS), 0, st, A1, lda1, B1, ldb1, bias, C, ldc, M, \
+                     N, K1, accumulate)
+  if (bn64) { if (vec) LAUNCH_NT(64, true); else LAUNCH_NT(64, false); }
+  else      { if (vec) LAUNCH_NT(128, true); else LAUNCH_NT(128, false); }
+#undef LAUNCH_NT
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                             int64_t ldc, int M, int N, int K, int accumulate, void* stream) {
+  return acvae_gemm_nt_dual(A, lda, B, ldb, K, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, accumulate,
+                            (hipStream_t)stream);
+}
+
+static int tn_splits(int M, int N, int K) {
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+  int s = (int)(1024 / (tiles > 0 ? tiles : 1));
+  const int maxs = cdiv(K, 4 * BKT);  // at least 64 k per slice
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return s;
+}
+
+extern "C" int64_t acvae_gemm_tn_workspace_bytes(int M, int N, int K) {
+  const int s = tn_splits(M, N, K);
+  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int acvae_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                             int N, int K, int accumulate, float* slab_ws, int64_t slab_ws_bytes, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ACVAE_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int s = tn_splits(M, N, K);
+  if (s > 1 && (!slab_ws || slab_ws_bytes < (int64_t)s * M * N * (int64_t)sizeof(float))) s = 1;
+  int k_per = cdiv(cdiv(K, s), BKT) * BKT;
+  s = cdiv(K, k_per);
+  const bool vec = aligned16(A) && aligned16(B) && (lda & 3) == 0 && (ldb & 3) == 0 && (M & 3) == 0 && (N & 3) == 0;
+  const bool narrow = (M <= 64);
+  dim3 grid(cdiv(M, narrow ? 64 : 128), cdiv(N, narrow ? 256 : 128), s);
+  float* out = s > 1 ? slab_ws : C;
+  const long out_ld = s > 1 ? N : ldc;
+  const long slab_stride = s > 1 ? (long)M * N : 0;
+  const int acc_k = s > 1 ? 0 : accumulate;
+#define LAUNCH_TN(WM_, WN_, V_)                                                                              \
+  hipLaunchKernelGGL((gemm_tn_kernel<WM_, WN_, V_>), grid, dim3(256), 0, st, A, lda, B, ldb, out, out_ld, M, N, K, \
+                     k_per, acc_k, slab_stride)
+  if (narrow) { if (vec) LAUNCH_TN(1, 4, true); else LAUNCH_TN(1, 4, false); }
+  else        { if (vec) LAUNCH_TN(2, 2, true); else LAUNCH_TN(2, 2, false); }
+#undef LAUNCH_TN
+  if (s > 1) {
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
+                       dim3(256), 0, st, slab_ws, slab_stride, s, C, ldc, M, N, accumulate);
+  }
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_transpose(const float* in, int64_t ld_in, float* out, int64_t ld_out, int rows, int cols,
+                               void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, (hipStream_t)stream, in,
+                     ld_in, out, ld_out, rows, cols);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}

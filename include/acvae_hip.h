@@ -1,0 +1,111 @@
+/* acvae_hip.h — C ABI of libacvae_hip.so: the MI355X (gfx950) kernels behind AC-VAE's training hot path.
+ *
+ * The reference (XinMing0411/AC-VAE) is pure Python on torch.nn and has NO FFI / operator API of its own
+ * (SURVEY.md F1, §8(b)); this ABI is therefore build-defined.  Each entry point names the reference
+ * computation it replaces (file:line relative to the reference root).  The Python host side
+ * (the acvae_amd package) mirrors the reference's module classes and calls these through ctypes; see
+ * INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless its name ends in _host.
+ *   - the caller owns every buffer, workspaces included; the library never allocates or frees device
+ *     memory and keeps no mutable global state.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises.
+ *   - return 0 on success, a negative ACVAE_E* code for bad arguments, or a positive hipError_t.
+ *   - fp32 everywhere ("dtype f32"), token ids / lengths int64 (as torch.long).
+ *   - "ld*" are leading dimensions in ELEMENTS; rows are addressed as base + row*ld.
+ */
+#ifndef ACVAE_HIP_H
+#define ACVAE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACVAE_ABI_VERSION 1
+int acvae_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic dense products on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replace torch.nn.Linear /
+ * F.linear call sites of the path (models/attn_model.py:32, models/decoder.py:198,
+ * models/text_encoder.py:192,255, models/vae_model.py:726) and their autograd backward.
+ *   NT: C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C if accumulate)
+ *   TN: C[M,N] = sum_k A[K,M]^T . B[K,N]   (weight gradients: dW = dY^T . X)
+ * ------------------------------------------------------------------------------------------- */
+int acvae_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                  int64_t ldc, int M, int N, int K, int accumulate, void* stream);
+int acvae_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N,
+                  int K, int accumulate, float* slab_ws, int64_t slab_ws_bytes, void* stream);
+int64_t acvae_gemm_tn_workspace_bytes(int M, int N, int K);
+/* out[c,r] = in[r,c] */
+int acvae_transpose(const float* in, int64_t ld_in, float* out, int64_t ld_out, int rows, int cols, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A3  Seq2SeqAttention.forward  models/attn_model.py:20-46, with the loop-invariant half of
+ * h2attn hoisted:  encproj[n,s,:] = W[:, hs_dec:] . h_enc[n,s] + b  (once per batch),
+ * qproj[row,:] = W[:, :hs_dec] . h_dec[row]  (per query).  Query row (n,j), n<N, j<Tq lives at
+ * base + n*stride_n + j*stride_j for qproj / ctx / weights (lets a decode step address column t of
+ * batch-major [N,Tc,.] buffers).  score = v . tanh(qproj + encproj), positions s >= lens[n] get
+ * -1e10 before the softmax (attn_model.py:41), ctx = sum_s w_s h_enc[n,s].
+ * ------------------------------------------------------------------------------------------- */
+int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, const float* encproj, const float* enc,
+                   const int64_t* lens, const float* v, float* ctx, int64_t c_sn, int64_t c_sj, float* weights,
+                   int64_t w_sn, int64_t w_sj, int N, int Tq, int S, int A, int E, void* stream);
+/* Backward of the above for upstream dctx (attention weights carry no gradient on this path).
+ * dencproj [N,S,A] and denc [N,S,E] are ACCUMULATED into (+=); dv_part [N,A] is accumulated into;
+ * dqproj rows are written. */
+int acvae_attn_bwd(const float* dctx, int64_t dc_sn, int64_t dc_sj, const float* qproj, int64_t q_sn, int64_t q_sj,
+                   const float* encproj, const float* enc, const int64_t* lens, const float* v,
+                   const float* weights, int64_t w_sn, int64_t w_sj, float* dqproj, int64_t dq_sn, int64_t dq_sj,
+                   float* dencproj, float* denc, float* dv_part, int N, int Tq, int S, int A, int E, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reparameterisation  z = eps * exp(.5*logvar) + mu   models/text_encoder.py:196-197,259-262.
+ * `ml` holds [rows, 2E] = [mu | logvar] (the Linear output, split at half: text_encoder.py:257-258).
+ * Writes mean/log/z (each row stride ld_out) and, if z2 != NULL, a second copy of z (row stride ld_z2).
+ * ------------------------------------------------------------------------------------------- */
+int acvae_reparam_fwd(const float* ml, int64_t ld_ml, const float* eps, int64_t ld_eps, float* mean, float* logv,
+                      float* z, int64_t ld_out, float* z2, int64_t ld_z2, int rows, int E, void* stream);
+/* dml[:, :E] = dz + dmean_ext ; dml[:, E:] = dz*eps*.5*exp(.5*logvar) + dlog_ext  (ext terms may be NULL) */
+int acvae_reparam_bwd(const float* dz, int64_t ld_dz, const float* dmean_ext, const float* dlog_ext, int64_t ld_ext,
+                      const float* logv, int64_t ld_lv, const float* eps, int64_t ld_eps, float* dml, int64_t ld_dml,
+                      int rows, int E, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A9  Normal_kl_loss.forward  utils/train_util.py:259-266:  sum over E, mean over ALL rows (unmasked, F8).
+ * Inputs are [rows,E] contiguous.  `partials` is a scratch of acvae_kl_partials(rows,E) floats.
+ * ------------------------------------------------------------------------------------------- */
+int64_t acvae_kl_partials(int64_t n_elem);
+int acvae_gauss_kl_fwd(const float* mu1, const float* lv1, const float* mu2, const float* lv2, float* partials,
+                       float* out_scalar, int64_t rows, int E, void* stream);
+/* grad_out: device scalar (dLoss/dKL).  Any of the four outputs may be NULL. */
+int acvae_gauss_kl_bwd(const float* mu1, const float* lv1, const float* mu2, const float* lv2, const float* grad_out,
+                       float* dmu1, float* dlv1, float* dmu2, float* dlv2, int64_t rows, int E, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A6  CaptionModel.sample_next_word (greedy)  models/word_model.py:173-207  and
+ * A8  LabelSmoothingLoss.forward  utils/train_util.py:243-251 / torch CrossEntropyLoss (runner :222-227)
+ * A13 masked CrossEntropyLoss / LabelSmoothingLoss  losses/loss.py:18-70
+ * One pass over logits [N,T,V] (row (n,t) at logits + n*ld_n + t*ld_t) producing per-row
+ * argmax (first maximum), max log-prob and log-sum-exp; the CE kernels reuse the row stats.
+ * A row (n,t) is valid iff t < lens1[n] (lens1 = cap_lens-1; NULL = all valid).
+ * ------------------------------------------------------------------------------------------- */
+int acvae_row_logsoftmax_argmax(const float* logits, int64_t ld_n, int64_t ld_t, int64_t* argmax, float* max_logprob,
+                                float* lse, int64_t o_sn, int64_t o_st, int N, int T, int V, void* stream);
+/* reduction: 0 none (writes loss_rows only), 1 mean over valid rows, 2 sum.  loss_rows [N,T] (0 at invalid rows). */
+int acvae_ls_ce_fwd(const float* logits, int64_t ld_n, int64_t ld_t, const int64_t* targets, int64_t tg_sn,
+                    const int64_t* lens1, const float* lse, float smoothing, int reduction, float* loss_rows,
+                    float* out_scalar, int N, int T, int V, void* stream);
+/* dlogits [N,T,V] contiguous rows (ld_n, ld_t as logits); grad_out device scalar; grad_rows optional [N,T]
+ * (reduction none).  Invalid rows get zeros. */
+int acvae_ls_ce_bwd(const float* logits, int64_t ld_n, int64_t ld_t, const int64_t* targets, int64_t tg_sn,
+                    const int64_t* lens1, const float* lse, float smoothing, int reduction, const float* grad_out,
+                    const float* grad_rows, float* dlogits, int N, int T, int V, void* stream);
+/* mean((a-b)^2) over n elements and its backward (runner :317, nn.MSELoss). */
+int acvae_mse_fwd(const float* a, const float* b, float* partials, float* out_scalar, int64_t n, void* stream);
+int acvae_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, float* db, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACVAE_HIP_H */
