@@ -1,0 +1,47 @@
+// Internal C++ launcher API of conv.hip (used by the composite encoder driver and the per-op C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct DropoutSpec {
+  float p;              // drop probability; 0 disables
+  const uint8_t* mask;  // optional explicit keep-mask in the reference's NCHW / [N,C] order (parity tests)
+  uint64_t seed;        // Philox key when mask == nullptr
+  uint32_t site;        // dropout call-site id (0..5 in Cnn10.forward order)
+};
+
+namespace acvae {
+int conv3x3_igemm(const float* X, const float* scale, const float* shift, const float* Wp, float* Y, float* partials,
+                  int N, int H, int W, int Cin, int Cout, hipStream_t st);
+int conv_partials_rows(int N, int H, int W);
+long conv3x3_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout);
+int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
+                  int N, int H, int W, int Cin, int Cout, hipStream_t st);
+int repack_weights(const float* W_oihw, float* Wf, float* Wd, int Cout, int Cin, hipStream_t st);
+int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hipStream_t st);
+int bn0_partials_rows(long rows);
+int bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, int64_t* nbt, int training, float* scale, float* shift,
+                float* mean, float* invstd, hipStream_t st);
+int conv1_first_blocks(int N, int T);
+int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, float* Y,
+                    float* partials, int N, int T, int F, hipStream_t st);
+int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
+                    const float* W1, const float* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
+                    float* dbeta0, int N, int T, int F, hipStream_t st);
+int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* P, int N, int H, int W, int C,
+                 DropoutSpec drop, hipStream_t st);
+int bn_bwd_blocks(int N, int H, int W);
+int bn_bwd(const float* Y, const float* dO, bool pool, const float* scale, const float* shift, const float* mean,
+           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, int N, int H, int W, int C,
+           DropoutSpec drop, hipStream_t st);
+int freq_mean(const float* P, float* out, long rows, int Fp, int C, hipStream_t st);
+int freq_mean_bwd(const float* dae, float* dP, long rows, int Fp, int C, hipStream_t st);
+int time_pool(const float* ae, float* out, int N, int S, int C, DropoutSpec drop, hipStream_t st);
+int relu_dropout(float* x, int total, DropoutSpec drop, hipStream_t st);
+}  // namespace acvae
+
+// gemm.hip
+int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1, const float* A2,
+                       int64_t lda2, const float* B2, int64_t ldb2, int K2, const float* bias, float* C, int64_t ldc,
+                       int M, int N, int accumulate, hipStream_t st);

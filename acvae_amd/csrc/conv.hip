@@ -1,0 +1,834 @@
+// A1: the Cnn10 audio encoder's convolution stack (models/encoder.py:606-707) on gfx950.
+//
+// Data layout in HBM: activations are NHWC = [clip][time][mel][channel] fp32 (the reference is NCHW);
+// with channels innermost the K index of the implicit GEMM (tap, ci) is contiguous per tap, so every
+// im2col row segment is a coalesced 128-B read, and the GEMM's N index (cout) is contiguous in the
+// output.  Weights are repacked once per step from the state-dict's OIHW to [cout][tap][cin].
+//
+// conv3x3 as implicit GEMM on fp32 MFMA:  Y[p, co] = sum_{tap,ci} act(X[p+tap, ci]) * W[co, tap, ci]
+//   M = N*H*W pixels, N = Cout, K = 9*Cin.  `act` is the PREVIOUS layer's BatchNorm+ReLU applied while
+//   staging the operand (relu(x*scale[ci]+shift[ci]), zero outside the image), so the normalised
+//   tensor is never written to HBM; the epilogue writes the raw conv output and this layer's
+//   per-channel sum / sum-of-squares partials for the batch statistics.
+// The same kernel computes the data gradient (X = dY, W = flipped/transposed weights, no act, no stats).
+// The weight gradient is the k-major (TN) MFMA kernel with the shifted/activated operand loader,
+// split over pixels (split-K) into slabs that are reduced in fixed order.
+#include "mfma_tile.h"
+#include "../../include/acvae_hip.h"
+#include "conv.h"
+
+namespace {
+using namespace mfma;
+
+// ------------------------------------------------------------------ im2col loaders
+struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
+  const float* X;
+  const float* scale;  // nullable: act = identity
+  const float* shift;
+  int H, W, C, M;
+  int ph[4], pw[4];
+  long pbase[4];
+  __device__ __forceinline__ void init(int row0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = row0 + (threadIdx.x >> 3) + 32 * j;
+      if (p < M) {
+        pw[j] = p % W;
+        ph[j] = (p / W) % H;
+        pbase[j] = (long)p * C;
+      } else {
+        pw[j] = -100000; ph[j] = -100000; pbase[j] = 0;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(int, int kstep, int, float4* regs) const {
+    const int k0 = kstep * BK;
+    const int tap = k0 / C;
+    const int ci = k0 - tap * C + (threadIdx.x & 7) * 4;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const long off = (long)(dy * W + dx) * C + ci;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) {
+      sc = *reinterpret_cast<const float4*>(scale + ci);
+      sh = *reinterpret_cast<const float4*>(shift + ci);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int hh = ph[j] + dy, ww = pw[j] + dx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+        v = *reinterpret_cast<const float4*>(X + pbase[j] + off);
+        if (scale) {
+          v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+          v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+        }
+      }
+      regs[j] = v;
+    }
+  }
+};
+
+struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
+  const float* X;
+  const float* scale;
+  const float* shift;
+  int H, W, C, M, NC;  // NC = 9*C
+  int dy, dx, ci;
+  bool colok;
+  float4 sc, sh;
+  template <int WT>
+  __device__ __forceinline__ void init(int col0) {
+    const int col = col0 + (threadIdx.x % (WT / 4)) * 4;
+    colok = col < NC;
+    const int tap = colok ? col / C : 0;
+    ci = colok ? col - tap * C : 0;
+    dy = tap / 3 - 1; dx = tap % 3 - 1;
+    sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale && colok) {
+      sc = *reinterpret_cast<const float4*>(scale + ci);
+      sh = *reinterpret_cast<const float4*>(shift + ci);
+    }
+  }
+  template <int WT>
+  __device__ __forceinline__ void load(int, int k0, float4* regs) const {
+    constexpr int TPR = WT / 4, RPI = 256 / TPR, ITS = BKT / RPI;
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const int p = k0 + threadIdx.x / TPR + it * RPI;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (colok && p < M) {
+        const int w = p % W, h = (p / W) % H;
+        const int hh = h + dy, ww = w + dx;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+          v = *reinterpret_cast<const float4*>(X + ((long)p + dy * W + dx) * C + ci);
+          if (scale) {
+            v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+            v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+          }
+        }
+      }
+      regs[it] = v;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ conv epilogue: raw store + BN partials
+struct ConvStatsEpilogue {
+  float* Y;          // [M][Cout]
+  float* partials;   // [gridM][2][Cout] or nullptr
+  int Cout;
+  template <int BN, int NTN>
+  __device__ __forceinline__ void run(const f32x16 (&acc)[2][NTN], int row0, int col0, int wm, int wn, int li, int lh,
+                                      int M, int N, float* lds) const {
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) {
+      const int nl = wn * (BN / 2) + j * 32 + li;
+      const int n = col0 + nl;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float v = acc[i][j][r];
+          if (m < M && n < N) Y[(long)m * Cout + n] = v;
+          s += v;          // rows >= M were staged as zeros -> contribute 0
+          q += v * v;
+        }
+      if (partials) {
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lh == 0) {
+          lds[(wm * 2 + 0) * BN + nl] = s;
+          lds[(wm * 2 + 1) * BN + nl] = q;
+        }
+      }
+    }
+    if (partials) {
+      __syncthreads();
+      const int t = threadIdx.x;
+      if (t < BN && col0 + t < N) {
+        float* out = partials + (long)(row0 / BM) * 2 * Cout + col0 + t;
+        out[0] = lds[0 * BN + t] + lds[2 * BN + t];
+        out[Cout] = lds[1 * BN + t] + lds[3 * BN + t];
+      }
+    }
+  }
+};
+
+template <int BN>
+__global__ __launch_bounds__(NT_THREADS, 2) void conv_igemm_kernel(ConvRowLoader al, const float* __restrict__ Wp,
+                                                                   ConvStatsEpilogue ep, int M, int Cout, int K) {
+  __shared__ NtSmem<BN> sm;
+  PlainLoader<true> bl{Wp, K, Cout, K};
+  nt_block<BN>(al, bl, M, Cout, K, blockIdx.x, blockIdx.y, ep, sm);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ dY, ConvKMajorLoader bl,
+                                                            float* __restrict__ slab, int M, int Cout, int NC,
+                                                            int k_per) {
+  __shared__ TnSmem<WM, WN> sm;
+  PlainKMajorLoader<true> al{dY, Cout, Cout, M};
+  const int kb = blockIdx.z * k_per;
+  const int ke = min(M, kb + k_per);
+  tn_block<WM, WN>(al, bl, Cout, NC, kb, ke, blockIdx.x, blockIdx.y, slab + (long)blockIdx.z * Cout * NC, NC, 0, sm);
+}
+
+// dW_oihw[co][ci][tap] = sum_z slab[z][co][tap*Cin + ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, float* __restrict__ dW, int Cout,
+                                    int Cin) {
+  const long total = (long)Cout * 9 * Cin;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int z = 0; z < nsplit; ++z) acc += slab[z * total + i];
+    const int co = (int)(i / (9 * Cin)), rem = (int)(i % (9 * Cin));
+    const int tap = rem / Cin, ci = rem % Cin;
+    dW[((long)co * Cin + ci) * 9 + tap] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ weight repacks
+// fwd:  Wf[co][tap*Cin + ci] = W[co][ci][tap];   dgrad: Wd[ci][tap'*Cout + co] = W[co][ci][8 - tap']
+__global__ void repack_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wf, int Cout, int Cin) {
+  const long total = (long)Cout * Cin * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i / (9 * Cin)), rem = (int)(i % (9 * Cin));
+    const int tap = rem / Cin, ci = rem % Cin;
+    Wf[i] = W[((long)co * Cin + ci) * 9 + tap];
+  }
+}
+__global__ void repack_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Cin) {
+  const long total = (long)Cout * Cin * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / (9 * Cout)), rem = (int)(i % (9 * Cout));
+    const int tp = rem / Cout, co = rem % Cout;
+    Wd[i] = W[((long)co * Cin + ci) * 9 + (8 - tp)];
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm statistics
+// bn0 (models/encoder.py:679-681: BatchNorm2d(64) over the mel axis): per-mel sums over all (clip, frame).
+__global__ __launch_bounds__(256) void bn0_stats_kernel(const float* __restrict__ x, float* __restrict__ partials,
+                                                        long rows, int F, int rows_per_block) {
+  __shared__ float red[2][4][64];
+  const int w = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  float s = 0.f, q = 0.f;
+  if (w < F)
+    for (long r = r0 + g; r < r0 + rows_per_block && r < rows; r += 4) {
+      const float v = x[r * F + w];
+      s += v; q += v * v;
+    }
+  red[0][g][w] = s; red[1][g][w] = q;
+  __syncthreads();
+  if (threadIdx.x < 64 && w < F) {
+    float* out = partials + (long)blockIdx.x * 2 * F;
+    out[w] = red[0][0][w] + red[0][1][w] + red[0][2][w] + red[0][3][w];
+    out[F + w] = red[1][0][w] + red[1][1][w] + red[1][2][w] + red[1][3][w];
+  }
+}
+
+// partials [P][2][C] -> batch mean / biased var (fp64 combine), scale/shift for the fused act, running stats
+// (momentum 0.1, unbiased var: torch BatchNorm2d).  eval mode: scale/shift from the running stats.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partials, int P, int C,
+                                                           double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* running_mean,
+                                                           float* running_var, int64_t* nbt, int training,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  __shared__ double rs[16][64], rq[16][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    if (c < C)
+      for (int p = g; p < P; p += 16) {
+        s += (double)partials[(long)p * 2 * C + c];
+        q += (double)partials[(long)p * 2 * C + C + c];
+      }
+    rs[g][cl] = s; rq[g][cl] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+      for (int i = 1; i < 16; ++i) { s += rs[i][cl]; q += rq[i][cl]; }
+      const double mean = s / count;
+      double var = q / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+      const float sc = gamma[c] * invstd;
+      scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
+      mean_out[c] = (float)mean; invstd_out[c] = invstd;
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)mean;
+      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
+      if (c == 0 && nbt) nbt[0] += 1;
+    }
+  } else if (g == 0 && c < C) {
+    const float invstd = 1.0f / sqrtf(running_var[c] + 1e-5f);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc; shift[c] = beta[c] - running_mean[c] * sc;
+    mean_out[c] = running_mean[c]; invstd_out[c] = invstd;
+  }
+}
+
+// ------------------------------------------------------------------ first conv (Cin = 1), direct
+// Y[n,t,w,co] = sum_tap W1[co][tap] * xin(t+dy, w+dx),  xin = x*scale0[w] + shift0[w] inside the image.
+// Block = RB time rows of one clip; 256 threads = 16 pixels x 16 cout-quads per pass.
+constexpr int C1_RB = 4;
+__global__ __launch_bounds__(256) void conv1_first_fwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ scale0,
+                                                              const float* __restrict__ shift0,
+                                                              const float* __restrict__ W1, float* __restrict__ Y,
+                                                              float* __restrict__ partials, int T, int F) {
+  __shared__ float wl[64 * 9];
+  __shared__ float patch[(C1_RB + 2) * 66];
+  __shared__ float red[2][16][64];
+  const int nblk_t = (T + C1_RB - 1) / C1_RB;
+  const int n = blockIdx.x / nblk_t, t0 = (blockIdx.x % nblk_t) * C1_RB;
+  for (int i = threadIdx.x; i < 64 * 9; i += 256) wl[i] = W1[i];
+  for (int i = threadIdx.x; i < (C1_RB + 2) * 66; i += 256) {
+    const int r = i / 66, cidx = i % 66;
+    const int t = t0 + r - 1, w = cidx - 1;
+    float v = 0.f;
+    if (t >= 0 && t < T && w >= 0 && w < F) v = x[((long)n * T + t) * F + w] * scale0[w] + shift0[w];
+    patch[i] = v;
+  }
+  __syncthreads();
+  const int cq = threadIdx.x & 15, pp = threadIdx.x >> 4;
+  float wreg[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wreg[c][k] = wl[(cq * 4 + c) * 9 + k];
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  for (int pix = pp; pix < C1_RB * 64; pix += 16) {
+    const int r = pix >> 6, w = pix & 63;
+    const int t = t0 + r;
+    if (t >= T || w >= F) continue;
+    float in[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) in[k] = patch[(r + k / 3) * 66 + w + k % 3];
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a += wreg[c][k] * in[k];
+      o[c] = a; s[c] += a; q[c] += a * a;
+    }
+    *reinterpret_cast<float4*>(Y + (((long)n * T + t) * F + w) * 64 + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { red[0][pp][cq * 4 + c] = s[c]; red[1][pp][cq * 4 + c] = q[c]; }
+  __syncthreads();
+  if (partials && threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, co = threadIdx.x & 63;
+    float a = 0.f;
+    for (int i = 0; i < 16; ++i) a += red[which][i][co];
+    partials[(long)blockIdx.x * 128 + which * 64 + co] = a;
+  }
+}
+
+// Backward of the first conv: dW1 partials [blocks][64*9] and bn0 grad partials [blocks][2][64]
+// (sum over pixels of dxin and dxin*xhat per mel bin), dxin[q] = sum_tap D[q - tap][tap],
+// D[p][tap] = sum_co dY[p][co] * W1[co][tap].
+__global__ __launch_bounds__(256) void conv1_first_bwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ scale0,
+                                                              const float* __restrict__ shift0,
+                                                              const float* __restrict__ mean0,
+                                                              const float* __restrict__ invstd0,
+                                                              const float* __restrict__ W1,
+                                                              const float* __restrict__ dY,
+                                                              float* __restrict__ dw_part, float* __restrict__ bn_part,
+                                                              int T, int F) {
+  __shared__ float wl[64 * 9];
+  __shared__ float patch[(C1_RB + 2) * 66];
+  __shared__ float D[(C1_RB + 2) * 64 * 9];
+  __shared__ float wacc[16][16 * 36];
+  const int nblk_t = (T + C1_RB - 1) / C1_RB;
+  const int n = blockIdx.x / nblk_t, t0 = (blockIdx.x % nblk_t) * C1_RB;
+  for (int i = threadIdx.x; i < 64 * 9; i += 256) wl[i] = W1[i];
+  for (int i = threadIdx.x; i < (C1_RB + 2) * 66; i += 256) {
+    const int r = i / 66, cidx = i % 66;
+    const int t = t0 + r - 1, w = cidx - 1;
+    float v = 0.f;
+    if (t >= 0 && t < T && w >= 0 && w < F) v = x[((long)n * T + t) * F + w] * scale0[w] + shift0[w];
+    patch[i] = v;
+  }
+  __syncthreads();
+  const int cq = threadIdx.x & 15, pp = threadIdx.x >> 4;
+  float wreg[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wreg[c][k] = wl[(cq * 4 + c) * 9 + k];
+  float dwacc[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwacc[c][k] = 0.f;
+  // rows t0-1 .. t0+RB (halo rows contribute to D only)
+  for (int pix = pp; pix < (C1_RB + 2) * 64; pix += 16) {
+    const int r = pix >> 6, w = pix & 63;
+    const int t = t0 + r - 1;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool inimg = (t >= 0 && t < T && w < F);
+    if (inimg) g = *reinterpret_cast<const float4*>(dY + (((long)n * T + t) * F + w) * 64 + cq * 4);
+    const float gv[4] = {g.x, g.y, g.z, g.w};
+    float d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = gv[0] * wreg[0][k] + gv[1] * wreg[1][k] + gv[2] * wreg[2][k] + gv[3] * wreg[3][k];
+    // reduce over the 16 cout-quads (16 consecutive lanes)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      float v = d[k];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      d[k] = v;
+    }
+    if (cq == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) D[(r * 64 + w) * 9 + k] = d[k];
+    }
+    if (inimg && r >= 1 && r <= C1_RB) {  // own rows: weight gradient
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float in = patch[(r - 1 + k / 3) * 66 + w + k % 3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dwacc[c][k] += gv[c] * in;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[pp][cq * 36 + c * 9 + k] = dwacc[c][k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 576; i += 256) {
+    float a = 0.f;
+    for (int j = 0; j < 16; ++j) a += wacc[j][i];
+    dw_part[(long)blockIdx.x * 576 + i] = a;   // index = co*9 + tap (cq*36 + c*9 + k)
+  }
+  // dxin for own pixels and the per-mel reductions
+  const int w = threadIdx.x & 63, rr = threadIdx.x >> 6;
+  float sg = 0.f, sgx = 0.f;
+  if (w < F)
+    for (int r = rr; r < C1_RB; r += 4) {
+      const int t = t0 + r;
+      if (t >= T) break;
+      float dx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        // Y[p] uses xin[p + (dy,dx)], so dxin[q] += D[q - (dy,dx)][tap]
+        const int dy = k / 3 - 1, dxx = k % 3 - 1;
+        const int pr = r + 1 - dy, pw2 = w - dxx;
+        if (pw2 >= 0 && pw2 < 64) dx += D[(pr * 64 + pw2) * 9 + k];
+      }
+      const float xhat = (x[((long)n * T + t) * F + w] - mean0[w]) * invstd0[w];
+      sg += dx; sgx += dx * xhat;
+    }
+  __syncthreads();
+  float* rb = wacc[0];
+  rb[rr * 128 + w] = sg; rb[rr * 128 + 64 + w] = sgx;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, ww = threadIdx.x & 63;
+    bn_part[(long)blockIdx.x * 128 + which * 64 + ww] =
+        rb[0 * 128 + which * 64 + ww] + rb[1 * 128 + which * 64 + ww] + rb[2 * 128 + which * 64 + ww] +
+        rb[3 * 128 + which * 64 + ww];
+  }
+}
+
+// out[i] = sum_p partials[p][i]  (fp64 combine, fixed order), i < width; optional scale
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partials, int P, int width,
+                                                     float* __restrict__ out, float* __restrict__ out2, int split) {
+  __shared__ double red[4][64];
+  const int il = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  double a = 0.0;
+  if (i < width)
+    for (int p = g; p < P; p += 4) a += (double)partials[(long)p * width + i];
+  red[g][il] = a;
+  __syncthreads();
+  if (g == 0 && i < width) {
+    a = red[0][il] + red[1][il] + red[2][il] + red[3][il];
+    // split > 0: first `split` entries go to out, the rest to out2 (bn partials [2][C]: dbeta | dgamma)
+    if (split > 0 && i >= split) out2[i - split] = (float)a;
+    else out[i] = (float)a;
+  }
+}
+
+// ------------------------------------------------------------------ BN + ReLU + 2x2 avg-pool + dropout
+__device__ __forceinline__ float4 bnrelu4(float4 v, float4 sc, float4 sh) {
+  return make_float4(fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f), fmaxf(v.z * sc.z + sh.z, 0.f),
+                     fmaxf(v.w * sc.w + sh.w, 0.f));
+}
+// keep-multiplier (0 or 1/(1-p)) for the 4 channels of pooled element (n,ho,wo,c4*4..+3)
+__device__ __forceinline__ float4 drop4(const DropoutSpec& d, long idx4, int n, int ho, int wo, int c, int Ho, int Wo,
+                                        int C) {
+  if (d.p <= 0.f) return make_float4(1.f, 1.f, 1.f, 1.f);
+  const float k = 1.0f / (1.0f - d.p);
+  if (d.mask) {  // explicit mask in the reference's NCHW order (parity tests)
+    const long b = (((long)n * C + c) * Ho + ho) * Wo + wo;
+    const long cs = (long)Ho * Wo;
+    return make_float4(d.mask[b] ? k : 0.f, d.mask[b + cs] ? k : 0.f, d.mask[b + 2 * cs] ? k : 0.f,
+                       d.mask[b + 3 * cs] ? k : 0.f);
+  }
+  const uint4 r = philox4x32(d.seed, (uint64_t)idx4, d.site);
+  const float u = 1.0f / 16777216.0f;
+  return make_float4((float)(r.x >> 8) * u >= d.p ? k : 0.f, (float)(r.y >> 8) * u >= d.p ? k : 0.f,
+                     (float)(r.z >> 8) * u >= d.p ? k : 0.f, (float)(r.w >> 8) * u >= d.p ? k : 0.f);
+}
+
+__global__ void bn_relu_pool_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float* __restrict__ P, int N, int H, int W, int C,
+                                    DropoutSpec drop) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+    const float* y = Y + ((((long)n * H + 2 * ho) * W + 2 * wo) * C + c4 * 4);
+    const float4 a = bnrelu4(*reinterpret_cast<const float4*>(y), sc, sh);
+    const float4 b = bnrelu4(*reinterpret_cast<const float4*>(y + C), sc, sh);
+    const float4 c = bnrelu4(*reinterpret_cast<const float4*>(y + (long)W * C), sc, sh);
+    const float4 d = bnrelu4(*reinterpret_cast<const float4*>(y + (long)W * C + C), sc, sh);
+    const float4 m = drop4(drop, i, n, ho, wo, c4 * 4, Ho, Wo, C);
+    // F.avg_pool2d then F.dropout: (sum * 0.25) * mask * 1/(1-p)
+    float4 o;
+    o.x = ((a.x + b.x + c.x + d.x) * 0.25f) * m.x; o.y = ((a.y + b.y + c.y + d.y) * 0.25f) * m.y;
+    o.z = ((a.z + b.z + c.z + d.z) * 0.25f) * m.z; o.w = ((a.w + b.w + c.w + d.w) * 0.25f) * m.w;
+    reinterpret_cast<float4*>(P)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ BN backward
+// g = relu'(bn(Y)) * upstream;  POOL: upstream = dP[n,h/2,w/2,c] * dropmask * 0.25 (0 for a trailing odd row/col)
+template <bool POOL>
+__device__ __forceinline__ float4 upstream4(const float* __restrict__ dO, const DropoutSpec& drop, int n, int h, int w,
+                                            int c, int H, int W, int C) {
+  if (!POOL) return *reinterpret_cast<const float4*>(dO + ((((long)n * H + h) * W + w) * C + c));
+  const int Ho = H / 2, Wo = W / 2;
+  const int ho = h >> 1, wo = w >> 1;
+  if (ho >= Ho || wo >= Wo) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const long i4 = ((((long)n * Ho + ho) * Wo + wo) * C + c) >> 2;
+  float4 v = reinterpret_cast<const float4*>(dO)[i4];
+  const float4 m = drop4(drop, i4, n, ho, wo, c, Ho, Wo, C);
+  v.x *= m.x * 0.25f; v.y *= m.y * 0.25f; v.z *= m.z * 0.25f; v.w *= m.w * 0.25f;
+  return v;
+}
+
+// partials [blocks][2][C]: sum g | sum g*yhat.  Block = 256 threads = (C/4) channel-quads x (1024/C) pixels.
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ Y, const float* __restrict__ dO,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ partials, int N, int H, int W, int C,
+                                                            int pix_per_block, DropoutSpec drop) {
+  extern __shared__ float red[];  // [256][8]
+  const int C4 = C / 4;
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
+  const long M = (long)N * H * W;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  const int c = cq * 4;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (pl < npl) {
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    for (long p = p0 + pl; p < p0 + pix_per_block && p < M; p += npl) {
+      const int w = (int)(p % W);
+      const long t = p / W;
+      const int h = (int)(t % H), n = (int)(t / H);
+      const float4 y = *reinterpret_cast<const float4*>(Y + p * C + c);
+      float4 g = upstream4<POOL>(dO, drop, n, h, w, c, H, W, C);
+      if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
+      if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
+      if (y.z * sc.z + sh.z <= 0.f) g.z = 0.f;
+      if (y.w * sc.w + sh.w <= 0.f) g.w = 0.f;
+      s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+      q[0] += g.x * ((y.x - mu.x) * is.x); q[1] += g.y * ((y.y - mu.y) * is.y);
+      q[2] += g.z * ((y.z - mu.z) * is.z); q[3] += g.w * ((y.w - mu.w) * is.w);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[threadIdx.x * 8 + k] = s[k]; red[threadIdx.x * 8 + 4 + k] = q[k]; }
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < npl; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += red[(j * C4 + threadIdx.x) * 8 + k];
+    float* out = partials + (long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { out[c + k] = a[k]; out[C + c + k] = a[4 + k]; }
+  }
+}
+
+// dY = scale * (g - sum_g/n - yhat * sum_gy/n)      (scale = gamma * invstd)
+template <bool POOL>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ Y, const float* __restrict__ dO,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ sum_g, const float* __restrict__ sum_gy,
+                                    float* __restrict__ dYout, int N, int H, int W, int C, DropoutSpec drop) {
+  const int C4 = C / 4;
+  const long total = (long)N * H * W * C4;
+  const float invn = 1.0f / (float)((long)N * H * W);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long p = i / C4;
+    const int w = (int)(p % W);
+    const long t = p / W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 sg = *reinterpret_cast<const float4*>(sum_g + c), sgy = *reinterpret_cast<const float4*>(sum_gy + c);
+    const float4 y = reinterpret_cast<const float4*>(Y)[i];
+    float4 g = upstream4<POOL>(dO, drop, n, h, w, c, H, W, C);
+    if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
+    if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
+    if (y.z * sc.z + sh.z <= 0.f) g.z = 0.f;
+    if (y.w * sc.w + sh.w <= 0.f) g.w = 0.f;
+    float4 o;
+    o.x = sc.x * (g.x - sg.x * invn - ((y.x - mu.x) * is.x) * (sgy.x * invn));
+    o.y = sc.y * (g.y - sg.y * invn - ((y.y - mu.y) * is.y) * (sgy.y * invn));
+    o.z = sc.z * (g.z - sg.z * invn - ((y.z - mu.z) * is.z) * (sgy.z * invn));
+    o.w = sc.w * (g.w - sg.w * invn - ((y.w - mu.w) * is.w) * (sgy.w * invn));
+    reinterpret_cast<float4*>(dYout)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ encoder tail
+// audio_embeds[n,s,c] = mean_f P4[n,s,f,c]  (torch.mean(x, dim=3), encoder.py:691)
+__global__ void freq_mean_kernel(const float* __restrict__ P, float* __restrict__ out, long rows, int Fp, int C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i % C);
+    float a = 0.f;
+    for (int f = 0; f < Fp; ++f) a += P[(r * Fp + f) * C + c];
+    out[i] = a / (float)Fp;
+  }
+}
+// dP4[n,s,f,c] = d_ae[n,s,c] / Fp
+__global__ void freq_mean_bwd_kernel(const float* __restrict__ dae, float* __restrict__ dP, long rows, int Fp, int C) {
+  const long total = rows * Fp * C;
+  const float k = 1.0f / (float)Fp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / ((long)Fp * C);
+    dP[i] = dae[r * C + c] * k;
+  }
+}
+// pooled_in[n,c] = dropout(max_s ae + mean_s ae)   (encoder.py:693-696, unmasked over s)
+__global__ void time_pool_kernel(const float* __restrict__ ae, float* __restrict__ out, int N, int S, int C,
+                                 DropoutSpec drop) {
+  const int total = N * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i / C, c = i % C;
+    float mx = -INFINITY, sm = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float v = ae[((long)n * S + s) * C + c];
+      mx = fmaxf(mx, v); sm += v;
+    }
+    float o = mx + sm / (float)S;
+    if (drop.p > 0.f) {
+      const float k = 1.0f / (1.0f - drop.p);
+      const bool keep = drop.mask ? drop.mask[i] != 0 : dropout_keep(drop.seed, drop.site, (uint64_t)i, drop.p);
+      o = keep ? o * k : 0.f;
+    }
+    out[i] = o;
+  }
+}
+__global__ void relu_dropout_kernel(float* __restrict__ x, int total, DropoutSpec drop) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float o = fmaxf(x[i], 0.f);
+    if (drop.p > 0.f) {
+      const float k = 1.0f / (1.0f - drop.p);
+      const bool keep = drop.mask ? drop.mask[i] != 0 : dropout_keep(drop.seed, drop.site, (uint64_t)i, drop.p);
+      o = keep ? o * k : 0.f;
+    }
+    x[i] = o;
+  }
+}
+
+inline int ew_grid(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+// =============================================================================================
+// host-side launchers (C++ internal API, declared in conv.h)
+// =============================================================================================
+namespace acvae {
+
+int conv3x3_igemm(const float* X, const float* scale, const float* shift, const float* Wp, float* Y, float* partials,
+                  int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  if (!X || !Wp || !Y) return ACVAE_EINVAL;
+  if (Cin % 32 != 0 || Cout % 4 != 0) return ACVAE_EUNSUPPORTED;
+  if (!aligned16(X) || !aligned16(Wp) || !aligned16(Y)) return ACVAE_EALIGN;
+  const int M = N * H * W, K = 9 * Cin;
+  ConvRowLoader al{X, scale, shift, H, W, Cin, M};
+  ConvStatsEpilogue ep{Y, partials, Cout};
+  if (Cout <= 64) {
+    dim3 grid(cdiv(M, BM), cdiv(Cout, 64));
+    hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(NT_THREADS), 0, st, al, Wp, ep, M, Cout, K);
+  } else {
+    dim3 grid(cdiv(M, BM), cdiv(Cout, 128));
+    hipLaunchKernelGGL(conv_igemm_kernel<128>, grid, dim3(NT_THREADS), 0, st, al, Wp, ep, M, Cout, K);
+  }
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, BM); }
+
+static int wgrad_splits(int M, int Cout, int NC) {
+  const bool narrow = Cout <= 64;
+  const long tiles = (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
+  int s = (int)(2048 / tiles);
+  const int maxs = cdiv(M, 16 * BKT);
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  return s;
+}
+long conv3x3_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout) {
+  return (long)wgrad_splits(N * H * W, Cout, 9 * Cin) * Cout * 9 * Cin;
+}
+int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
+                  int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  if (!dY || !X || !dW_oihw || !slab) return ACVAE_EINVAL;
+  if (Cin % 4 != 0 || Cout % 4 != 0) return ACVAE_EUNSUPPORTED;
+  const int M = N * H * W, NC = 9 * Cin;
+  int s = wgrad_splits(M, Cout, NC);
+  const int k_per = cdiv(cdiv(M, s), BKT) * BKT;
+  s = cdiv(M, k_per);
+  ConvKMajorLoader bl{X, scale, shift, H, W, Cin, M, NC};
+  if (Cout <= 64) {
+    dim3 grid(cdiv(Cout, 64), cdiv(NC, 256), s);
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
+  } else {
+    dim3 grid(cdiv(Cout, 128), cdiv(NC, 128), s);
+    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((long)Cout * NC)), dim3(256), 0, st, slab, s, dW_oihw, Cout,
+                     Cin);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+int repack_weights(const float* W_oihw, float* Wf, float* Wd, int Cout, int Cin, hipStream_t st) {
+  const long total = (long)Cout * Cin * 9;
+  if (Wf) hipLaunchKernelGGL(repack_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W_oihw, Wf, Cout, Cin);
+  if (Wd) hipLaunchKernelGGL(repack_dgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W_oihw, Wd, Cout, Cin);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hipStream_t st) {
+  if (F > 64) return ACVAE_EUNSUPPORTED;
+  const int rpb = 256;
+  const int nb = cdiv(rows, rpb);
+  hipLaunchKernelGGL(bn0_stats_kernel, dim3(nb), dim3(256), 0, st, x, partials, rows, F, rpb);
+  *nparts = nb;
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int bn0_partials_rows(long rows) { return cdiv(rows, 256); }
+
+int bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, int64_t* nbt, int training, float* scale, float* shift,
+                float* mean, float* invstd, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, partials, P, C, count, gamma, beta,
+                     running_mean, running_var, nbt, training, scale, shift, mean, invstd);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+int conv1_first_blocks(int N, int T) { return N * cdiv(T, C1_RB); }
+int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, float* Y,
+                    float* partials, int N, int T, int F, hipStream_t st) {
+  if (F != 64) return ACVAE_EUNSUPPORTED;
+  hipLaunchKernelGGL(conv1_first_fwd_kernel, dim3(conv1_first_blocks(N, T)), dim3(256), 0, st, x, scale0, shift0, W1, Y,
+                     partials, T, F);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
+                    const float* W1, const float* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
+                    float* dbeta0, int N, int T, int F, hipStream_t st) {
+  if (F != 64) return ACVAE_EUNSUPPORTED;
+  const int nb = conv1_first_blocks(N, T);
+  hipLaunchKernelGGL(conv1_first_bwd_kernel, dim3(nb), dim3(256), 0, st, x, scale0, shift0, mean0, invstd0, W1, dY,
+                     dw_part, bn_part, T, F);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(576, 64)), dim3(256), 0, st, dw_part, nb, 576, dW1, (float*)nullptr, 0);
+  // bn0: y = xhat*gamma + beta with xin = scale0*x + shift0  ->  dbeta = sum dxin, dgamma = sum dxin*xhat
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(128, 64)), dim3(256), 0, st, bn_part, nb, 128, dbeta0, dgamma0, 64);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* P, int N, int H, int W, int C,
+                 DropoutSpec drop, hipStream_t st) {
+  const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+  if (total <= 0) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, 512); }
+int bn_bwd(const float* Y, const float* dO, bool pool, const float* scale, const float* shift, const float* mean,
+           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, int N, int H, int W, int C,
+           DropoutSpec drop, hipStream_t st) {
+  if (C % 4 != 0 || C > 1024 || 1024 % C != 0) return ACVAE_EUNSUPPORTED;
+  const int nb = bn_bwd_blocks(N, H, W);
+  const size_t shm = 256 * 8 * sizeof(float);
+  if (pool)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), shm, st, Y, dO, scale, shift, mean, invstd,
+                       partials, N, H, W, C, 512, drop);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), shm, st, Y, dO, scale, shift, mean, invstd,
+                       partials, N, H, W, C, 512, drop);
+  // sum_g (= dbeta) | sum_gy (= dgamma)
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(2 * C, 64)), dim3(256), 0, st, partials, nb, 2 * C, sum_g, sum_gy, C);
+  const long total = (long)N * H * W * (C / 4);
+  if (pool)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,
+                       invstd, sum_g, sum_gy, dY, N, H, W, C, drop);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,
+                       invstd, sum_g, sum_gy, dY, N, H, W, C, drop);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+int freq_mean(const float* P, float* out, long rows, int Fp, int C, hipStream_t st) {
+  hipLaunchKernelGGL(freq_mean_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, st, P, out, rows, Fp, C);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int freq_mean_bwd(const float* dae, float* dP, long rows, int Fp, int C, hipStream_t st) {
+  hipLaunchKernelGGL(freq_mean_bwd_kernel, dim3(ew_grid(rows * Fp * C)), dim3(256), 0, st, dae, dP, rows, Fp, C);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int time_pool(const float* ae, float* out, int N, int S, int C, DropoutSpec drop, hipStream_t st) {
+  hipLaunchKernelGGL(time_pool_kernel, dim3(ew_grid((long)N * C)), dim3(256), 0, st, ae, out, N, S, C, drop);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int relu_dropout(float* x, int total, DropoutSpec drop, hipStream_t st) {
+  hipLaunchKernelGGL(relu_dropout_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, total, drop);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+}  // namespace acvae

@@ -1,0 +1,233 @@
+// Composite driver for A1 Cnn10.forward (models/encoder.py:672-707) and its backward: sequences the
+// kernels of conv.hip / gemm.hip on one stream with no host synchronisation.  All memory is supplied by
+// the caller: `saved` keeps what the backward needs (raw conv outputs, pooled tensors, BN statistics,
+// repacked weights), `scratch` is reusable within a call.
+#include "common.h"
+#include "conv.h"
+#include "../../include/acvae_hip.h"
+
+namespace {
+
+constexpr int kChan[5] = {1, 64, 128, 256, 512};
+
+struct EncLayout {
+  int N, T, F;
+  int H[5], W[5];              // conv spatial dims of block b (1..4); [0] unused
+  long y1[5], y2[5], p[5];     // float offsets into `saved`
+  long wf1[5], wf2[5];
+  long bn[9];                  // each: 4*C floats (scale, shift, mean, invstd); 0 = bn0, 1+2*(b-1)+{0,1} = block b bn1/bn2
+  long pooled_in;
+  long total;
+  // scratch
+  long s_partials, s_dya, s_dyb, s_dpa, s_dpb, s_wd, s_slab, s_bnpart, s_c1w, s_c1b, s_total;
+};
+
+long align4(long x) { return (x + 63) & ~63L; }
+
+int make_layout(int N, int T, int F, EncLayout& L) {
+  if (N <= 0 || F != 64 || T < 16) return ACVAE_EINVAL;
+  L.N = N; L.T = T; L.F = F;
+  long off = 0;
+  int h = T, w = F;
+  long max_act = 0, max_pool = 0, max_part = 0, max_slab = 0, max_bnpart = 0;
+  for (int b = 1; b <= 4; ++b) {
+    L.H[b] = h; L.W[b] = w;
+    const long act = (long)N * h * w * kChan[b];
+    const long pool = (long)N * (h / 2) * (w / 2) * kChan[b];
+    L.y1[b] = off; off = align4(off + act);
+    L.y2[b] = off; off = align4(off + act);
+    L.p[b] = off; off = align4(off + pool);
+    L.wf1[b] = off; off = align4(off + (long)kChan[b] * 9 * kChan[b - 1]);
+    L.wf2[b] = off; off = align4(off + (long)kChan[b] * 9 * kChan[b]);
+    if (act > max_act) max_act = act;
+    if (pool > max_pool) max_pool = pool;
+    const long part = (long)acvae::conv_partials_rows(N, h, w) * 2 * kChan[b];
+    if (part > max_part) max_part = part;
+    long sl = acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b], kChan[b]);
+    if (sl > max_slab) max_slab = sl;
+    if (b > 1) {
+      sl = acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b - 1], kChan[b]);
+      if (sl > max_slab) max_slab = sl;
+    }
+    const long bp = (long)acvae::bn_bwd_blocks(N, h, w) * 2 * kChan[b];
+    if (bp > max_bnpart) max_bnpart = bp;
+    h /= 2; w /= 2;
+  }
+  L.H[0] = h; L.W[0] = w;  // S and F' after the last pool
+  for (int i = 0; i < 9; ++i) {
+    const int C = i == 0 ? 64 : kChan[(i - 1) / 2 + 1];
+    L.bn[i] = off; off = align4(off + 4L * C);
+  }
+  L.pooled_in = off; off = align4(off + (long)N * 512);
+  L.total = off;
+  // scratch
+  const long c1 = (long)acvae::conv1_first_blocks(N, T) * 128;
+  const long b0 = (long)acvae::bn0_partials_rows((long)N * T) * 128;
+  if (c1 > max_part) max_part = c1;
+  if (b0 > max_part) max_part = b0;
+  long s = 0;
+  L.s_partials = s; s = align4(s + max_part);
+  L.s_bnpart = s; s = align4(s + max_bnpart);
+  L.s_wd = s; s = align4(s + 512L * 9 * 512);
+  L.s_slab = s; s = align4(s + max_slab);
+  L.s_c1w = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 576);
+  L.s_c1b = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 128);
+  L.s_dpa = s; s = align4(s + max_pool);
+  L.s_dpb = s; s = align4(s + max_pool);
+  L.s_dya = s; s = align4(s + max_act);
+  L.s_dyb = s; s = align4(s + max_act);
+  L.s_total = s;
+  return ACVAE_OK;
+}
+
+// parameter table order == state-dict order of the reference's Cnn10 (see include/acvae_hip.h)
+inline int p_bn0(int k) { return k; }                                  // w, b, rm, rv, nbt
+inline int p_conv(int b, int which) { return 5 + (b - 1) * 12 + (which - 1); }
+inline int p_bn(int b, int which, int k) { return 5 + (b - 1) * 12 + 2 + (which - 1) * 5 + k; }
+constexpr int P_EMBED_W = 53, P_EMBED_B = 54;
+
+struct BnPtrs { float *scale, *shift, *mean, *invstd; };
+inline BnPtrs bn_at(float* saved, const EncLayout& L, int i) {
+  const int C = i == 0 ? 64 : kChan[(i - 1) / 2 + 1];
+  float* b = saved + L.bn[i];
+  return {b, b + C, b + 2 * C, b + 3 * C};
+}
+
+inline DropoutSpec dspec(float p, const uint8_t* const* masks, uint64_t seed, int site, int training) {
+  DropoutSpec d;
+  d.p = training ? p : 0.f;
+  d.mask = (masks && training) ? masks[site] : nullptr;
+  d.seed = seed; d.site = (uint32_t)site;
+  return d;
+}
+
+}  // namespace
+
+extern "C" int64_t acvae_encoder_saved_bytes(int N, int T, int F) {
+  EncLayout L;
+  if (make_layout(N, T, F, L) != ACVAE_OK) return -1;
+  return L.total * (int64_t)sizeof(float);
+}
+extern "C" int64_t acvae_encoder_scratch_bytes(int N, int T, int F) {
+  EncLayout L;
+  if (make_layout(N, T, F, L) != ACVAE_OK) return -1;
+  return L.s_total * (int64_t)sizeof(float);
+}
+
+extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, float* audio_embeds, float* pooled,
+                                 void* saved_v, int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N,
+                                 int T, int F, int training, float p_block, float p_fc, uint64_t seed,
+                                 const uint8_t* const* masks, void* stream) {
+  EncLayout L;
+  ACVAE_TRY(make_layout(N, T, F, L));
+  if (!params || !feats || !audio_embeds || !pooled || !saved_v || !scratch_v) return ACVAE_EINVAL;
+  if (saved_bytes < L.total * (int64_t)sizeof(float) || scratch_bytes < L.s_total * (int64_t)sizeof(float))
+    return ACVAE_EWORKSPACE;
+  if (!aligned16(saved_v) || !aligned16(scratch_v) || !aligned16(feats)) return ACVAE_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* saved = (float*)saved_v;
+  float* scratch = (float*)scratch_v;
+  float* partials = scratch + L.s_partials;
+  auto P = [&](int i) { return (float*)params[i]; };
+
+  // bn0 over the mel axis (encoder.py:679-681)
+  BnPtrs b0 = bn_at(saved, L, 0);
+  int nparts = 0;
+  if (training) ACVAE_TRY(acvae::bn0_stats(feats, partials, (long)N * T, F, &nparts, st));
+  ACVAE_TRY(acvae::bn_finalize(partials, nparts, 64, (double)N * T, P(p_bn0(0)), P(p_bn0(1)), P(p_bn0(2)), P(p_bn0(3)),
+                               (int64_t*)params[p_bn0(4)], training, b0.scale, b0.shift, b0.mean, b0.invstd, st));
+  const float* x_in = nullptr;
+  for (int b = 1; b <= 4; ++b) {
+    const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
+    const double cnt = (double)N * H * W;
+    float* Y1 = saved + L.y1[b];
+    float* Y2 = saved + L.y2[b];
+    BnPtrs n1 = bn_at(saved, L, 1 + 2 * (b - 1)), n2 = bn_at(saved, L, 2 + 2 * (b - 1));
+    int np1;
+    if (b == 1) {
+      ACVAE_TRY(acvae::conv1_first_fwd(feats, b0.scale, b0.shift, P(p_conv(1, 1)), Y1, training ? partials : nullptr,
+                                       N, T, F, st));
+      np1 = acvae::conv1_first_blocks(N, T);
+    } else {
+      ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 1)), saved + L.wf1[b], nullptr, C, Cin, st));
+      ACVAE_TRY(acvae::conv3x3_igemm(x_in, nullptr, nullptr, saved + L.wf1[b], Y1, training ? partials : nullptr, N, H,
+                                     W, Cin, C, st));
+      np1 = acvae::conv_partials_rows(N, H, W);
+    }
+    ACVAE_TRY(acvae::bn_finalize(partials, np1, C, cnt, P(p_bn(b, 1, 0)), P(p_bn(b, 1, 1)), P(p_bn(b, 1, 2)),
+                                 P(p_bn(b, 1, 3)), (int64_t*)params[p_bn(b, 1, 4)], training, n1.scale, n1.shift,
+                                 n1.mean, n1.invstd, st));
+    ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), saved + L.wf2[b], nullptr, C, C, st));
+    ACVAE_TRY(acvae::conv3x3_igemm(Y1, n1.scale, n1.shift, saved + L.wf2[b], Y2, training ? partials : nullptr, N, H,
+                                   W, C, C, st));
+    ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_partials_rows(N, H, W), C, cnt, P(p_bn(b, 2, 0)),
+                                 P(p_bn(b, 2, 1)), P(p_bn(b, 2, 2)), P(p_bn(b, 2, 3)), (int64_t*)params[p_bn(b, 2, 4)],
+                                 training, n2.scale, n2.shift, n2.mean, n2.invstd, st));
+    ACVAE_TRY(acvae::bn_relu_pool(Y2, n2.scale, n2.shift, saved + L.p[b], N, H, W, C,
+                                  dspec(p_block, masks, seed, b - 1, training), st));
+    x_in = saved + L.p[b];
+  }
+  const int S = L.H[0], Fp = L.W[0];
+  ACVAE_TRY(acvae::freq_mean(saved + L.p[4], audio_embeds, (long)N * S, Fp, 512, st));
+  // pooled branch (encoder.py:693-698)
+  float* pin = saved + L.pooled_in;
+  ACVAE_TRY(acvae::time_pool(audio_embeds, pin, N, S, 512, dspec(p_fc, masks, seed, 4, training), st));
+  ACVAE_TRY(acvae_gemm_nt_dual(pin, 512, P(P_EMBED_W), 512, 512, nullptr, 0, nullptr, 0, 0, P(P_EMBED_B), pooled, 512,
+                               N, 512, 0, st));
+  ACVAE_TRY(acvae::relu_dropout(pooled, N * 512, dspec(p_fc, masks, seed, 5, training), st));
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
+                                 const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
+                                 int64_t scratch_bytes, int N, int T, int F, float p_block, uint64_t seed,
+                                 const uint8_t* const* masks, void* stream) {
+  EncLayout L;
+  ACVAE_TRY(make_layout(N, T, F, L));
+  if (!params || !grads || !feats || !d_audio_embeds || !saved_v || !scratch_v) return ACVAE_EINVAL;
+  if (saved_bytes < L.total * (int64_t)sizeof(float) || scratch_bytes < L.s_total * (int64_t)sizeof(float))
+    return ACVAE_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* saved = (float*)saved_v;
+  float* scratch = (float*)scratch_v;
+  auto P = [&](int i) { return (float*)params[i]; };
+  auto G = [&](int i) { return (float*)grads[i]; };
+  float* dya = scratch + L.s_dya;
+  float* dyb = scratch + L.s_dyb;
+  float* dp_cur = scratch + L.s_dpa;
+  float* dp_nxt = scratch + L.s_dpb;
+  float* wd = scratch + L.s_wd;
+  float* slab = scratch + L.s_slab;
+  float* bnpart = scratch + L.s_bnpart;
+  const int S = L.H[0], Fp = L.W[0];
+  ACVAE_TRY(acvae::freq_mean_bwd(d_audio_embeds, dp_cur, (long)N * S, Fp, 512, st));
+  for (int b = 4; b >= 1; --b) {
+    const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
+    float* Y1 = saved + L.y1[b];
+    float* Y2 = saved + L.y2[b];
+    BnPtrs n1 = bn_at(saved, L, 1 + 2 * (b - 1)), n2 = bn_at(saved, L, 2 + 2 * (b - 1));
+    // conv2 / bn2 / pool / dropout
+    ACVAE_TRY(acvae::bn_bwd(Y2, dp_cur, true, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
+                            G(p_bn(b, 2, 0)), dya, N, H, W, C, dspec(p_block, masks, seed, b - 1, 1), st));
+    ACVAE_TRY(acvae::conv3x3_wgrad(dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
+    ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), nullptr, wd, C, C, st));
+    ACVAE_TRY(acvae::conv3x3_igemm(dya, nullptr, nullptr, wd, dyb, nullptr, N, H, W, C, C, st));
+    // conv1 / bn1
+    DropoutSpec none{0.f, nullptr, 0, 0};
+    ACVAE_TRY(acvae::bn_bwd(Y1, dyb, false, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
+                            G(p_bn(b, 1, 0)), dya, N, H, W, C, none, st));
+    if (b > 1) {
+      ACVAE_TRY(acvae::conv3x3_wgrad(dya, saved + L.p[b - 1], nullptr, nullptr, G(p_conv(b, 1)), slab, N, H, W, Cin, C,
+                                     st));
+      ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 1)), nullptr, wd, C, Cin, st));
+      ACVAE_TRY(acvae::conv3x3_igemm(dya, nullptr, nullptr, wd, dp_nxt, nullptr, N, H, W, C, Cin, st));
+      float* t = dp_cur; dp_cur = dp_nxt; dp_nxt = t;
+    } else {
+      BnPtrs b0 = bn_at(saved, L, 0);
+      ACVAE_TRY(acvae::conv1_first_bwd(feats, b0.scale, b0.shift, b0.mean, b0.invstd, P(p_conv(1, 1)), dya,
+                                       scratch + L.s_c1w, scratch + L.s_c1b, G(p_conv(1, 1)), G(p_bn0(0)), G(p_bn0(1)),
+                                       N, T, F, st));
+    }
+  }
+  return ACVAE_OK;
+}

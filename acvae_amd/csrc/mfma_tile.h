@@ -35,6 +35,7 @@ struct PlainLoader {
   const float* base;
   long ld;
   int rows, K;
+  __device__ __forceinline__ void init(int) {}
   __device__ __forceinline__ void load(int row0, int kstep, int nrow_iters, float4* regs) const {
     const int c = (threadIdx.x & 7) * 4 + kstep * BK;
 #pragma unroll
@@ -91,8 +92,8 @@ struct PlainEpilogue {
 
 // The block-level mainloop.  ALoader must provide load(row0, kstep, 4, regs).
 template <int BN, class ALoader, class BLoader, class Epilogue>
-__device__ __forceinline__ void nt_block(const ALoader& al, const BLoader& bl, int M, int N, int K, int block_m,
-                                         int block_n, const Epilogue& ep, NtSmem<BN>& sm) {
+__device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, int K, int block_m, int block_n,
+                                         const Epilogue& ep, NtSmem<BN>& sm) {
   constexpr int NTN = BN / 64;  // MFMA tiles per wave along N
   constexpr int BROWS = BN / 32;  // B row iterations per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,6 +111,8 @@ __device__ __forceinline__ void nt_block(const ALoader& al, const BLoader& bl, i
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[4], rb[4];
+  al.init(row0);
+  bl.init(col0);
   const int srow = tid >> 3, scol = (tid & 7) * 4;
   auto stash = [&](int buf) {
 #pragma unroll
@@ -180,6 +183,8 @@ struct PlainKMajorLoader {
   long ld;
   int cols, K;  // cols = M or N extent
   template <int W>
+  __device__ __forceinline__ void init(int) {}
+  template <int W>
   __device__ __forceinline__ void load(int col0, int k0, float4* regs) const {
     constexpr int TPR = W / 4;           // threads per k-row
     constexpr int ROWS_PER_IT = 256 / TPR;
@@ -206,7 +211,7 @@ struct PlainKMajorLoader {
 };
 
 template <int WM, int WN, class ALoader, class BLoader>
-__device__ __forceinline__ void tn_block(const ALoader& al, const BLoader& bl, int M, int N, int k_begin, int k_end,
+__device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, int k_begin, int k_end,
                                          int block_m, int block_n, float* C, long ldc, int accumulate,
                                          TnSmem<WM, WN>& sm) {
   constexpr int TM = 64 * WM, TN_ = 64 * WN;
@@ -226,6 +231,8 @@ __device__ __forceinline__ void tn_block(const ALoader& al, const BLoader& bl, i
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[AITS], rb[BITS];
+  al.template init<TM>(row0);
+  bl.template init<TN_>(col0);
   auto stash = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < AITS; ++it) {

@@ -1,0 +1,166 @@
+"""Audio encoder: mirror of the reference's ``models/encoder.py`` ``Cnn10`` (:651-707) and
+``ConvBlock`` (:606-649) on the HIP path.
+
+Same constructor ``Cnn10(inputdim, embed_size, **kwargs)``, same ``forward(input, lens)`` returning
+``{"audio_embeds", "audio_embeds_pooled", "state", "audio_embeds_lens"}``, same state-dict names and
+shapes (so reference checkpoints load), same initialisation (``init_layer`` / ``init_bn`` :593-604).
+The torch.nn sub-modules are parameter containers only — their ``forward`` is never called; all
+arithmetic runs in libacvae_hip.so (``acvae_encoder_fwd`` / ``acvae_encoder_bwd``).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_SCRATCH = {}
+
+
+def scratch_buffer(nbytes, device):
+    """Grow-only per-device scratch (contents are dead between library calls)."""
+    key = (device.type, device.index)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _SCRATCH[key] = buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return buf
+
+
+def ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def init_layer(layer):
+    """models/encoder.py:593-599"""
+    nn.init.xavier_uniform_(layer.weight)
+    if getattr(layer, "bias", None) is not None:
+        layer.bias.data.fill_(0.)
+
+
+def init_bn(bn):
+    """models/encoder.py:601-604"""
+    bn.bias.data.fill_(0.)
+    bn.weight.data.fill_(1.)
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        init_layer(self.conv1); init_layer(self.conv2); init_bn(self.bn1); init_bn(self.bn2)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("ConvBlock is a parameter container on the HIP path; call Cnn10.forward")
+
+
+def _bn_tensors(bn):
+    return [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+
+
+class _Cnn10Fn(torch.autograd.Function):
+    """One autograd node for the whole encoder: forward and backward are one library call each."""
+
+    @staticmethod
+    def forward(ctx, mod, feats, *weights):
+        _lib.require_cuda(feats)
+        feats = feats.contiguous().float()
+        N, T, F = feats.shape
+        tensors = mod._param_table()
+        dev = feats.device
+        saved_b = _lib.call("acvae_encoder_saved_bytes", N, T, F)
+        scratch_b = _lib.call("acvae_encoder_scratch_bytes", N, T, F)
+        if saved_b < 0:
+            raise RuntimeError(f"Cnn10: unsupported input shape {tuple(feats.shape)} (need F=64, T>=16)")
+        saved = torch.empty(saved_b, dtype=torch.uint8, device=dev)
+        scratch = scratch_buffer(scratch_b, dev)
+        S = T // 16
+        ae = torch.empty(N, S, 512, device=dev)
+        pooled = torch.empty(N, 512, device=dev)
+        training = bool(mod.training)
+        masks = None
+        if training and mod.dropout_masks is not None:
+            masks = [m.to(device=dev, dtype=torch.uint8).contiguous() for m in mod.dropout_masks]
+            if len(masks) != 6:
+                raise ValueError("dropout_masks must hold the 6 masks of Cnn10.forward in call order")
+        seed = mod._next_seed() if training else 0
+        mt = ptr_table(masks) if masks is not None else None
+        _lib.call("acvae_encoder_fwd", ptr_table(tensors), feats, ae, pooled, saved, saved_b, scratch, scratch_b, N, T,
+                  F, int(training), float(mod.p_block), float(mod.p_fc), seed, mt, _lib.current_stream())
+        ctx.mod, ctx.feats, ctx.saved, ctx.masks, ctx.seed = mod, feats, saved, masks, seed
+        ctx.mark_non_differentiable(pooled)
+        return ae, pooled
+
+    @staticmethod
+    def backward(ctx, d_ae, _d_pooled):
+        mod, feats = ctx.mod, ctx.feats
+        N, T, F = feats.shape
+        tensors = mod._param_table()
+        grads = [None] * len(tensors)
+        outs = []
+        for i, t in enumerate(tensors):
+            if t.dtype.is_floating_point and t.requires_grad and i < 53:
+                grads[i] = mod._grad_buffer(t)
+        d_ae = d_ae.contiguous().float()
+        scratch_b = _lib.call("acvae_encoder_scratch_bytes", N, T, F)
+        scratch = scratch_buffer(scratch_b, feats.device)
+        mt = ptr_table(ctx.masks) if ctx.masks is not None else None
+        _lib.call("acvae_encoder_bwd", ptr_table(tensors), ptr_table(grads), feats, d_ae, ctx.saved,
+                  ctx.saved.numel(), scratch, scratch_b, N, T, F, float(mod.p_block), ctx.seed, mt,
+                  _lib.current_stream())
+        ctx.saved = None
+        for w in mod._weights():
+            outs.append(next((g for t, g in zip(tensors, grads) if t is w), None))
+        return (None, None, *outs)
+
+
+class Cnn10(nn.Module):
+    """PANNs CNN10 audio encoder (reference ``models/encoder.py:651-707``)."""
+
+    def __init__(self, inputdim, embed_size, **kwargs):
+        super().__init__()
+        self.inputdim = inputdim          # BaseEncoder attributes
+        self.embed_size = embed_size
+        self.bn0 = nn.BatchNorm2d(64)
+        self.conv_block1 = ConvBlock(1, 64)
+        self.conv_block2 = ConvBlock(64, 128)
+        self.conv_block3 = ConvBlock(128, 256)
+        self.conv_block4 = ConvBlock(256, 512)
+        self.embed_pooled = nn.Linear(512, 512, bias=True)
+        init_bn(self.bn0)
+        init_layer(self.embed_pooled)
+        self.p_block, self.p_fc = 0.2, 0.5      # F.dropout probabilities, encoder.py:684-698
+        self.dropout_masks = None               # optional explicit keep-masks (parity tests)
+        self._seed_base, self._calls = None, 0
+        self._grad_views = None                 # {param: flat-gradient view}, set by the train-step harness
+
+    # ---- plumbing
+    def _param_table(self):
+        t = _bn_tensors(self.bn0)
+        for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4):
+            t += [blk.conv1.weight, blk.conv2.weight] + _bn_tensors(blk.bn1) + _bn_tensors(blk.bn2)
+        t += [self.embed_pooled.weight, self.embed_pooled.bias]
+        return t
+
+    def _weights(self):
+        return [t for t in self._param_table()[:53] if isinstance(t, nn.Parameter)]
+
+    def _grad_buffer(self, p):
+        if self._grad_views is not None and p in self._grad_views:
+            return self._grad_views[p]
+        return torch.empty_like(p)
+
+    def _next_seed(self):
+        if self._seed_base is None:
+            self._seed_base = int(torch.initial_seed()) & 0x7FFFFFFFFFFF
+        self._calls += 1
+        return (self._seed_base * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
+
+    def forward(self, input, lens):
+        """input: [batch, time, 64] log-mel; lens: frame counts (numpy array / list / tensor)."""
+        lens = torch.as_tensor(lens)
+        lens //= 16                       # in place on the caller's array, as the reference does (:677-678)
+        ae, pooled = _Cnn10Fn.apply(self, input, *self._weights())
+        return {"audio_embeds": ae, "audio_embeds_pooled": pooled, "state": None, "audio_embeds_lens": lens}

@@ -105,6 +105,33 @@ int acvae_ls_ce_bwd(const float* logits, int64_t ld_n, int64_t ld_t, const int64
 int acvae_mse_fwd(const float* a, const float* b, float* partials, float* out_scalar, int64_t n, void* stream);
 int acvae_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, float* db, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A1  Cnn10.forward  models/encoder.py:672-707 (ConvBlock :606-649) and its backward.
+ * feats f32 [N,T,F=64] -> audio_embeds f32 [N,S,512] (S = T/16), audio_embeds_pooled f32 [N,512].
+ * `params` / `grads`: pointer tables in the reference's state-dict order for the encoder:
+ *   bn0.{weight,bias,running_mean,running_var,num_batches_tracked},
+ *   conv_block{1..4}.{conv1.weight, conv2.weight, bn1.{w,b,rm,rv,nbt}, bn2.{w,b,rm,rv,nbt}},
+ *   embed_pooled.{weight,bias}                                   (55 entries; weights in OIHW).
+ * training != 0: BatchNorm uses batch statistics and updates the running buffers (momentum 0.1,
+ * unbiased variance) and dropout (p_block after every block, p_fc around embed_pooled) is applied,
+ * drawn from Philox(seed) unless `masks` supplies the 6 keep-masks explicitly (uint8, the reference's
+ * NCHW / [N,512] order: parity tests).  `saved` (acvae_encoder_saved_bytes) carries activations from
+ * fwd to bwd; `scratch` (acvae_encoder_scratch_bytes) is free between calls.  Gradients are WRITTEN
+ * (not accumulated) for every conv / bn weight and bias; embed_pooled receives none (its output is
+ * not consumed on this path, models/vae_model.py:821).
+ * ------------------------------------------------------------------------------------------- */
+#define ACVAE_ENC_NPARAMS 55
+int64_t acvae_encoder_saved_bytes(int N, int T, int F);
+int64_t acvae_encoder_scratch_bytes(int N, int T, int F);
+int acvae_encoder_fwd(const void* const* params, const float* feats, float* audio_embeds, float* pooled,
+                      void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int T, int F,
+                      int training, float p_block, float p_fc, uint64_t seed, const uint8_t* const* masks,
+                      void* stream);
+int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
+                      const float* d_audio_embeds, void* saved, int64_t saved_bytes, void* scratch,
+                      int64_t scratch_bytes, int N, int T, int F, float p_block, uint64_t seed,
+                      const uint8_t* const* masks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,106 @@
+"""GPU parity of the Cnn10 encoder (conv stack on fp32 MFMA, fused BN/ReLU/pool/dropout) against the
+golden vectors generated from the reference (g4) and, for the backward, against autograd through the
+oracle restatement."""
+import numpy as np
+import pytest
+import torch
+
+import acvae_oracle as O
+from acvae_amd.encoder import Cnn10
+from conftest import load_golden, unpack_masks
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, what=""):
+    a = torch.as_tensor(a).detach().cpu().double(); b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    ok = err <= atol + rtol * b.abs()
+    assert bool(ok.all()), f"{what}: max abs err {float(err.max()):.3e} (ref max {float(b.abs().max()):.3e}), " \
+                           f"{int((~ok).sum())}/{ok.numel()} out of tolerance"
+
+
+def make_encoder(full):
+    enc = Cnn10(64, 512)
+    enc.load_state_dict({k[len("encoder."):]: v.clone() for k, v in full.items() if k.startswith("encoder.")})
+    return enc.cuda()
+
+
+def test_g4_encoder_golden():
+    g = load_golden("g4_encoder")
+    full = O.closed_form_state(O.state_shapes(10))
+    for ci in range(int(g["ncases"])):
+        enc = make_encoder(full)
+        enc.train()
+        enc.dropout_masks = unpack_masks(g, f"c{ci}_")
+        lens = g[f"c{ci}_lens"].copy()
+        with torch.no_grad():
+            o = enc(T(g[f"c{ci}_feats"]).cuda(), lens)
+        close(o["audio_embeds"], g[f"c{ci}_train_audio_embeds"], what=f"c{ci} audio_embeds")
+        close(o["audio_embeds_pooled"], g[f"c{ci}_train_pooled"], 1e-4, 1e-4, what=f"c{ci} pooled")
+        assert np.array_equal(o["audio_embeds_lens"].numpy(), g[f"c{ci}_train_lens"])
+        assert np.array_equal(lens, g[f"c{ci}_train_lens"])      # caller's array mutated in place (F11)
+        sd = enc.state_dict()
+        close(sd["bn0.running_mean"], g[f"c{ci}_bn0_running_mean"], what="bn0 rm")
+        close(sd["bn0.running_var"], g[f"c{ci}_bn0_running_var"], what="bn0 rv")
+        close(sd["conv_block4.bn2.running_mean"], g[f"c{ci}_b4bn2_running_mean"], what="b4bn2 rm")
+        close(sd["conv_block4.bn2.running_var"], g[f"c{ci}_b4bn2_running_var"], what="b4bn2 rv")
+        close(sd["conv_block1.bn1.running_var"], g[f"c{ci}_b1bn1_running_var"], what="b1bn1 rv")
+        assert int(sd["bn0.num_batches_tracked"]) == 1
+        enc = make_encoder(full)
+        enc.eval()
+        with torch.no_grad():
+            o = enc(T(g[f"c{ci}_feats"]).cuda(), g[f"c{ci}_lens"].copy())
+        close(o["audio_embeds"], g[f"c{ci}_eval_audio_embeds"], what=f"c{ci} eval audio_embeds")
+        close(o["audio_embeds_pooled"], g[f"c{ci}_eval_pooled"], 1e-4, 1e-4, what=f"c{ci} eval pooled")
+
+
+@pytest.mark.parametrize("B,Tt", [(2, 32), (3, 80), (2, 250)])
+def test_encoder_backward_vs_oracle(B, Tt):
+    full = O.closed_form_state(O.state_shapes(10))
+    g = torch.Generator().manual_seed(B * 100 + Tt)
+    feats = torch.randn(B, Tt, 64, generator=g) * 1.5 + 0.3
+    R = torch.randn(B, Tt // 16, 512, generator=g)
+    # oracle (CPU autograd), recording its dropout masks
+    st = {k: v.clone() for k, v in full.items() if k.startswith("encoder.")}
+    keys = [k for k in O.trainable_keys(st)]
+    for k in keys:
+        st[k].requires_grad_(True)
+    rec = []
+    torch.manual_seed(5)
+    o = O.cnn10_forward(st, feats, [Tt] * B, True, None, rec)
+    (o["audio_embeds"] * R).sum().backward()
+    enc = make_encoder(full)
+    enc.train()
+    enc.dropout_masks = rec
+    out = enc(feats.cuda(), [Tt] * B)
+    close(out["audio_embeds"], o["audio_embeds"], what="fwd")
+    (out["audio_embeds"] * R.cuda()).sum().backward()
+    named = dict(enc.named_parameters())
+    for k in keys:
+        kk = k[len("encoder."):]
+        if kk.startswith("embed_pooled"):
+            assert named[kk].grad is None and st[k].grad is None
+            continue
+        ref = st[k].grad
+        scale = float(ref.abs().max())
+        close(named[kk].grad, ref, rtol=2e-3, atol=2e-4 * max(scale, 1e-3), what=kk)
+
+
+def test_encoder_philox_dropout_statistics():
+    enc = Cnn10(64, 512).cuda()
+    enc.train()
+    x = torch.randn(4, 64, 64).cuda()
+    with torch.no_grad():
+        a = enc(x, [64] * 4)["audio_embeds"]
+        b = enc(x, [64] * 4)["audio_embeds"]
+    assert not torch.equal(a, b)            # fresh Philox seed per call
+    enc.p_block = 0.0
+    with torch.no_grad():
+        c = enc(x, [64] * 4)["audio_embeds"]
+        d = enc(x, [64] * 4)["audio_embeds"]
+    assert torch.equal(c, d)                # deterministic without dropout
+    # dropout keeps the expectation: mean over many elements within a few percent
+    assert abs(float(a.mean()) / float(c.mean()) - 1.0) < 0.05
