@@ -22,19 +22,20 @@ int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hi
 int bn0_partials_rows(long rows);
 int bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, int64_t* nbt, int training, float* scale, float* shift,
-                float* mean, float* invstd, hipStream_t st);
+                float* mean, float* invstd, double* dpart, hipStream_t st);
+long colsum_scratch_doubles(int width);
 int conv1_first_blocks(int N, int T);
 int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, float* Y,
                     float* partials, int N, int T, int F, hipStream_t st);
 int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
                     const float* W1, const float* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
-                    float* dbeta0, int N, int T, int F, hipStream_t st);
+                    float* dbeta0, double* dpart, int N, int T, int F, hipStream_t st);
 int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* P, int N, int H, int W, int C,
                  DropoutSpec drop, hipStream_t st);
 int bn_bwd_blocks(int N, int H, int W);
 int bn_bwd(const float* Y, const float* dO, bool pool, const float* scale, const float* shift, const float* mean,
-           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, int N, int H, int W, int C,
-           DropoutSpec drop, hipStream_t st);
+           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
+           int W, int C, DropoutSpec drop, hipStream_t st);
 int freq_mean(const float* P, float* out, long rows, int Fp, int C, hipStream_t st);
 int freq_mean_bwd(const float* dae, float* dP, long rows, int Fp, int C, hipStream_t st);
 int time_pool(const float* ae, float* out, int N, int S, int C, DropoutSpec drop, hipStream_t st);

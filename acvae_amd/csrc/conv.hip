@@ -229,46 +229,68 @@ __global__ __launch_bounds__(256) void bn0_stats_kernel(const float* __restrict_
   }
 }
 
-// partials [P][2][C] -> batch mean / biased var (fp64 combine), scale/shift for the fused act, running stats
+// Column sums of a [P][width] fp32 partial matrix in two fixed-order stages (deterministic):
+// stage 1: grid (width/64, R) blocks, block r sums rows p = r, r+R, ... in fp64 -> dpart[r][width].
+constexpr int CS_R = 64;
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ partials, int P, int width,
+                                                            double* __restrict__ dpart) {
+  __shared__ double red[4][64];
+  const int il = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  const int R = gridDim.y;
+  double a = 0.0;
+  if (i < width)
+    for (int p = blockIdx.y + g * R; p < P; p += 4 * R) a += (double)partials[(long)p * width + i];
+  red[g][il] = a;
+  __syncthreads();
+  if (g == 0 && i < width) dpart[(long)blockIdx.y * width + i] = red[0][il] + red[1][il] + red[2][il] + red[3][il];
+}
+
+// dpart [R][2][C] -> batch mean / biased var, scale/shift for the fused act, running stats
 // (momentum 0.1, unbiased var: torch BatchNorm2d).  eval mode: scale/shift from the running stats.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partials, int P, int C,
-                                                           double count, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* running_mean,
-                                                           float* running_var, int64_t* nbt, int training,
-                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  __shared__ double rs[16][64], rq[16][64];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ dpart, int R, int C, double count,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* running_mean,
+                                                         float* running_var, int64_t* nbt, int training,
+                                                         float* __restrict__ scale, float* __restrict__ shift,
+                                                         float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
   if (training) {
     double s = 0.0, q = 0.0;
-    if (c < C)
-      for (int p = g; p < P; p += 16) {
-        s += (double)partials[(long)p * 2 * C + c];
-        q += (double)partials[(long)p * 2 * C + C + c];
-      }
-    rs[g][cl] = s; rq[g][cl] = q;
-    __syncthreads();
-    if (g == 0 && c < C) {
-      for (int i = 1; i < 16; ++i) { s += rs[i][cl]; q += rq[i][cl]; }
-      const double mean = s / count;
-      double var = q / count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const float invstd = (float)(1.0 / sqrt(var + 1e-5));
-      const float sc = gamma[c] * invstd;
-      scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
-      mean_out[c] = (float)mean; invstd_out[c] = invstd;
-      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)mean;
-      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
-      if (c == 0 && nbt) nbt[0] += 1;
+    for (int r = 0; r < R; ++r) {
+      s += dpart[(long)r * 2 * C + c];
+      q += dpart[(long)r * 2 * C + C + c];
     }
-  } else if (g == 0 && c < C) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
+    mean_out[c] = (float)mean; invstd_out[c] = invstd;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)mean;
+    running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
+    if (c == 0 && nbt) nbt[0] += 1;
+  } else {
     const float invstd = 1.0f / sqrtf(running_var[c] + 1e-5f);
     const float sc = gamma[c] * invstd;
     scale[c] = sc; shift[c] = beta[c] - running_mean[c] * sc;
     mean_out[c] = running_mean[c]; invstd_out[c] = invstd;
   }
+}
+
+// stage 2 for plain sums: out[i] = sum_r dpart[r][i]; entries >= split go to out2 (bn: dbeta | dgamma)
+__global__ __launch_bounds__(64) void colsum_stage2_kernel(const double* __restrict__ dpart, int R, int width,
+                                                           float* __restrict__ out, float* __restrict__ out2,
+                                                           int split) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= width) return;
+  double a = 0.0;
+  for (int r = 0; r < R; ++r) a += dpart[(long)r * width + i];
+  if (split > 0 && i >= split) out2[i - split] = (float)a;
+  else out[i] = (float)a;
 }
 
 // ------------------------------------------------------------------ first conv (Cin = 1), direct
@@ -435,25 +457,6 @@ __global__ __launch_bounds__(256) void conv1_first_bwd_kernel(const float* __res
     bn_part[(long)blockIdx.x * 128 + which * 64 + ww] =
         rb[0 * 128 + which * 64 + ww] + rb[1 * 128 + which * 64 + ww] + rb[2 * 128 + which * 64 + ww] +
         rb[3 * 128 + which * 64 + ww];
-  }
-}
-
-// out[i] = sum_p partials[p][i]  (fp64 combine, fixed order), i < width; optional scale
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partials, int P, int width,
-                                                     float* __restrict__ out, float* __restrict__ out2, int split) {
-  __shared__ double red[4][64];
-  const int il = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + il;
-  double a = 0.0;
-  if (i < width)
-    for (int p = g; p < P; p += 4) a += (double)partials[(long)p * width + i];
-  red[g][il] = a;
-  __syncthreads();
-  if (g == 0 && i < width) {
-    a = red[0][il] + red[1][il] + red[2][il] + red[3][il];
-    // split > 0: first `split` entries go to out, the rest to out2 (bn partials [2][C]: dbeta | dgamma)
-    if (split > 0 && i >= split) out2[i - split] = (float)a;
-    else out[i] = (float)a;
   }
 }
 
@@ -743,10 +746,25 @@ int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hi
 }
 int bn0_partials_rows(long rows) { return cdiv(rows, 256); }
 
+static int colsum2(const float* partials, int P, int width, double* dpart, float* out, float* out2, int split,
+                   hipStream_t st) {
+  const int R = P < CS_R ? (P < 1 ? 1 : P) : CS_R;
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3(cdiv(width, 64), R), dim3(256), 0, st, partials, P, width, dpart);
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(width, 64)), dim3(64), 0, st, dpart, R, width, out, out2, split);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+long colsum_scratch_doubles(int width) { return (long)CS_R * width; }
+
 int bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, int64_t* nbt, int training, float* scale, float* shift,
-                float* mean, float* invstd, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, partials, P, C, count, gamma, beta,
+                float* mean, float* invstd, double* dpart, hipStream_t st) {
+  int R = 0;
+  if (training) {
+    R = P < CS_R ? (P < 1 ? 1 : P) : CS_R;
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(cdiv(2 * C, 64), R), dim3(256), 0, st, partials, P, 2 * C, dpart);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, dpart, R, C, count, gamma, beta,
                      running_mean, running_var, nbt, training, scale, shift, mean, invstd);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
@@ -763,15 +781,14 @@ int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, co
 }
 int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
                     const float* W1, const float* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
-                    float* dbeta0, int N, int T, int F, hipStream_t st) {
+                    float* dbeta0, double* dpart, int N, int T, int F, hipStream_t st) {
   if (F != 64) return ACVAE_EUNSUPPORTED;
   const int nb = conv1_first_blocks(N, T);
   hipLaunchKernelGGL(conv1_first_bwd_kernel, dim3(nb), dim3(256), 0, st, x, scale0, shift0, mean0, invstd0, W1, dY,
                      dw_part, bn_part, T, F);
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(576, 64)), dim3(256), 0, st, dw_part, nb, 576, dW1, (float*)nullptr, 0);
+  ACVAE_TRY(colsum2(dw_part, nb, 576, dpart, dW1, nullptr, 0, st));
   // bn0: y = xhat*gamma + beta with xin = scale0*x + shift0  ->  dbeta = sum dxin, dgamma = sum dxin*xhat
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(128, 64)), dim3(256), 0, st, bn_part, nb, 128, dbeta0, dgamma0, 64);
-  ACVAE_LAUNCH_CHECK();
+  ACVAE_TRY(colsum2(bn_part, nb, 128, dpart, dbeta0, dgamma0, 64, st));
   return ACVAE_OK;
 }
 
@@ -784,21 +801,22 @@ int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* 
   return ACVAE_OK;
 }
 
-int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, 512); }
+constexpr int BNB_PIX = 2048;
+int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, BNB_PIX); }
 int bn_bwd(const float* Y, const float* dO, bool pool, const float* scale, const float* shift, const float* mean,
-           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, int N, int H, int W, int C,
-           DropoutSpec drop, hipStream_t st) {
+           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
+           int W, int C, DropoutSpec drop, hipStream_t st) {
   if (C % 4 != 0 || C > 1024 || 1024 % C != 0) return ACVAE_EUNSUPPORTED;
   const int nb = bn_bwd_blocks(N, H, W);
   const size_t shm = 256 * 8 * sizeof(float);
   if (pool)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), shm, st, Y, dO, scale, shift, mean, invstd,
-                       partials, N, H, W, C, 512, drop);
+                       partials, N, H, W, C, BNB_PIX, drop);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), shm, st, Y, dO, scale, shift, mean, invstd,
-                       partials, N, H, W, C, 512, drop);
+                       partials, N, H, W, C, BNB_PIX, drop);
   // sum_g (= dbeta) | sum_gy (= dgamma)
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(2 * C, 64)), dim3(256), 0, st, partials, nb, 2 * C, sum_g, sum_gy, C);
+  ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st));
   const long total = (long)N * H * W * (C / 4);
   if (pool)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,

@@ -1,0 +1,657 @@
+// Composite drivers for the text side of the path, forward and backward, each ONE library call:
+//   A2  PosteriorRNN_hybrid.forward            models/text_encoder.py:182-216
+//   A4  PriorRNN.forward (per step)            models/text_encoder.py:247-268
+//   A5  VAERNNBahdanauAttnDecoder.forward      models/decoder.py:175-203
+//   A6  sample_next_word (greedy)              models/word_model.py:173-207
+//   A7  Hybrid_VAEModel.stepwise_forward / decode_step / prepare_decoder_input / stepwise_process_step
+//                                              models/vae_model.py:700-730,792-869
+//   A12 inference twin (greedy, z from the prior)  models/vae_model.py:880-894
+// The reference runs ~45 small torch kernels and >=5 host<->device copies per decode step; here the
+// host only enqueues kernels (no synchronisation inside a call), the loop-invariant halves of both
+// attentions and of both recurrent input projections are hoisted out of the time loop as batched MFMA
+// GEMMs whenever the words are known up front (teacher forcing), and the classifier / log-softmax /
+// argmax run once over all N*Tc rows.  Buffers are batch-major [N,Tc,*] like the reference's outputs;
+// "step t" addresses column t with row stride Tc*C.
+#include "common.h"
+#include "conv.h"
+#include "rnn.h"
+#include "../../include/acvae_hip.h"
+
+namespace {
+
+struct Bump {
+  long off = 0;
+  long take(long n) { const long o = off; off = (off + n + 63) & ~63L; return o; }
+};
+
+inline int gemm(const float* A, long lda, const float* B, long ldb, const float* bias, float* C, long ldc, int M, int N,
+                int K, int acc, hipStream_t st) {
+  return acvae_gemm_nt_dual(A, lda, B, ldb, K, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, acc, st);
+}
+inline int gemm2(const float* A1, long lda1, const float* B1, long ldb1, int K1, const float* A2, long lda2,
+                 const float* B2, long ldb2, int K2, const float* bias, float* C, long ldc, int M, int N, int acc,
+                 hipStream_t st) {
+  if (M <= 64) return acvae_gemm_nt_dual(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, bias, C, ldc, M, N, acc, st);
+  ACVAE_TRY(acvae_gemm_nt_dual(A1, lda1, B1, ldb1, K1, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, acc, st));
+  return acvae_gemm_nt_dual(A2, lda2, B2, ldb2, K2, nullptr, 0, nullptr, 0, 0, nullptr, C, ldc, M, N, 1, st);
+}
+struct TnWs { float* p; long bytes; };
+inline int gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K, TnWs ws,
+                   hipStream_t st) {
+  return acvae_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, 0, ws.p, ws.bytes, st);
+}
+inline int transp(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, hipStream_t st) {
+  return acvae_transpose(in, ld_in, out, ld_out, rows, cols, st);
+}
+inline int zero(float* p, long n, hipStream_t st) {
+  return hipMemsetAsync(p, 0, (size_t)n * sizeof(float), st) == hipSuccess ? ACVAE_OK : (int)hipGetLastError();
+}
+inline long tn_ws_floats(int M, int N, int K) { return acvae_gemm_tn_workspace_bytes(M, N, K) / 4 + 64; }
+
+// text-parameter table (state-dict order after the encoder; see include/acvae_hip.h)
+enum {
+  TP_DEC_EMB, TP_DEC_WIH, TP_DEC_WHH, TP_DEC_BIH, TP_DEC_BHH, TP_DEC_CLS_W, TP_DEC_CLS_B, TP_DEC_ATT_V, TP_DEC_ATT_W,
+  TP_DEC_ATT_B, TP_Q_EMB, TP_Q_WIH, TP_Q_WHH, TP_Q_BIH, TP_Q_BHH, TP_Q_WIH_R, TP_Q_WHH_R, TP_Q_BIH_R, TP_Q_BHH_R,
+  TP_Q_TML_W, TP_Q_TML_B, TP_P_EMB, TP_P_ATT_V, TP_P_ATT_W, TP_P_ATT_B, TP_P_WIH, TP_P_WHH, TP_P_BIH, TP_P_BHH,
+  TP_P_ML_W, TP_P_ML_B, TP_MLO_W, TP_MLO_B, TP_LN_W, TP_LN_B, TP_COUNT
+};
+static_assert(TP_COUNT == ACVAE_TEXT_NPARAMS, "text parameter table out of sync with the header");
+
+// ------------------------------------------------------------------------------------------ posterior
+struct PostLayout {
+  // saved
+  long words, x, hidden, save_f, save_r, hprev_f, hprev_r, argmax, saved_total;
+  // scratch
+  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, tn, scratch_total;
+  long tn_floats;
+};
+int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
+  if (N <= 0 || Tc <= 0 || E <= 0 || Hq <= 0 || V <= 0) return ACVAE_EINVAL;
+  const long R = (long)N * Tc;
+  Bump s;
+  L.words = s.take(R * 2);  // int64
+  L.x = s.take(R * E);
+  L.hidden = s.take(R * 2 * Hq);
+  L.save_f = s.take(R * 4 * Hq); L.save_r = s.take(R * 4 * Hq);
+  L.hprev_f = s.take(R * Hq); L.hprev_r = s.take(R * Hq);
+  L.argmax = s.take((long)N * 2 * Hq);
+  L.saved_total = s.off;
+  Bump c;
+  L.gi_f = c.take(R * 3 * Hq); L.gi_r = c.take(R * 3 * Hq);
+  L.gh = c.take((long)N * 3 * Hq); L.hf = c.take((long)N * Hq);
+  L.ml = c.take(R * 2 * E); L.dml = c.take(R * 2 * E); L.dhid = c.take(R * 2 * Hq);
+  L.dgi_f = c.take(R * 3 * Hq); L.dgi_r = c.take(R * 3 * Hq); L.dgh_f = c.take(R * 3 * Hq); L.dgh_r = c.take(R * 3 * Hq);
+  L.dh_a = c.take((long)N * Hq); L.dh_b = c.take((long)N * Hq);
+  L.dx = c.take(R * E);
+  long wt = (long)2 * E * 2 * Hq;
+  if ((long)3 * Hq * Hq > wt) wt = (long)3 * Hq * Hq;
+  if ((long)3 * Hq * E > wt) wt = (long)3 * Hq * E;
+  L.wt = c.take(wt);
+  long tn = tn_ws_floats(2 * E, 2 * Hq, (int)R);
+  long t2 = tn_ws_floats(3 * Hq, E, (int)R); if (t2 > tn) tn = t2;
+  t2 = tn_ws_floats(3 * Hq, Hq, (int)R); if (t2 > tn) tn = t2;
+  L.tn_floats = tn;
+  L.tn = c.take(tn);
+  L.scratch_total = c.off;
+  return ACVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ decode
+struct DecLayout {
+  // saved
+  long words, mem, encproj_d, encproj_p, qd, qp, attw_p, rnn_d, rnn_p, gru_save, hprev_d, lstm_save, c_all, hp_all,
+      hpprev, lse, pool_arg, pool_hid, unfinished, saved_total;
+  // fwd scratch
+  long gi_d, gh_d, gates_p, ml, h0, scratch_fwd;
+  // bwd scratch
+  long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
+  long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a,
+      dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, scratch_bwd;
+  long tn_floats;
+};
+int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLayout& L) {
+  if (N <= 0 || Tc <= 0 || S <= 0 || E <= 0 || H <= 0 || A <= 0 || V <= 1 || Eenc <= 0) return ACVAE_EINVAL;
+  const long R = (long)N * Tc;
+  const int Hp = E;
+  Bump s;
+  L.words = s.take(R * 2);
+  L.mem = s.take((long)N * S * E);
+  L.encproj_d = s.take((long)N * S * A); L.encproj_p = s.take((long)N * S * E);
+  L.qd = s.take(R * A); L.qp = s.take(R * E); L.attw_p = s.take(R * S);
+  L.rnn_d = s.take(R * 3 * E); L.rnn_p = s.take(R * 3 * E);
+  L.gru_save = s.take(R * 4 * H); L.hprev_d = s.take(R * H);
+  L.lstm_save = s.take(R * 5 * Hp); L.c_all = s.take(R * Hp); L.hp_all = s.take(R * Hp); L.hpprev = s.take(R * Hp);
+  L.lse = s.take(R); L.pool_arg = s.take((long)N * H); L.pool_hid = s.take((long)N * H);
+  L.unfinished = s.take(N);
+  L.saved_total = s.off;
+  Bump f;
+  L.gi_d = f.take(R * 3 * H); L.gh_d = f.take((long)N * 3 * H); L.gates_p = f.take(R * 4 * Hp);
+  L.ml = f.take((long)N * 2 * E); L.h0 = f.take((long)N * (H > Hp ? H : Hp));
+  L.scratch_fwd = f.off;
+  Bump b;
+  L.wt_cls = b.take((long)H * V + 64); L.wt_dih = b.take((long)3 * E * 3 * H); L.wt_dhh = b.take((long)H * 3 * H);
+  L.wt_datt = b.take((long)(E + H) * A); L.wt_pih = b.take((long)3 * E * 4 * Hp); L.wt_phh = b.take((long)Hp * 4 * Hp);
+  L.wt_pml = b.take((long)Hp * 2 * E); L.wt_patt = b.take((long)2 * E * E); L.wt_mlo = b.take((long)H * 2 * E);
+  L.wt_ln = b.take((long)Eenc * E);
+  L.d_out = b.take(R * H); L.dgi = b.take(R * 3 * H); L.dgh = b.take(R * 3 * H); L.dqd = b.take(R * A);
+  L.dencproj = b.take((long)N * S * (A > E ? A : E)); L.dvpart = b.take((long)N * (A > E ? A : E));
+  L.dctx = b.take((long)N * E); L.dh_a = b.take((long)N * H); L.dh_b = b.take((long)N * H);
+  L.dgates = b.take(R * 4 * Hp); L.dml_all = b.take(R * 2 * E); L.dml = b.take((long)N * 2 * E);
+  L.dhp_a = b.take((long)N * Hp); L.dhp_b = b.take((long)N * Hp); L.dc_a = b.take((long)N * Hp);
+  L.dc_b = b.take((long)N * Hp); L.dlz_a = b.take((long)N * E); L.dlz_b = b.take((long)N * E);
+  L.drnn = b.take(R * 3 * E); L.dz_dec = b.take(R * E); L.dqp = b.take(R * E);
+  L.dmem = b.take((long)N * S * E); L.dhid = b.take((long)N * H); L.words_c = b.take(R * 2);
+  long tn = 0;
+  auto mx = [&](int M, int Nn, int K) { const long t = tn_ws_floats(M, Nn, K); if (t > tn) tn = t; };
+  mx(V, H, (int)R); mx(3 * H, 3 * E, (int)R); mx(3 * H, H, (int)R); mx(A, H, (int)R); mx(A, E, N * S); mx(E, E, N * S);
+  mx(4 * Hp, 3 * E, (int)R); mx(4 * Hp, Hp, (int)R); mx(2 * E, Hp, (int)R); mx(E, E, (int)R); mx(2 * E, H, N);
+  mx(E, Eenc, N * S);
+  L.tn_floats = tn;
+  L.tn = b.take(tn);
+  L.scratch_bwd = b.off;
+  return ACVAE_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// posterior
+// ==========================================================================================
+extern "C" int64_t acvae_posterior_saved_bytes(int N, int Tc, int E, int Hq, int V) {
+  PostLayout L;
+  return post_layout(N, Tc, E, Hq, V, L) == ACVAE_OK ? L.saved_total * 4 : -1;
+}
+extern "C" int64_t acvae_posterior_scratch_bytes(int N, int Tc, int E, int Hq, int V) {
+  PostLayout L;
+  return post_layout(N, Tc, E, Hq, V, L) == ACVAE_OK ? L.scratch_total * 4 : -1;
+}
+
+extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* caps, int64_t ld_caps, const int64_t* lens1,
+                                   const float* eps_q, float* q_means, float* q_logs, float* q_z, float* q_means_utt,
+                                   void* saved_v, int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N,
+                                   int Tc, int E, int Hq, int V, void* stream) {
+  PostLayout L;
+  ACVAE_TRY(post_layout(N, Tc, E, Hq, V, L));
+  if (!params || !caps || !lens1 || !eps_q || !q_means || !q_logs || !q_z || !q_means_utt || !saved_v || !scratch_v)
+    return ACVAE_EINVAL;
+  if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_total * 4) return ACVAE_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* sv = (float*)saved_v;
+  float* sc = (float*)scratch_v;
+  auto P = [&](int i) { return (const float*)params[i]; };
+  const int R = N * Tc;
+  int64_t* words = (int64_t*)(sv + L.words);
+  float* X = sv + L.x;
+  float* hid = sv + L.hidden;
+  ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));            // x[:, :-1] restricted to Tc steps
+  ACVAE_TRY(acvae::embed_gather(words, 1, P(TP_Q_EMB), V, X, E, R, E, st));
+  for (int dir = 0; dir < 2; ++dir) {
+    const int o = dir * 4;
+    float* gi = sc + (dir ? L.gi_r : L.gi_f);
+    float* save = sv + (dir ? L.save_r : L.save_f);
+    float* hprev = sv + (dir ? L.hprev_r : L.hprev_f);
+    float* h = sc + L.hf;
+    float* gh = sc + L.gh;
+    ACVAE_TRY(gemm(X, E, P(TP_Q_WIH + o), E, P(TP_Q_BIH + o), gi, 3 * Hq, R, 3 * Hq, E, 0, st));
+    ACVAE_TRY(acvae::copy_rows(h, Hq, nullptr, 0, N, Hq, st));
+    for (int k = 0; k < Tc; ++k) {
+      const int t = dir ? Tc - 1 - k : k;
+      ACVAE_TRY(gemm(h, Hq, P(TP_Q_WHH + o), Hq, P(TP_Q_BHH + o), gh, 3 * Hq, N, 3 * Hq, Hq, 0, st));
+      ACVAE_TRY(acvae::gru_fwd(gi + (long)t * 3 * Hq, (long)Tc * 3 * Hq, gh, 3 * Hq, h, Hq, h, Hq,
+                               hid + (long)t * 2 * Hq + dir * Hq, (long)Tc * 2 * Hq, save + (long)t * 4 * Hq,
+                               (long)Tc * 4 * Hq, hprev + (long)t * Hq, (long)Tc * Hq, lens1, t, N, Hq, st));
+    }
+  }
+  float* ml = sc + L.ml;
+  ACVAE_TRY(gemm(hid, 2 * Hq, P(TP_Q_TML_W), 2 * Hq, P(TP_Q_TML_B), ml, 2 * E, R, 2 * E, 2 * Hq, 0, st));
+  ACVAE_TRY(acvae_reparam_fwd(ml, 2 * E, eps_q, E, q_means, q_logs, q_z, E, nullptr, 0, R, E, st));
+  ACVAE_TRY(acvae::pool_fwd(hid, (long)Tc * 2 * Hq, 2 * Hq, lens1, q_means_utt, (int*)(sv + L.argmax), N, Tc, 2 * Hq, st));
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads, const int64_t* lens1,
+                                   const float* eps_q, const float* q_logs, const float* d_q_means,
+                                   const float* d_q_logs, const float* d_q_z, const float* d_q_means_utt, void* saved_v,
+                                   int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int E,
+                                   int Hq, int V, void* stream) {
+  PostLayout L;
+  ACVAE_TRY(post_layout(N, Tc, E, Hq, V, L));
+  if (!params || !grads || !lens1 || !eps_q || !q_logs || !saved_v || !scratch_v) return ACVAE_EINVAL;
+  if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_total * 4) return ACVAE_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* sv = (float*)saved_v;
+  float* sc = (float*)scratch_v;
+  auto P = [&](int i) { return (const float*)params[i]; };
+  auto G = [&](int i) { return (float*)grads[i]; };
+  const int R = N * Tc;
+  TnWs tn{sc + L.tn, L.tn_floats * 4};
+  const int64_t* words = (const int64_t*)(sv + L.words);
+  float* X = sv + L.x;
+  float* hid = sv + L.hidden;
+  float* dml = sc + L.dml;
+  float* dhid = sc + L.dhid;
+  float* wt = sc + L.wt;
+  ACVAE_TRY(acvae_reparam_bwd(d_q_z, E, d_q_means, d_q_logs, E, q_logs, E, eps_q, E, dml, 2 * E, R, E, st));
+  ACVAE_TRY(transp(P(TP_Q_TML_W), 2 * Hq, wt, 2 * E, 2 * E, 2 * Hq, st));                 // [2Hq][2E]
+  ACVAE_TRY(gemm(dml, 2 * E, wt, 2 * E, nullptr, dhid, 2 * Hq, R, 2 * Hq, 2 * E, 0, st));
+  if (d_q_means_utt)
+    ACVAE_TRY(acvae::pool_bwd(d_q_means_utt, lens1, (const int*)(sv + L.argmax), dhid, (long)Tc * 2 * Hq, 2 * Hq, 1, N,
+                              Tc, 2 * Hq, st));
+  ACVAE_TRY(gemm_tn(dml, 2 * E, hid, 2 * Hq, G(TP_Q_TML_W), 2 * Hq, 2 * E, 2 * Hq, R, tn, st));
+  ACVAE_TRY(acvae::colsum_rows(dml, 2 * E, R, 2 * E, G(TP_Q_TML_B), 0, st));
+  float* dx = sc + L.dx;
+  for (int dir = 0; dir < 2; ++dir) {
+    const int o = dir * 4;
+    float* save = sv + (dir ? L.save_r : L.save_f);
+    float* hprev = sv + (dir ? L.hprev_r : L.hprev_f);
+    float* dgi = sc + (dir ? L.dgi_r : L.dgi_f);
+    float* dgh = sc + (dir ? L.dgh_r : L.dgh_f);
+    float* dh = sc + L.dh_a;
+    float* dh2 = sc + L.dh_b;
+    ACVAE_TRY(transp(P(TP_Q_WHH + o), Hq, wt, 3 * Hq, 3 * Hq, Hq, st));                   // [Hq][3Hq]
+    ACVAE_TRY(acvae::copy_rows(dh, Hq, nullptr, 0, N, Hq, st));
+    for (int k = 0; k < Tc; ++k) {
+      const int t = dir ? k : Tc - 1 - k;  // reverse of the forward order
+      ACVAE_TRY(acvae::gru_bwd(dh, Hq, dhid + (long)t * 2 * Hq + dir * Hq, (long)Tc * 2 * Hq, save + (long)t * 4 * Hq,
+                               (long)Tc * 4 * Hq, hprev + (long)t * Hq, (long)Tc * Hq, dgi + (long)t * 3 * Hq,
+                               (long)Tc * 3 * Hq, dgh + (long)t * 3 * Hq, (long)Tc * 3 * Hq, dh2, Hq, lens1, t, N, Hq,
+                               st));
+      ACVAE_TRY(gemm(dgh + (long)t * 3 * Hq, (long)Tc * 3 * Hq, wt, 3 * Hq, nullptr, dh2, Hq, N, Hq, 3 * Hq, 1, st));
+      float* tmp = dh; dh = dh2; dh2 = tmp;
+    }
+    ACVAE_TRY(gemm_tn(dgi, 3 * Hq, X, E, G(TP_Q_WIH + o), E, 3 * Hq, E, R, tn, st));
+    ACVAE_TRY(acvae::colsum_rows(dgi, 3 * Hq, R, 3 * Hq, G(TP_Q_BIH + o), 0, st));
+    ACVAE_TRY(gemm_tn(dgh, 3 * Hq, hprev, Hq, G(TP_Q_WHH + o), Hq, 3 * Hq, Hq, R, tn, st));
+    ACVAE_TRY(acvae::colsum_rows(dgh, 3 * Hq, R, 3 * Hq, G(TP_Q_BHH + o), 0, st));
+    ACVAE_TRY(transp(P(TP_Q_WIH + o), E, wt, 3 * Hq, 3 * Hq, E, st));                     // [E][3Hq]
+    ACVAE_TRY(gemm(dgi, 3 * Hq, wt, 3 * Hq, nullptr, dx, E, R, E, 3 * Hq, dir, st));
+  }
+  ACVAE_TRY(zero(G(TP_Q_EMB), (long)V * E, st));
+  ACVAE_TRY(acvae::embed_scatter(words, dx, E, G(TP_Q_EMB), V, R, E, st));
+  return ACVAE_OK;
+}
+
+// ==========================================================================================
+// prior + decoder loop
+// ==========================================================================================
+extern "C" int64_t acvae_decode_saved_bytes(int N, int Tc, int S, int E, int H, int A, int V, int Eenc) {
+  DecLayout L;
+  return dec_layout(N, Tc, S, E, H, A, V, Eenc, L) == ACVAE_OK ? L.saved_total * 4 : -1;
+}
+extern "C" int64_t acvae_decode_scratch_bytes(int N, int Tc, int S, int E, int H, int A, int V, int Eenc) {
+  DecLayout L;
+  if (dec_layout(N, Tc, S, E, H, A, V, Eenc, L) != ACVAE_OK) return -1;
+  return (L.scratch_fwd > L.scratch_bwd ? L.scratch_fwd : L.scratch_bwd) * 4;
+}
+
+extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64_t* mem_lens,
+                                const int64_t* caps, int64_t ld_caps, const int64_t* lens1, const float* q_z,
+                                const float* eps_p, const int* ss_flags_host, const int* dis_flags_host, float* logits,
+                                float* outputs, int64_t* seqs, float* sampled_logprobs, float* attn_w, float* p_means,
+                                float* p_logs, float* p_z, float* p_means_utt, float* h_final, float* hp_final,
+                                float* cp_final, void* saved_v, int64_t saved_bytes, void* scratch_v,
+                                int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc,
+                                int start_idx, int end_idx, void* stream) {
+  DecLayout L;
+  ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
+  if (!params || !mem_in || !mem_lens || !eps_p || !logits || !outputs || !seqs || !sampled_logprobs || !attn_w ||
+      !p_means || !p_logs || !p_z || !saved_v || !scratch_v)
+    return ACVAE_EINVAL;
+  const bool train = caps != nullptr;
+  if (train && (!lens1 || !q_z || !ss_flags_host || !dis_flags_host || !p_means_utt)) return ACVAE_EINVAL;
+  if (train && H != E) return ACVAE_EUNSUPPORTED;  // mean_log_out = Linear(embed_size, .) is fed the GRU output
+  if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_fwd * 4) return ACVAE_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* sv = (float*)saved_v;
+  float* sc = (float*)scratch_v;
+  auto P = [&](int i) { return (const float*)params[i]; };
+  const int R = N * Tc, Hp = E;
+  const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
+  bool teacher = train;
+  if (train)
+    for (int t = 0; t < Tc; ++t) teacher = teacher && ss_flags_host[t] != 0;
+
+  int64_t* words = (int64_t*)(sv + L.words);
+  float* mem = sv + L.mem;
+  float* encproj_d = sv + L.encproj_d;
+  float* encproj_p = sv + L.encproj_p;
+  float* qd = sv + L.qd;
+  float* qp = sv + L.qp;
+  float* attw_p = sv + L.attw_p;
+  float* rnn_d = sv + L.rnn_d;
+  float* rnn_p = sv + L.rnn_p;
+  float* gi_d = sc + L.gi_d;
+  float* gh_d = sc + L.gh_d;
+  float* gates_p = sc + L.gates_p;
+  float* ml = sc + L.ml;
+  float* zeros = sc + L.h0;
+  uint8_t* unfinished = (uint8_t*)(sv + L.unfinished);
+  const long ld3E = (long)Tc * 3 * E;
+
+  // encoder memory (optional ln projection, vae_model.py:743-744) and the hoisted attention halves
+  if (has_ln) {
+    ACVAE_TRY(gemm(mem_in, Eenc, P(TP_LN_W), Eenc, P(TP_LN_B), mem, E, N * S, E, Eenc, 0, st));
+  } else {
+    ACVAE_TRY(acvae::copy_rows(mem, E, mem_in, E, N * S, E, st));
+  }
+  ACVAE_TRY(gemm(mem, E, P(TP_DEC_ATT_W) + H, E + H, P(TP_DEC_ATT_B), encproj_d, A, N * S, A, E, 0, st));
+  ACVAE_TRY(gemm(mem, E, P(TP_P_ATT_W) + E, 2 * E, P(TP_P_ATT_B), encproj_p, E, N * S, E, E, 0, st));
+  ACVAE_TRY(acvae::copy_rows(zeros, H > Hp ? H : Hp, nullptr, 0, N, H > Hp ? H : Hp, st));
+
+  // ---- per-range helpers; (t0,cnt) is either (0,Tc) [rows contiguous] or (t,1) [row stride Tc*C]
+  auto rows_of = [&](int cnt) { return cnt == Tc ? R : N; };
+  auto ldof = [&](int cnt, long C) { return cnt == Tc ? C : (long)Tc * C; };
+  auto prior_pre = [&](int t0, int cnt) -> int {
+    const int M = rows_of(cnt);
+    // embedding -> rnn_p[:, t, 0:E]
+    ACVAE_TRY(acvae::embed_gather(words + t0, cnt == Tc ? 1 : Tc, P(TP_P_EMB), V, rnn_p + (long)t0 * 3 * E,
+                                  ldof(cnt, 3 * E), M, E, st));
+    // query projection and attention over the audio memory (text_encoder.py:251)
+    ACVAE_TRY(gemm(rnn_p + (long)t0 * 3 * E, ldof(cnt, 3 * E), P(TP_P_ATT_W), 2 * E, nullptr, qp + (long)t0 * E,
+                   ldof(cnt, E), M, E, E, 0, st));
+    ACVAE_TRY(acvae_attn_fwd(qp + (long)t0 * E, (long)Tc * E, E, encproj_p, mem, mem_lens, P(TP_P_ATT_V),
+                             rnn_p + (long)t0 * 3 * E + E, ld3E, 3 * E, attw_p + (long)t0 * S, (long)Tc * S, S, N, cnt, S,
+                             E, E, st));
+    // LSTM input projection of [emb; ctx] (+ both biases); the last_z / h parts are added per step
+    ACVAE_TRY(gemm(rnn_p + (long)t0 * 3 * E, ldof(cnt, 3 * E), P(TP_P_WIH), 3 * E, P(TP_P_BIH),
+                   gates_p + (long)t0 * 4 * Hp, ldof(cnt, 4 * Hp), M, 4 * Hp, 2 * E, 0, st));
+    return ACVAE_OK;
+  };
+  float* hp_all = sv + L.hp_all;
+  float* c_all = sv + L.c_all;
+  float* hpprev = sv + L.hpprev;
+  float* lstm_save = sv + L.lstm_save;
+  auto prior_step = [&](int t) -> int {
+    const float* hprev = t ? hp_all + (long)(t - 1) * Hp : zeros;
+    const long ldh = t ? (long)Tc * Hp : Hp;
+    const float* cprev = t ? c_all + (long)(t - 1) * Hp : nullptr;
+    ACVAE_TRY(acvae::copy_rows(hpprev + (long)t * Hp, (long)Tc * Hp, hprev, ldh, N, Hp, st));
+    if (t == 0) ACVAE_TRY(acvae::copy_rows(rnn_p + 2 * E, ld3E, nullptr, 0, N, E, st));  // last_z = 0
+    // gates += last_z . W_ih[:, 2E:3E]^T + h . W_hh^T + b_hh
+    ACVAE_TRY(gemm2(rnn_p + (long)t * 3 * E + 2 * E, ld3E, P(TP_P_WIH) + 2 * E, 3 * E, E, hprev, ldh, P(TP_P_WHH), Hp,
+                    Hp, P(TP_P_BHH), gates_p + (long)t * 4 * Hp, (long)Tc * 4 * Hp, N, 4 * Hp, 1, st));
+    ACVAE_TRY(acvae::lstm_fwd(gates_p + (long)t * 4 * Hp, (long)Tc * 4 * Hp, cprev, (long)Tc * Hp,
+                              hp_all + (long)t * Hp, (long)Tc * Hp, c_all + (long)t * Hp, (long)Tc * Hp,
+                              lstm_save + (long)t * 5 * Hp, (long)Tc * 5 * Hp, N, Hp, st));
+    ACVAE_TRY(gemm(hp_all + (long)t * Hp, (long)Tc * Hp, P(TP_P_ML_W), Hp, P(TP_P_ML_B), ml, 2 * E, N, 2 * E, Hp, 0, st));
+    float* z2 = (t + 1 < Tc) ? rnn_p + (long)(t + 1) * 3 * E + 2 * E : nullptr;
+    ACVAE_TRY(acvae_reparam_fwd(ml, 2 * E, eps_p + (long)t * N * E, E, p_means + (long)t * E, p_logs + (long)t * E,
+                                p_z + (long)t * E, (long)Tc * E, z2, ld3E, N, E, st));
+    return ACVAE_OK;
+  };
+  auto dec_pre = [&](int t0, int cnt) -> int {
+    const int M = rows_of(cnt);
+    ACVAE_TRY(acvae::embed_gather(words + t0, cnt == Tc ? 1 : Tc, P(TP_DEC_EMB), V, rnn_d + (long)t0 * 3 * E,
+                                  ldof(cnt, 3 * E), M, E, st));
+    for (int t = t0; t < t0 + cnt; ++t) {  // z: posterior sample unless this step drew the prior (vae_model.py:800-808)
+      const float* zsrc = (train && !dis_flags_host[t]) ? q_z : p_z;
+      ACVAE_TRY(acvae::copy_rows(rnn_d + (long)t * 3 * E + 2 * E, ld3E, zsrc + (long)t * E, (long)Tc * E, N, E, st));
+    }
+    ACVAE_TRY(gemm2(rnn_d + (long)t0 * 3 * E, ldof(cnt, 3 * E), P(TP_DEC_WIH), 3 * E, E,
+                    rnn_d + (long)t0 * 3 * E + 2 * E, ldof(cnt, 3 * E), P(TP_DEC_WIH) + 2 * E, 3 * E, E, P(TP_DEC_BIH),
+                    gi_d + (long)t0 * 3 * H, ldof(cnt, 3 * H), M, 3 * H, 0, st));
+    return ACVAE_OK;
+  };
+  float* gru_save = sv + L.gru_save;
+  float* hprev_d = sv + L.hprev_d;
+  auto dec_step = [&](int t) -> int {
+    const float* hprev = t ? outputs + (long)(t - 1) * H : zeros;
+    const long ldh = t ? (long)Tc * H : H;
+    ACVAE_TRY(gemm(hprev, ldh, P(TP_DEC_ATT_W), E + H, nullptr, qd + (long)t * A, (long)Tc * A, N, A, H, 0, st));
+    ACVAE_TRY(acvae_attn_fwd(qd + (long)t * A, (long)Tc * A, A, encproj_d, mem, mem_lens, P(TP_DEC_ATT_V),
+                             rnn_d + (long)t * 3 * E + E, ld3E, 3 * E, attn_w + (long)t * S, (long)Tc * S, S, N, 1, S, A,
+                             E, st));
+    ACVAE_TRY(gemm(rnn_d + (long)t * 3 * E + E, ld3E, P(TP_DEC_WIH) + E, 3 * E, nullptr, gi_d + (long)t * 3 * H,
+                   (long)Tc * 3 * H, N, 3 * H, E, 1, st));
+    ACVAE_TRY(gemm(hprev, ldh, P(TP_DEC_WHH), H, P(TP_DEC_BHH), gh_d, 3 * H, N, 3 * H, H, 0, st));
+    ACVAE_TRY(acvae::gru_fwd(gi_d + (long)t * 3 * H, (long)Tc * 3 * H, gh_d, 3 * H, hprev, ldh, outputs + (long)t * H,
+                             (long)Tc * H, nullptr, 0, gru_save + (long)t * 4 * H, (long)Tc * 4 * H,
+                             hprev_d + (long)t * H, (long)Tc * H, nullptr, t, N, H, st));
+    return ACVAE_OK;
+  };
+  float* lse = sv + L.lse;
+  auto classify = [&](int t0, int cnt) -> int {
+    const int M = rows_of(cnt);
+    ACVAE_TRY(gemm(outputs + (long)t0 * H, ldof(cnt, H), P(TP_DEC_CLS_W), H, P(TP_DEC_CLS_B), logits + (long)t0 * V,
+                   ldof(cnt, V), M, V, H, 0, st));
+    ACVAE_TRY(acvae_row_logsoftmax_argmax(logits + (long)t0 * V, (long)Tc * V, V, seqs + t0, sampled_logprobs + t0,
+                                          lse + t0, Tc, 1, N, cnt, V, st));
+    return ACVAE_OK;
+  };
+
+  if (teacher) {
+    ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));
+    ACVAE_TRY(prior_pre(0, Tc));
+    for (int t = 0; t < Tc; ++t) ACVAE_TRY(prior_step(t));
+    ACVAE_TRY(dec_pre(0, Tc));
+    for (int t = 0; t < Tc; ++t) ACVAE_TRY(dec_step(t));
+    ACVAE_TRY(classify(0, Tc));
+  } else {
+    for (int t = 0; t < Tc; ++t) {
+      ACVAE_TRY(acvae::select_word(caps, ld_caps, seqs, Tc, words, Tc, t, train && ss_flags_host[t], start_idx, N, st));
+      ACVAE_TRY(prior_pre(t, 1));
+      ACVAE_TRY(prior_step(t));
+      ACVAE_TRY(dec_pre(t, 1));
+      ACVAE_TRY(dec_step(t));
+      ACVAE_TRY(classify(t, 1));
+      if (!train) ACVAE_TRY(acvae::finish_rows(seqs, Tc, unfinished, t, end_idx, N, st));
+    }
+  }
+  if (h_final) ACVAE_TRY(acvae::copy_rows(h_final, H, outputs + (long)(Tc - 1) * H, (long)Tc * H, N, H, st));
+  if (hp_final) ACVAE_TRY(acvae::copy_rows(hp_final, Hp, hp_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp, st));
+  if (cp_final) ACVAE_TRY(acvae::copy_rows(cp_final, Hp, c_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp, st));
+  if (train) {  // p_means_utt = mean_log_out(mean_with_lens + max_with_lens of the GRU outputs), vae_model.py:722-728
+    float* hidp = sv + L.pool_hid;
+    ACVAE_TRY(acvae::pool_fwd(outputs, (long)Tc * H, H, lens1, hidp, (int*)(sv + L.pool_arg), N, Tc, H, st));
+    ACVAE_TRY(gemm(hidp, H, P(TP_MLO_W), H, P(TP_MLO_B), p_means_utt, 2 * E, N, 2 * E, H, 0, st));
+  }
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, const float* mem_in,
+                                const int64_t* mem_lens, const int64_t* lens1, const float* eps_p,
+                                const int* dis_flags_host, const float* outputs, const float* attn_w,
+                                const float* p_logs, const float* d_logits, const float* d_outputs_ext,
+                                const float* d_p_means, const float* d_p_logs, const float* d_p_z,
+                                const float* d_p_means_utt, float* d_mem_in, float* d_q_z, void* saved_v,
+                                int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S, int E,
+                                int H, int A, int V, int Eenc, void* stream) {
+  DecLayout L;
+  ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
+  if (!params || !grads || !mem_in || !mem_lens || !lens1 || !eps_p || !dis_flags_host || !outputs || !attn_w ||
+      !p_logs || !d_mem_in || !d_q_z || !saved_v || !scratch_v)
+    return ACVAE_EINVAL;
+  if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_bwd * 4) return ACVAE_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* sv = (float*)saved_v;
+  float* sc = (float*)scratch_v;
+  auto P = [&](int i) { return (const float*)params[i]; };
+  auto G = [&](int i) { return (float*)grads[i]; };
+  const int R = N * Tc, Hp = E;
+  const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
+  TnWs tn{sc + L.tn, L.tn_floats * 4};
+  const int64_t* words = (const int64_t*)(sv + L.words);
+  float* mem = sv + L.mem;
+  float* rnn_d = sv + L.rnn_d;
+  float* rnn_p = sv + L.rnn_p;
+  const long ld3E = (long)Tc * 3 * E;
+
+  // transposed weights for the dX = dY . W products
+  const int Vp = (V + 3) & ~3;
+  float *wt_cls = sc + L.wt_cls, *wt_dih = sc + L.wt_dih, *wt_dhh = sc + L.wt_dhh, *wt_datt = sc + L.wt_datt;
+  float *wt_pih = sc + L.wt_pih, *wt_phh = sc + L.wt_phh, *wt_pml = sc + L.wt_pml, *wt_patt = sc + L.wt_patt;
+  float *wt_mlo = sc + L.wt_mlo, *wt_ln = sc + L.wt_ln;
+  (void)Vp;
+  ACVAE_TRY(transp(P(TP_DEC_CLS_W), H, wt_cls, V, V, H, st));            // [H][V]
+  ACVAE_TRY(transp(P(TP_DEC_WIH), 3 * E, wt_dih, 3 * H, 3 * H, 3 * E, st));  // [3E][3H]
+  ACVAE_TRY(transp(P(TP_DEC_WHH), H, wt_dhh, 3 * H, 3 * H, H, st));      // [H][3H]
+  ACVAE_TRY(transp(P(TP_DEC_ATT_W), E + H, wt_datt, A, A, E + H, st));   // [H+E][A]: rows 0:H query half, H: memory half
+  ACVAE_TRY(transp(P(TP_P_WIH), 3 * E, wt_pih, 4 * Hp, 4 * Hp, 3 * E, st));  // [3E][4Hp]
+  ACVAE_TRY(transp(P(TP_P_WHH), Hp, wt_phh, 4 * Hp, 4 * Hp, Hp, st));    // [Hp][4Hp]
+  ACVAE_TRY(transp(P(TP_P_ML_W), Hp, wt_pml, 2 * E, 2 * E, Hp, st));     // [Hp][2E]
+  ACVAE_TRY(transp(P(TP_P_ATT_W), 2 * E, wt_patt, E, E, 2 * E, st));     // [2E][E]
+  ACVAE_TRY(transp(P(TP_MLO_W), H, wt_mlo, 2 * E, 2 * E, H, st));        // [H][2E]
+
+  // ---- d_outputs = external + utterance head + classifier
+  float* d_out = sc + L.d_out;
+  if (d_outputs_ext) ACVAE_TRY(acvae::copy_rows(d_out, H, d_outputs_ext, H, R, H, st));
+  else ACVAE_TRY(zero(d_out, (long)R * H, st));
+  if (d_p_means_utt) {
+    float* dhid = sc + L.dhid;
+    const float* hidp = sv + L.pool_hid;
+    ACVAE_TRY(gemm(d_p_means_utt, 2 * E, wt_mlo, 2 * E, nullptr, dhid, H, N, H, 2 * E, 0, st));
+    ACVAE_TRY(gemm_tn(d_p_means_utt, 2 * E, hidp, H, G(TP_MLO_W), H, 2 * E, H, N, tn, st));
+    ACVAE_TRY(acvae::colsum_rows(d_p_means_utt, 2 * E, N, 2 * E, G(TP_MLO_B), 0, st));
+    ACVAE_TRY(acvae::pool_bwd(dhid, lens1, (const int*)(sv + L.pool_arg), d_out, (long)Tc * H, H, 1, N, Tc, H, st));
+  } else {
+    ACVAE_TRY(zero(G(TP_MLO_W), (long)2 * E * H, st));
+    ACVAE_TRY(zero(G(TP_MLO_B), 2 * E, st));
+  }
+  if (d_logits) {
+    ACVAE_TRY(gemm(d_logits, V, wt_cls, V, nullptr, d_out, H, R, H, V, 1, st));
+    ACVAE_TRY(gemm_tn(d_logits, V, outputs, H, G(TP_DEC_CLS_W), H, V, H, R, tn, st));
+    ACVAE_TRY(acvae::colsum_rows(d_logits, V, R, V, G(TP_DEC_CLS_B), 0, st));
+  } else {
+    ACVAE_TRY(zero(G(TP_DEC_CLS_W), (long)V * H, st));
+    ACVAE_TRY(zero(G(TP_DEC_CLS_B), V, st));
+  }
+
+  // ---- decoder BPTT
+  float* dgi = sc + L.dgi;
+  float* dgh = sc + L.dgh;
+  float* dqd = sc + L.dqd;
+  float* dencproj = sc + L.dencproj;
+  float* dvpart = sc + L.dvpart;
+  float* dctx = sc + L.dctx;
+  float* dmem = sc + L.dmem;
+  float* dh = sc + L.dh_a;
+  float* dh2 = sc + L.dh_b;
+  const float* gru_save = sv + L.gru_save;
+  const float* hprev_d = sv + L.hprev_d;
+  const float* qd = sv + L.qd;
+  ACVAE_TRY(zero(dencproj, (long)N * S * A, st));
+  ACVAE_TRY(zero(dvpart, (long)N * A, st));
+  ACVAE_TRY(zero(dmem, (long)N * S * E, st));
+  ACVAE_TRY(zero(dh, (long)N * H, st));
+  for (int t = Tc - 1; t >= 0; --t) {
+    ACVAE_TRY(acvae::gru_bwd(dh, H, d_out + (long)t * H, (long)Tc * H, gru_save + (long)t * 4 * H, (long)Tc * 4 * H,
+                             hprev_d + (long)t * H, (long)Tc * H, dgi + (long)t * 3 * H, (long)Tc * 3 * H,
+                             dgh + (long)t * 3 * H, (long)Tc * 3 * H, dh2, H, nullptr, t, N, H, st));
+    // dctx = dgi . W_ih[:, E:2E]
+    ACVAE_TRY(gemm(dgi + (long)t * 3 * H, (long)Tc * 3 * H, wt_dih + (long)E * 3 * H, 3 * H, nullptr, dctx, E, N, E,
+                   3 * H, 0, st));
+    ACVAE_TRY(acvae_attn_bwd(dctx, E, 0, qd + (long)t * A, (long)Tc * A, A, sv + L.encproj_d, mem, mem_lens,
+                             P(TP_DEC_ATT_V), attn_w + (long)t * S, (long)Tc * S, S, dqd + (long)t * A, (long)Tc * A, A,
+                             dencproj, dmem, dvpart, N, 1, S, A, E, st));
+    // dh_prev = dh*z + dgh . W_hh + dqd . W_att[:, :H]
+    ACVAE_TRY(gemm2(dgh + (long)t * 3 * H, (long)Tc * 3 * H, wt_dhh, 3 * H, 3 * H, dqd + (long)t * A, (long)Tc * A,
+                    wt_datt, A, A, nullptr, dh2, H, N, H, 1, st));
+    float* tmp = dh; dh = dh2; dh2 = tmp;
+  }
+  // batched parameter gradients of the decoder
+  ACVAE_TRY(gemm_tn(dgi, 3 * H, rnn_d, 3 * E, G(TP_DEC_WIH), 3 * E, 3 * H, 3 * E, R, tn, st));
+  ACVAE_TRY(acvae::colsum_rows(dgi, 3 * H, R, 3 * H, G(TP_DEC_BIH), 0, st));
+  ACVAE_TRY(gemm_tn(dgh, 3 * H, hprev_d, H, G(TP_DEC_WHH), H, 3 * H, H, R, tn, st));
+  ACVAE_TRY(acvae::colsum_rows(dgh, 3 * H, R, 3 * H, G(TP_DEC_BHH), 0, st));
+  // attention parameters: W = [query half | memory half]
+  ACVAE_TRY(gemm_tn(dqd, A, hprev_d, H, G(TP_DEC_ATT_W), E + H, A, H, R, tn, st));
+  ACVAE_TRY(gemm_tn(dencproj, A, mem, E, G(TP_DEC_ATT_W) + H, E + H, A, E, N * S, tn, st));
+  ACVAE_TRY(acvae::colsum_rows(dencproj, A, N * S, A, G(TP_DEC_ATT_B), 0, st));
+  ACVAE_TRY(acvae::colsum_rows(dvpart, A, N, A, G(TP_DEC_ATT_V), 0, st));
+  ACVAE_TRY(gemm(dencproj, A, wt_datt + (long)H * A, A, nullptr, dmem, E, N * S, E, A, 1, st));
+  // d(rnn_input) for the embedding and z columns
+  float* drnn = sc + L.drnn;
+  float* dz_dec = sc + L.dz_dec;
+  ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, st));                    // d emb
+  ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, st));  // d z
+  int64_t* words_c = (int64_t*)(sc + L.words_c);
+  ACVAE_TRY(acvae::gather_words(words, Tc, 1, words_c, N, Tc, st));
+  ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, st));
+  ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, st));
+  // route dz to the posterior sample or to the prior sample, per step
+  float* dpz = sc + L.dqp;  // reuse as d p_z total [N,Tc,E] until the prior attention needs dqp
+  for (int t = 0; t < Tc; ++t) {
+    const bool prior_z = dis_flags_host[t] != 0;
+    ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, prior_z ? nullptr : dz_dec + (long)t * E,
+                               (long)Tc * E, N, E, st));
+    const float* src = d_p_z ? d_p_z + (long)t * E : nullptr;
+    ACVAE_TRY(acvae::copy_rows(dpz + (long)t * E, (long)Tc * E, src, (long)Tc * E, N, E, st));
+    if (prior_z) ACVAE_TRY(acvae::add_rows(dpz + (long)t * E, (long)Tc * E, dz_dec + (long)t * E, (long)Tc * E, N, E, st));
+  }
+
+  // ---- prior BPTT
+  float* dgates = sc + L.dgates;
+  float* dml_all = sc + L.dml_all;
+  float* dhp = sc + L.dhp_a;
+  float* dhp2 = sc + L.dhp_b;
+  float* dc = sc + L.dc_a;
+  float* dc2 = sc + L.dc_b;
+  float* dlz = sc + L.dlz_a;
+  float* dlz2 = sc + L.dlz_b;
+  const float* lstm_save = sv + L.lstm_save;
+  const float* c_all = sv + L.c_all;
+  const float* hp_all = sv + L.hp_all;
+  const float* hpprev = sv + L.hpprev;
+  ACVAE_TRY(zero(dhp, (long)N * Hp, st));
+  ACVAE_TRY(zero(dc, (long)N * Hp, st));
+  ACVAE_TRY(zero(dlz, (long)N * E, st));
+  for (int t = Tc - 1; t >= 0; --t) {
+    // dz_t = d p_z[:,t] (+ decoder share) + d last_z from step t+1
+    ACVAE_TRY(acvae::add_rows(dlz, E, dpz + (long)t * E, (long)Tc * E, N, E, st));
+    ACVAE_TRY(acvae_reparam_bwd(dlz, E, d_p_means ? d_p_means + (long)t * E : nullptr,
+                                d_p_logs ? d_p_logs + (long)t * E : nullptr, (long)Tc * E, p_logs + (long)t * E,
+                                (long)Tc * E, eps_p + (long)t * N * E, E, dml_all + (long)t * 2 * E, (long)Tc * 2 * E, N,
+                                E, st));
+    // dh = dh_next + dml . W_ml
+    ACVAE_TRY(gemm(dml_all + (long)t * 2 * E, (long)Tc * 2 * E, wt_pml, 2 * E, nullptr, dhp, Hp, N, Hp, 2 * E, 1, st));
+    ACVAE_TRY(acvae::lstm_bwd(dhp, Hp, dc, Hp, lstm_save + (long)t * 5 * Hp, (long)Tc * 5 * Hp,
+                              t ? c_all + (long)(t - 1) * Hp : nullptr, (long)Tc * Hp, dgates + (long)t * 4 * Hp,
+                              (long)Tc * 4 * Hp, dc2, Hp, N, Hp, st));
+    ACVAE_TRY(gemm(dgates + (long)t * 4 * Hp, (long)Tc * 4 * Hp, wt_phh, 4 * Hp, nullptr, dhp2, Hp, N, Hp, 4 * Hp, 0, st));
+    ACVAE_TRY(gemm(dgates + (long)t * 4 * Hp, (long)Tc * 4 * Hp, wt_pih + (long)2 * E * 4 * Hp, 4 * Hp, nullptr, dlz2, E,
+                   N, E, 4 * Hp, 0, st));
+    float* tmp = dhp; dhp = dhp2; dhp2 = tmp;
+    tmp = dc; dc = dc2; dc2 = tmp;
+    tmp = dlz; dlz = dlz2; dlz2 = tmp;
+  }
+  // batched parameter gradients of the prior
+  ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn, st));
+  ACVAE_TRY(acvae::colsum_rows(dml_all, 2 * E, R, 2 * E, G(TP_P_ML_B), 0, st));
+  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, rnn_p, 3 * E, G(TP_P_WIH), 3 * E, 4 * Hp, 3 * E, R, tn, st));
+  ACVAE_TRY(acvae::colsum_rows(dgates, 4 * Hp, R, 4 * Hp, G(TP_P_BIH), 0, st));
+  ACVAE_TRY(acvae::colsum_rows(dgates, 4 * Hp, R, 4 * Hp, G(TP_P_BHH), 0, st));
+  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, hpprev, Hp, G(TP_P_WHH), Hp, 4 * Hp, Hp, R, tn, st));
+  // d[emb; ctx] of the prior
+  ACVAE_TRY(gemm(dgates, 4 * Hp, wt_pih, 4 * Hp, nullptr, drnn, 3 * E, R, 2 * E, 4 * Hp, 0, st));   // cols 0:2E of drnn[R,3E]
+  // prior attention backward (all Tc queries of a clip inside one workgroup: deterministic accumulation)
+  float* dqp = sc + L.dqp;  // dpz is dead from here on
+  ACVAE_TRY(zero(dencproj, (long)N * S * E, st));
+  ACVAE_TRY(zero(dvpart, (long)N * E, st));
+  ACVAE_TRY(acvae_attn_bwd(drnn + E, (long)Tc * 3 * E, 3 * E, sv + L.qp, (long)Tc * E, E, sv + L.encproj_p, mem,
+                           mem_lens, P(TP_P_ATT_V), sv + L.attw_p, (long)Tc * S, S, dqp, (long)Tc * E, E, dencproj, dmem,
+                           dvpart, N, Tc, S, E, E, st));
+  // d emb_p = drnn[:, 0:E] + dqp . W_att[:, :E]
+  ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn, 3 * E, R, E, E, 1, st));
+  ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn, st));
+  ACVAE_TRY(gemm_tn(dencproj, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn, st));
+  ACVAE_TRY(acvae::colsum_rows(dencproj, E, N * S, E, G(TP_P_ATT_B), 0, st));
+  ACVAE_TRY(acvae::colsum_rows(dvpart, E, N, E, G(TP_P_ATT_V), 0, st));
+  ACVAE_TRY(gemm(dencproj, E, wt_patt + (long)E * E, E, nullptr, dmem, E, N * S, E, E, 1, st));
+  ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, st));
+  ACVAE_TRY(acvae::embed_scatter(words_c, drnn, 3 * E, G(TP_P_EMB), V, R, E, st));
+  // ---- memory gradient back through the optional ln projection
+  if (has_ln) {
+    ACVAE_TRY(transp(P(TP_LN_W), Eenc, wt_ln, E, E, Eenc, st));                          // [Eenc][E]
+    ACVAE_TRY(gemm(dmem, E, wt_ln, E, nullptr, d_mem_in, Eenc, N * S, Eenc, E, 0, st));
+    ACVAE_TRY(gemm_tn(dmem, E, mem_in, Eenc, G(TP_LN_W), Eenc, E, Eenc, N * S, tn, st));
+    ACVAE_TRY(acvae::colsum_rows(dmem, E, N * S, E, G(TP_LN_B), 0, st));
+  } else {
+    ACVAE_TRY(acvae::copy_rows(d_mem_in, E, dmem, E, N * S, E, st));
+  }
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, void* stream) {
+  if (!caps || !out || n <= 0) return ACVAE_EINVAL;
+  return acvae::caps_to_long(caps, out, (long)n, (hipStream_t)stream);
+}

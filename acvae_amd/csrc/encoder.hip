@@ -19,7 +19,7 @@ struct EncLayout {
   long pooled_in;
   long total;
   // scratch
-  long s_partials, s_dya, s_dyb, s_dpa, s_dpb, s_wd, s_slab, s_bnpart, s_c1w, s_c1b, s_total;
+  long s_partials, s_dya, s_dyb, s_dpa, s_dpb, s_wd, s_slab, s_bnpart, s_c1w, s_c1b, s_dpart, s_total;
 };
 
 long align4(long x) { return (x + 63) & ~63L; }
@@ -66,6 +66,7 @@ int make_layout(int N, int T, int F, EncLayout& L) {
   if (c1 > max_part) max_part = c1;
   if (b0 > max_part) max_part = b0;
   long s = 0;
+  L.s_dpart = s; s = align4(s + 2 * acvae::colsum_scratch_doubles(1024));
   L.s_partials = s; s = align4(s + max_part);
   L.s_bnpart = s; s = align4(s + max_bnpart);
   L.s_wd = s; s = align4(s + 512L * 9 * 512);
@@ -128,6 +129,7 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
   float* saved = (float*)saved_v;
   float* scratch = (float*)scratch_v;
   float* partials = scratch + L.s_partials;
+  double* dpart = (double*)(scratch + L.s_dpart);
   auto P = [&](int i) { return (float*)params[i]; };
 
   // bn0 over the mel axis (encoder.py:679-681)
@@ -135,7 +137,7 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
   int nparts = 0;
   if (training) ACVAE_TRY(acvae::bn0_stats(feats, partials, (long)N * T, F, &nparts, st));
   ACVAE_TRY(acvae::bn_finalize(partials, nparts, 64, (double)N * T, P(p_bn0(0)), P(p_bn0(1)), P(p_bn0(2)), P(p_bn0(3)),
-                               (int64_t*)params[p_bn0(4)], training, b0.scale, b0.shift, b0.mean, b0.invstd, st));
+                               (int64_t*)params[p_bn0(4)], training, b0.scale, b0.shift, b0.mean, b0.invstd, dpart, st));
   const float* x_in = nullptr;
   for (int b = 1; b <= 4; ++b) {
     const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
@@ -156,13 +158,13 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
     }
     ACVAE_TRY(acvae::bn_finalize(partials, np1, C, cnt, P(p_bn(b, 1, 0)), P(p_bn(b, 1, 1)), P(p_bn(b, 1, 2)),
                                  P(p_bn(b, 1, 3)), (int64_t*)params[p_bn(b, 1, 4)], training, n1.scale, n1.shift,
-                                 n1.mean, n1.invstd, st));
+                                 n1.mean, n1.invstd, dpart, st));
     ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), saved + L.wf2[b], nullptr, C, C, st));
     ACVAE_TRY(acvae::conv3x3_igemm(Y1, n1.scale, n1.shift, saved + L.wf2[b], Y2, training ? partials : nullptr, N, H,
                                    W, C, C, st));
     ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_partials_rows(N, H, W), C, cnt, P(p_bn(b, 2, 0)),
                                  P(p_bn(b, 2, 1)), P(p_bn(b, 2, 2)), P(p_bn(b, 2, 3)), (int64_t*)params[p_bn(b, 2, 4)],
-                                 training, n2.scale, n2.shift, n2.mean, n2.invstd, st));
+                                 training, n2.scale, n2.shift, n2.mean, n2.invstd, dpart, st));
     ACVAE_TRY(acvae::bn_relu_pool(Y2, n2.scale, n2.shift, saved + L.p[b], N, H, W, C,
                                   dspec(p_block, masks, seed, b - 1, training), st));
     x_in = saved + L.p[b];
@@ -199,6 +201,7 @@ extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, 
   float* wd = scratch + L.s_wd;
   float* slab = scratch + L.s_slab;
   float* bnpart = scratch + L.s_bnpart;
+  double* dpart = (double*)(scratch + L.s_dpart);
   const int S = L.H[0], Fp = L.W[0];
   ACVAE_TRY(acvae::freq_mean_bwd(d_audio_embeds, dp_cur, (long)N * S, Fp, 512, st));
   for (int b = 4; b >= 1; --b) {
@@ -208,14 +211,14 @@ extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, 
     BnPtrs n1 = bn_at(saved, L, 1 + 2 * (b - 1)), n2 = bn_at(saved, L, 2 + 2 * (b - 1));
     // conv2 / bn2 / pool / dropout
     ACVAE_TRY(acvae::bn_bwd(Y2, dp_cur, true, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
-                            G(p_bn(b, 2, 0)), dya, N, H, W, C, dspec(p_block, masks, seed, b - 1, 1), st));
+                            G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, 1), st));
     ACVAE_TRY(acvae::conv3x3_wgrad(dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
     ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), nullptr, wd, C, C, st));
     ACVAE_TRY(acvae::conv3x3_igemm(dya, nullptr, nullptr, wd, dyb, nullptr, N, H, W, C, C, st));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
     ACVAE_TRY(acvae::bn_bwd(Y1, dyb, false, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
-                            G(p_bn(b, 1, 0)), dya, N, H, W, C, none, st));
+                            G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st));
     if (b > 1) {
       ACVAE_TRY(acvae::conv3x3_wgrad(dya, saved + L.p[b - 1], nullptr, nullptr, G(p_conv(b, 1)), slab, N, H, W, Cin, C,
                                      st));
@@ -226,7 +229,7 @@ extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, 
       BnPtrs b0 = bn_at(saved, L, 0);
       ACVAE_TRY(acvae::conv1_first_bwd(feats, b0.scale, b0.shift, b0.mean, b0.invstd, P(p_conv(1, 1)), dya,
                                        scratch + L.s_c1w, scratch + L.s_c1b, G(p_conv(1, 1)), G(p_bn0(0)), G(p_bn0(1)),
-                                       N, T, F, st));
+                                       dpart, N, T, F, st));
     }
   }
   return ACVAE_OK;

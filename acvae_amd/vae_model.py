@@ -1,0 +1,208 @@
+"""Mirror of ``models/vae_model.py`` ``Hybrid_VAEModel`` (:674-894): the autoregressive-prior +
+global-constraint AC-VAE.  Same constructor ``Hybrid_VAEModel(Audioencoder, Textdecoder,
+posterior_model=, posterior_args=, prior_model=, prior_args=)``, same forward contract
+
+    forward(feats, feat_lens, caps, cap_lens, ss_ratio=, dis_ratio=)   -> training dict
+    forward(feats, feat_lens, method="greedy", max_length=, ...)       -> inference dict ("seqs", ...)
+
+and the same state-dict names.  Host code here only draws the random decisions in the reference's
+order (python ``random.random()`` per step for scheduled sampling :826, CPU ``torch.randn`` for both
+reparameterisations — SURVEY F9 —, ``torch.rand(1)`` per step when dis_ratio != 0 :805), allocates
+outputs and wires three autograd nodes (encoder, posterior, decode loop), each ONE call into
+libacvae_hip.so for forward and one for backward.
+"""
+import random
+import weakref
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, text_encoder
+from .encoder import ptr_table, scratch_buffer
+from .word_model import CaptionModel
+
+
+class _DecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, mem, mem_lens_d, caps_d, lens1_d, q_z, eps_p, ss_flags, dis_flags, Tc, *weights):
+        N, S, Eenc = mem.shape
+        dec = model.decoder
+        E, H, A, V = dec.embed_size, dec.model.hidden_size, dec.attn.attn_size, dec.vocab_size
+        dev = mem.device
+        train = caps_d is not None
+        params = model._text_table()
+        dims = (N, Tc, S, E, H, A, V, Eenc)
+        saved_b = _lib.call("acvae_decode_saved_bytes", *dims)
+        scratch_b = _lib.call("acvae_decode_scratch_bytes", *dims)
+        if saved_b < 0:
+            raise RuntimeError(f"decode: unsupported dims {dims}")
+        saved = torch.empty(saved_b, dtype=torch.uint8, device=dev)
+        scratch = scratch_buffer(scratch_b, dev)
+        f = lambda *s: torch.empty(*s, device=dev)
+        logits, outputs = f(N, Tc, V), f(N, Tc, H)
+        seqs = torch.empty(N, Tc, dtype=torch.long, device=dev)
+        slp, attw = f(N, Tc), f(N, Tc, S)
+        pm, pl, pz = f(N, Tc, E), f(N, Tc, E), f(N, Tc, E)
+        putt = f(N, 2 * E) if train else None
+        hfin, hp, cp = f(N, H), f(N, E), f(N, E)
+        IntArr = _lib.ctypes.c_int * Tc
+        ss_arr = IntArr(*[int(bool(x)) for x in ss_flags]) if train else None
+        dis_arr = IntArr(*[int(bool(x)) for x in dis_flags]) if train else IntArr(*([1] * Tc))
+        mem = mem.contiguous()
+        _lib.call("acvae_decode_fwd", ptr_table(params), mem, mem_lens_d, caps_d, caps_d.stride(0) if train else 0,
+                  lens1_d, q_z, eps_p, ss_arr, dis_arr, logits, outputs, seqs, slp, attw, pm, pl, pz, putt, hfin, hp, cp,
+                  saved, saved_b, scratch, scratch_b, *dims, model.start_idx, model.end_idx, _lib.current_stream())
+        ctx.model, ctx.saved, ctx.dims, ctx.dis_arr = model, saved, dims, dis_arr
+        ctx.keep = (mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl)
+        ctx.mark_non_differentiable(seqs, slp, attw, hfin, hp, cp)
+        if not train:
+            putt = torch.zeros(0, device=dev)
+            ctx.mark_non_differentiable(putt)
+        return logits, outputs, seqs, slp, attw, pm, pl, pz, putt, hfin, hp, cp
+
+    @staticmethod
+    def backward(ctx, d_logits, d_outputs, _s, _l, _a, d_pm, d_pl, d_pz, d_putt, *_rest):
+        model = ctx.model
+        N, Tc, S, E, H, A, V, Eenc = ctx.dims
+        mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl = ctx.keep
+        dev = mem.device
+        params = model._text_table()
+        grads = [None] * len(params)
+        mine = set(range(0, 10)) | set(range(21, 35))
+        for i, p in enumerate(params):
+            if p is not None and p.requires_grad and i in mine:
+                grads[i] = model._grad_buffer(p)
+        c = lambda t: None if t is None else t.contiguous().float()
+        d_mem = torch.empty(N, S, Eenc, device=dev)
+        d_qz = torch.empty(N, Tc, E, device=dev)
+        scratch_b = _lib.call("acvae_decode_scratch_bytes", *ctx.dims)
+        scratch = scratch_buffer(scratch_b, dev)
+        _lib.call("acvae_decode_bwd", ptr_table(params), ptr_table(grads), mem, mem_lens_d, lens1_d, eps_p, ctx.dis_arr,
+                  outputs, attw, pl, c(d_logits), c(d_outputs), c(d_pm), c(d_pl), c(d_pz), c(d_putt), d_mem, d_qz,
+                  ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, _lib.current_stream())
+        ctx.saved = None
+        outs = [next((g for p, g in zip(params, grads) if p is w), None) for w in model._decode_weights()]
+        return (None, d_mem, None, None, None, d_qz, None, None, None, None, *outs)
+
+
+class Hybrid_VAEModel(CaptionModel):
+    def __init__(self, Audioencoder: nn.Module, Textdecoder: nn.Module, **kwargs):
+        super().__init__(Audioencoder, Textdecoder, **kwargs)
+        E = Textdecoder.embed_size
+        self.qnet = getattr(text_encoder, kwargs["posterior_model"])(
+            word_dim=E, embed_size=E, vocab_size=Textdecoder.vocab_size, **kwargs["posterior_args"])
+        self.pnet = getattr(text_encoder, kwargs["prior_model"])(
+            word_dim=E, audiofeats_size=E, embed_size=E, vocab_size=Textdecoder.vocab_size, **kwargs["prior_args"])
+        self.mean_log_out = nn.Linear(E, 2 * E)
+        if E != Audioencoder.embed_size:
+            self.ln = nn.Linear(Audioencoder.embed_size, E)
+            nn.init.xavier_uniform_(self.ln.weight)
+        nn.init.xavier_uniform_(self.mean_log_out.weight)
+        self.qnet._owner = weakref.ref(self)
+        self.noise = None          # optional replay: dict(eps_q=[N,Tc,E], eps_p=[Tc,N,E]) consumed by the next forward
+        self._grad_views = None    # {param: flat-gradient view}, set by the train-step harness
+
+    # ---- plumbing: the text-side parameter table in state-dict order (include/acvae_hip.h)
+    def _text_table(self):
+        d, q, p = self.decoder, self.qnet, self.pnet
+        g, qn, pn = d.model, q.network, p.network
+        t = [d.word_embeddings.weight, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+             d.classifier.weight, d.classifier.bias, d.attn.v, d.attn.h2attn.weight, d.attn.h2attn.bias,
+             q.word_embedding.weight, qn.weight_ih_l0, qn.weight_hh_l0, qn.bias_ih_l0, qn.bias_hh_l0,
+             qn.weight_ih_l0_reverse, qn.weight_hh_l0_reverse, qn.bias_ih_l0_reverse, qn.bias_hh_l0_reverse,
+             q.token_mean_log.weight, q.token_mean_log.bias,
+             p.word_embedding.weight, p.word_attn.v, p.word_attn.h2attn.weight, p.word_attn.h2attn.bias,
+             pn.weight_ih_l0, pn.weight_hh_l0, pn.bias_ih_l0, pn.bias_hh_l0, p.mean_log_out.weight, p.mean_log_out.bias,
+             self.mean_log_out.weight, self.mean_log_out.bias]
+        t += [self.ln.weight, self.ln.bias] if hasattr(self, "ln") else [None, None]
+        assert len(t) == _lib.ENUMS_TEXT_N
+        return t
+
+    def _decode_weights(self):
+        t = self._text_table()
+        return [p for i, p in enumerate(t) if p is not None and (i < 10 or i >= 21)]
+
+    def _grad_buffer(self, p):
+        if self._grad_views is not None and p in self._grad_views:
+            return self._grad_views[p]
+        return torch.empty_like(p)
+
+    def _set_grad_views(self, views):
+        self._grad_views = views
+        self.encoder._grad_views = views
+
+    # ---- reference API
+    def train_forward(self, encoded, caps, cap_lens, **kwargs):
+        return self.stepwise_forward(encoded, caps, cap_lens, **kwargs)
+
+    def inference_forward(self, encoded, **kwargs):
+        method = kwargs.get("method", "greedy")
+        if method != "greedy":
+            raise NotImplementedError(f"inference method {method!r}: the HIP path implements greedy decoding with "
+                                      "z ~ prior (beam / dbs / sampling are SURVEY §8(f) next rows)")
+        return self.stepwise_forward(encoded, None, None, **kwargs)
+
+    def forward(self, *input, **kwargs):
+        """models/vae_model.py:732-760"""
+        if len(input) == 4:
+            feats, feat_lens, caps, cap_lens = input
+            encoded = self.encoder(feats, feat_lens)
+            qnetout = self.qnet(caps, cap_lens, eps=None if self.noise is None else self.noise.get("eps_q"))
+            encoded.update(qnetout)
+            return self.train_forward(encoded, caps, cap_lens, **kwargs)
+        if len(input) == 2:
+            feats, feat_lens = input
+            encoded = self.encoder(feats, feat_lens)
+            return self.inference_forward(encoded, **kwargs)
+        raise Exception("Number of input should be either 4 (feats, feat_lens, caps, cap_lens) or 2 (feats, feat_lens)")
+
+    def stepwise_forward(self, encoded, caps, cap_lens, **kwargs):
+        """models/vae_model.py:700-730 with decode_step (:792-816), prepare_decoder_input (:818-848) and
+        stepwise_process_step (:850-869) fused into one device-side loop."""
+        mem = encoded["audio_embeds"]
+        dev = mem.device
+        N = mem.shape[0]
+        E = self.decoder.embed_size
+        train = caps is not None
+        mem_lens_d = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long).to(dev)
+        if train:
+            lens1 = np.asarray(cap_lens) - 1
+            Tc = int(max(cap_lens)) - 1
+            ss_ratio, dis_ratio = kwargs["ss_ratio"], kwargs["dis_ratio"]
+        else:
+            Tc = kwargs.get("max_length", self.max_length)
+        # host-side random decisions, in the reference's per-step order
+        replay = self.noise
+        self.noise = None
+        ss_flags, dis_flags, eps_list = [], [], []
+        for t in range(Tc):
+            if train:
+                ss_flags.append(random.random() < ss_ratio)                    # :826
+            if replay is None or replay.get("eps_p") is None:
+                eps_list.append(torch.randn(N, E))                               # text_encoder.py:259 (CPU, F9)
+            if train:
+                dis_flags.append(bool(dis_ratio != 0 and torch.rand(1) <= dis_ratio))   # :802-806
+        if eps_list:
+            eps_p = torch.stack(eps_list, 0)
+        else:
+            eps_p = replay["eps_p"][:Tc]
+        eps_p = eps_p.to(dev, non_blocking=True).contiguous().float()
+        if train:
+            caps_d = caps.to(torch.long).to(dev).contiguous()
+            lens1_d = torch.as_tensor(lens1, dtype=torch.long).to(dev)
+            q_z = encoded["q_z"]
+        else:
+            caps_d = lens1_d = q_z = None
+        outs = _DecodeFn.apply(self, mem, mem_lens_d, caps_d, lens1_d, q_z, eps_p, ss_flags, dis_flags, Tc,
+                               *self._decode_weights())
+        logits, outputs, seqs, slp, attw, pm, pl, pz, putt, hfin, hp, cp = outs
+        output = {"seqs": seqs, "logits": logits, "outputs": outputs, "sampled_logprobs": slp,
+                  "attn_weights": attw.transpose(1, 2), "p_means": pm, "p_logs": pl, "p_z": pz,
+                  "state": hfin.unsqueeze(0), "hiddens_state": (hp.unsqueeze(0), cp.unsqueeze(0)), "last_z": pz[:, -1]}
+        if train:
+            for k in ("q_means", "q_logs", "q_z", "q_means_utt", "q_logs_utt"):
+                output[k] = encoded[k]
+            output["p_means_utt"] = putt
+            output["p_logs_utt"] = None
+        return output

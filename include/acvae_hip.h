@@ -132,6 +132,68 @@ int acvae_encoder_bwd(const void* const* params, void* const* grads, const float
                       int64_t scratch_bytes, int N, int T, int F, float p_block, uint64_t seed,
                       const uint8_t* const* masks, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Text side of the path.  `params` / `grads` are pointer tables in the reference's state-dict order
+ * after the encoder (ACVAE_TEXT_NPARAMS entries; ln.* may be NULL when absent):
+ *   decoder.{word_embeddings.weight, model.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0},
+ *            classifier.{weight,bias}, attn.{v, h2attn.weight, h2attn.bias}},
+ *   qnet.{word_embedding.weight, network.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0,
+ *         *_reverse x4}, token_mean_log.{weight,bias}},
+ *   pnet.{word_embedding.weight, word_attn.{v, h2attn.weight, h2attn.bias},
+ *         network.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0}, mean_log_out.{weight,bias}},
+ *   mean_log_out.{weight,bias}, ln.{weight,bias}.
+ * All [N,Tc,*] tensors are batch-major and contiguous like the reference's outputs.
+ * Gradients are WRITTEN (not accumulated).
+ * ------------------------------------------------------------------------------------------- */
+#define ACVAE_TEXT_NPARAMS 35
+
+/* A2  PosteriorRNN_hybrid.forward  models/text_encoder.py:182-216.  caps: int64 token ids [N, >=Tc]
+ * (row stride ld_caps), lens1 = cap_lens-1 (device int64), Tc = max(lens1); eps_q [N,Tc,E] is the
+ * torch.randn draw of :196 (made on the host, F9).  Packed-sequence semantics: a row stops at its
+ * length, padded outputs are zero (so q_means/q_logs there equal the Linear bias). */
+int64_t acvae_posterior_saved_bytes(int N, int Tc, int E, int Hq, int V);
+int64_t acvae_posterior_scratch_bytes(int N, int Tc, int E, int Hq, int V);
+int acvae_posterior_fwd(const void* const* params, const int64_t* caps, int64_t ld_caps, const int64_t* lens1,
+                        const float* eps_q, float* q_means, float* q_logs, float* q_z, float* q_means_utt,
+                        void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int Tc, int E,
+                        int Hq, int V, void* stream);
+int acvae_posterior_bwd(const void* const* params, void* const* grads, const int64_t* lens1, const float* eps_q,
+                        const float* q_logs, const float* d_q_means, const float* d_q_logs, const float* d_q_z,
+                        const float* d_q_means_utt, void* saved, int64_t saved_bytes, void* scratch,
+                        int64_t scratch_bytes, int N, int Tc, int E, int Hq, int V, void* stream);
+
+/* A4+A5+A6+A7 (+A12 when caps == NULL): the step-by-step decode of Hybrid_VAEModel
+ * models/vae_model.py:700-730,792-869 with PriorRNN (text_encoder.py:247-268),
+ * VAERNNBahdanauAttnDecoder (decoder.py:175-203) and greedy sample_next_word (word_model.py:173-207).
+ *   mem_in [N,S,Eenc] audio_embeds (projected by ln when Eenc != E), mem_lens [N] (= feat_lens//16),
+ *   caps/ld_caps/lens1 as above (NULL caps = inference: words come from the previous argmax, z from
+ *   the prior, finished rows emit <end>),  q_z [N,Tc,E] posterior samples,
+ *   eps_p [Tc,N,E] the per-step torch.randn draws of text_encoder.py:259,
+ *   ss_flags_host[t] != 0: step t is teacher-forced (random.random() < ss_ratio, vae_model.py:826),
+ *   dis_flags_host[t] != 0: step t feeds the PRIOR's z to the decoder (torch.rand(1) <= dis_ratio, :805).
+ * Outputs: logits [N,Tc,V], outputs [N,Tc,H], seqs i64 [N,Tc], sampled_logprobs [N,Tc],
+ *   attn_w [N,Tc,S] (the reference's attn_weights transposed), p_means/p_logs/p_z [N,Tc,E],
+ *   p_means_utt [N,2E] (training only), final states h [N,H], (hp, cp) [N,E]. */
+int64_t acvae_decode_saved_bytes(int N, int Tc, int S, int E, int H, int A, int V, int Eenc);
+int64_t acvae_decode_scratch_bytes(int N, int Tc, int S, int E, int H, int A, int V, int Eenc);
+int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64_t* mem_lens, const int64_t* caps,
+                     int64_t ld_caps, const int64_t* lens1, const float* q_z, const float* eps_p,
+                     const int* ss_flags_host, const int* dis_flags_host, float* logits, float* outputs, int64_t* seqs,
+                     float* sampled_logprobs, float* attn_w, float* p_means, float* p_logs, float* p_z,
+                     float* p_means_utt, float* h_final, float* hp_final, float* cp_final, void* saved,
+                     int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int Tc, int S, int E, int H,
+                     int A, int V, int Eenc, int start_idx, int end_idx, void* stream);
+/* Backward for upstream gradients of logits / outputs / p_means / p_logs / p_z / p_means_utt (each may be
+ * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E]. */
+int acvae_decode_bwd(const void* const* params, void* const* grads, const float* mem_in, const int64_t* mem_lens,
+                     const int64_t* lens1, const float* eps_p, const int* dis_flags_host, const float* outputs,
+                     const float* attn_w, const float* p_logs, const float* d_logits, const float* d_outputs_ext,
+                     const float* d_p_means, const float* d_p_logs, const float* d_p_z, const float* d_p_means_utt,
+                     float* d_mem_in, float* d_q_z, void* saved, int64_t saved_bytes, void* scratch,
+                     int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc, void* stream);
+/* float caption ids (collate pads with torch.zeros -> float32, caption_dataset.py:293) -> int64 */
+int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
