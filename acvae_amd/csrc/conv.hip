@@ -16,6 +16,7 @@
 #include "mfma_tile.h"
 #include "../../include/acvae_hip.h"
 #include "conv.h"
+#include "prof.h"
 
 namespace {
 using namespace mfma;
@@ -681,6 +682,7 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
   const int M = N * H * W, K = 9 * Cin;
   ConvRowLoader al{X, scale, shift, H, W, Cin, M};
   ConvStatsEpilogue ep{Y, partials, Cout};
+  prof_begin(ACVAE_PROF_CONV_IGEMM, st);
   if (Cout <= 64) {
     dim3 grid(cdiv(M, BM), cdiv(Cout, 64));
     hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(NT_THREADS), 0, st, al, Wp, ep, M, Cout, K);
@@ -688,6 +690,7 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
     dim3 grid(cdiv(M, BM), cdiv(Cout, 128));
     hipLaunchKernelGGL(conv_igemm_kernel<128>, grid, dim3(NT_THREADS), 0, st, al, Wp, ep, M, Cout, K);
   }
+  prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
@@ -714,6 +717,7 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
   const int k_per = cdiv(cdiv(M, s), BKT) * BKT;
   s = cdiv(M, k_per);
   ConvKMajorLoader bl{X, scale, shift, H, W, Cin, M, NC};
+  prof_begin(ACVAE_PROF_CONV_WGRAD, st);
   if (Cout <= 64) {
     dim3 grid(cdiv(Cout, 64), cdiv(NC, 256), s);
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
@@ -721,6 +725,7 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
     dim3 grid(cdiv(Cout, 128), cdiv(NC, 128), s);
     hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
   }
+  prof_end(ACVAE_PROF_CONV_WGRAD, st);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((long)Cout * NC)), dim3(256), 0, st, slab, s, dW_oihw, Cout,
                      Cin);
   ACVAE_LAUNCH_CHECK();

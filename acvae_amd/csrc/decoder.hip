@@ -474,7 +474,6 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   float* mem = sv + L.mem;
   float* rnn_d = sv + L.rnn_d;
   float* rnn_p = sv + L.rnn_p;
-  const long ld3E = (long)Tc * 3 * E;
 
   // transposed weights for the dX = dY . W products
   const int Vp = (V + 3) & ~3;

@@ -111,6 +111,8 @@ class _Cnn10Fn(torch.autograd.Function):
                   ctx.saved.numel(), scratch, scratch_b, N, T, F, float(mod.p_block), ctx.seed, mt,
                   _lib.current_stream())
         ctx.saved = None
+        if mod._grad_ready_cb is not None:
+            mod._grad_ready_cb("encoder")
         for w in mod._weights():
             outs.append(next((g for t, g in zip(tensors, grads) if t is w), None))
         return (None, None, *outs)
@@ -135,6 +137,7 @@ class Cnn10(nn.Module):
         self.dropout_masks = None               # optional explicit keep-masks (parity tests)
         self._seed_base, self._calls = None, 0
         self._grad_views = None                 # {param: flat-gradient view}, set by the train-step harness
+        self._grad_ready_cb = None              # called with "encoder" when the backward has written all grads
 
     # ---- plumbing
     def _param_table(self):
@@ -149,7 +152,7 @@ class Cnn10(nn.Module):
 
     def _grad_buffer(self, p):
         if self._grad_views is not None and p in self._grad_views:
-            return self._grad_views[p]
+            return self._grad_views[p].detach()     # fresh alias: autograd adopts it as .grad without a copy
         return torch.empty_like(p)
 
     def _next_seed(self):

@@ -83,6 +83,9 @@ class _PosteriorFn(torch.autograd.Function):
                   c(d_ql), c(d_qz), c(d_utt), ctx.saved, ctx.saved.numel(), scratch, scratch_b, N, Tc, E, Hq, V,
                   _lib.current_stream())
         ctx.saved = None
+        owner = mod._owner() if mod._owner is not None else None
+        if owner is not None and owner._grad_ready_cb is not None:
+            owner._grad_ready_cb("text")            # decode backward always precedes this node (it consumes d_q_z)
         outs = [next((g for p, g in zip(params, grads) if p is w), None) for w in mod._weights()]
         return (None, None, None, None, None, *outs)
 
@@ -126,7 +129,7 @@ class PosteriorRNN_hybrid(PosteriorBaseEncoder):
         owner = self._owner() if self._owner is not None else None
         views = getattr(owner, "_grad_views", None) if owner is not None else None
         if views is not None and p in views:
-            return views[p]
+            return views[p].detach()
         return torch.empty_like(p)
 
     def forward(self, x, lengths, eps=None):

@@ -1,0 +1,206 @@
+"""Train-step harness: the body of ``Runner.train``'s inner loop (``runners/pytorch_runner_vae.py:286,
+311-324``) around the HIP model — zero_grad, ``_forward`` (:76-98), loss = CE + kl_weight*KL (+ alpha*MSE),
+backward, ``clip_grad_norm_(max_grad_norm)``, ``Adam.step`` — with the MI355X-specific plumbing:
+
+  * all parameters live in ONE flat fp32 buffer and all gradients in another (the backward kernels write
+    straight into it), so the global-norm clip is one reduction and Adam is one fused pass
+    (acvae_grad_norm / acvae_adam_step), and the data-parallel exchange is two large RCCL all-reduces
+    (text-side bucket, launched as soon as its gradients exist and overlapped with the encoder backward,
+    then the encoder bucket) instead of ~60 per-tensor buckets;
+  * one process per GPU over ``torch.distributed`` (backend "nccl" = RCCL over xGMI); gradients are
+    averaged like torch DDP does (reference :204-207); BatchNorm statistics stay local per rank (the
+    reference uses plain BatchNorm2d) and rank 0's running buffers are broadcast before each forward
+    (DDP's default broadcast_buffers=True).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .train_util import LabelSmoothingLoss, MSELoss, Normal_kl_loss
+
+
+class FlatGradExchange:
+    """Data-parallel gradient exchange over one flat buffer split into ordered buckets.
+
+    ``ready(i)`` launches the asynchronous SUM all-reduce of bucket i (called from the backward as soon as the
+    bucket's gradients are written, so it overlaps with the rest of the backward); ``finish()`` waits for all of
+    them and returns the factor 1/world that the consumer folds into its next kernel (norm / Adam), which
+    makes it an average like torch DDP's.  Device-agnostic (RCCL on MI355X, gloo in the CPU tests)."""
+
+    def __init__(self, flat, bucket_sizes, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.slices, off = [], 0
+        for n in bucket_sizes:
+            self.slices.append((off, off + n))
+            off += n
+        assert off <= flat.numel()
+        self._works, self._done = [], set()
+
+    def begin(self):
+        self._works, self._done = [], set()
+
+    def ready(self, i):
+        if self.world == 1 or i in self._done:
+            return
+        self._done.add(i)
+        a, b = self.slices[i]
+        if b > a:
+            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for i in range(len(self.slices)):
+            self.ready(i)                      # any bucket nobody announced (e.g. frozen sub-model)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return 1.0 / self.world
+
+
+def max_over_ranks(value, device="cpu", group=None):
+    """bench.py timing contract: the step time of the job is the MAX over ranks."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def kl_weight_for(epoch, epochs, beta):
+    """runners/pytorch_runner_vae.py:286: max(0.5, epoch/epochs*beta)"""
+    return max(0.5, float(epoch) / epochs * beta)
+
+
+class TrainStep:
+    def __init__(self, model, vocab_size, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
+                 label_smoothing=True, smoothing=0.1, alpha=1.0, global_loss="MSE", process_group=None,
+                 broadcast_buffers=True):
+        self.model = model
+        self.vocab = vocab_size
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.smoothing = smoothing if label_smoothing else 0.0
+        self.alpha, self.global_loss = alpha, global_loss
+        if alpha is not None and global_loss != "MSE":
+            raise NotImplementedError("global_loss other than 'MSE' (the shipped q_logs_utt/p_logs_utt are None)")
+        self.criterion = LabelSmoothingLoss(vocab_size, self.smoothing)
+        self.kl_loss = Normal_kl_loss()
+        self.mse_loss = MSELoss()
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if self._dist() else 1
+        self.broadcast_buffers = broadcast_buffers
+        self.step_count = 0
+        self._flatten()
+        self.exchange = FlatGradExchange(self.flat_g, [self.n_text, self.n_enc], process_group)
+        model._grad_ready_cb = self._on_grads_ready
+        model.encoder._grad_ready_cb = self._on_grads_ready
+        if self._dist():
+            dist.broadcast(self.flat_p, src=0, group=self.pg)
+            if self.flat_buf is not None:
+                dist.broadcast(self.flat_buf, src=0, group=self.pg)
+
+    def _dist(self):
+        return dist.is_available() and dist.is_initialized() and (self.pg is not None or dist.get_world_size() > 1)
+
+    # ------------------------------------------------------------------ flat parameter / gradient storage
+    def _flatten(self):
+        model = self.model
+        enc_params = set(model.encoder.parameters())
+        never = {model.encoder.embed_pooled.weight, model.encoder.embed_pooled.bias}   # no gradient on this path
+        params = [p for p in model.parameters() if p.requires_grad]
+        text = [p for p in params if p not in enc_params]
+        enc = [p for p in params if p in enc_params and p not in never]
+        tail = [p for p in params if p in never]
+        order = text + enc + tail
+        dev = order[0].device
+        _lib.require_cuda(order[0])
+        sizes = [(p.numel() + 3) // 4 * 4 for p in order]          # keep every view 16-B aligned
+        total = sum(sizes)
+        self.flat_p = torch.zeros(total, device=dev)
+        self.flat_g = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        views, off = {}, 0
+        for p, sz in zip(order, sizes):
+            pv = self.flat_p[off:off + p.numel()].view_as(p)
+            pv.copy_(p.data)
+            p.data = pv
+            views[p] = self.flat_g[off:off + p.numel()].view_as(p)
+            off += sz
+        self.n_text = sum(sizes[:len(text)])
+        self.n_enc = sum(sizes[len(text):len(text) + len(enc)])
+        self.n_active = self.n_text + self.n_enc
+        self.order, self.views = order, views
+        model._set_grad_views(views)
+        # BatchNorm running statistics in one buffer (for the DDP-style broadcast)
+        bufs = [b for n, b in model.named_buffers() if b.dtype.is_floating_point]
+        self.flat_buf = None
+        if bufs:
+            self.flat_buf = torch.zeros(sum(b.numel() for b in bufs), device=dev)
+            off = 0
+            for b in bufs:
+                v = self.flat_buf[off:off + b.numel()].view_as(b)
+                v.copy_(b.data); b.data = v
+                off += b.numel()
+        self.norm_partials = torch.empty(_lib.call("acvae_grad_norm_partials"), device=dev)
+        self.total_norm = torch.zeros(1, device=dev)
+
+    # ------------------------------------------------------------------ gradient exchange
+    def _on_grads_ready(self, tag):
+        self.exchange.ready(0 if tag == "text" else 1)
+
+    # ------------------------------------------------------------------ one optimiser step
+    def forward_loss(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):
+        """Runner._forward(mode='train') + the loss line (:315-318).  Returns (loss, parts, output)."""
+        out = self.model(feats, feat_lens, caps, cap_lens, ss_ratio=ss_ratio, dis_ratio=dis_ratio)
+        lens1 = np.asarray(cap_lens) - 1
+        targets = caps[:, 1:1 + out["logits"].shape[1]].to(torch.long)
+        ce = self.criterion.masked(out["logits"], targets, lens1)     # == criterion(packed_logits, packed targets)
+        kl = self.kl_loss(out["q_means"], out["q_logs"], out["p_means"], out["p_logs"])
+        loss = ce + kl_weight * kl
+        mse = None
+        if self.alpha is not None:
+            mse = self.mse_loss(out["q_means_utt"], out["p_means_utt"])
+            loss = loss + self.alpha * mse
+        return loss, {"ce": ce.detach(), "kl": kl.detach(), "mse": None if mse is None else mse.detach()}, out
+
+    def step(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):
+        model = self.model
+        if self.world > 1 and self.broadcast_buffers and self.flat_buf is not None:
+            dist.broadcast(self.flat_buf, src=0, group=self.pg)
+        for p in self.order:
+            p.grad = None                                             # optimizer.zero_grad(set_to_none=True)
+        loss, parts, _ = self.forward_loss(feats, feat_lens, caps, cap_lens, ss_ratio, dis_ratio, kl_weight)
+        self.exchange.begin()
+        loss.backward()
+        gscale = self.exchange.finish()
+        self._check_grad_aliasing()
+        st = _lib.current_stream()
+        n = self.n_active
+        tn = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            _lib.call("acvae_grad_norm", self.flat_g, n, gscale, self.norm_partials, self.total_norm, st)
+            tn = self.total_norm
+        self.step_count += 1
+        _lib.call("acvae_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, n, self.lr,
+                  self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, gscale,
+                  float(self.max_grad_norm or 0.0), tn, st)
+        parts["loss"] = loss.detach()
+        parts["grad_norm"] = self.total_norm
+        return parts
+
+    def _check_grad_aliasing(self):
+        """The backward kernels write into the flat gradient buffer and autograd is expected to adopt those
+        views as .grad; if it cloned one instead (or a parameter got no gradient), repair the flat buffer."""
+        for p in self.order:
+            v = self.views[p]
+            if p.grad is None:
+                if v.data_ptr() < self.flat_g.data_ptr() + 4 * self.n_active:
+                    v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                p.grad = v            # autograd cloned the view; the flat buffer (already all-reduced) is authoritative
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}

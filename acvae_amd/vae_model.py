@@ -102,6 +102,7 @@ class Hybrid_VAEModel(CaptionModel):
         self.qnet._owner = weakref.ref(self)
         self.noise = None          # optional replay: dict(eps_q=[N,Tc,E], eps_p=[Tc,N,E]) consumed by the next forward
         self._grad_views = None    # {param: flat-gradient view}, set by the train-step harness
+        self._grad_ready_cb = None # called with "text" once every text-side gradient has been written
 
     # ---- plumbing: the text-side parameter table in state-dict order (include/acvae_hip.h)
     def _text_table(self):
@@ -125,7 +126,7 @@ class Hybrid_VAEModel(CaptionModel):
 
     def _grad_buffer(self, p):
         if self._grad_views is not None and p in self._grad_views:
-            return self._grad_views[p]
+            return self._grad_views[p].detach()
         return torch.empty_like(p)
 
     def _set_grad_views(self, views):

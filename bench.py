@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — training-step throughput of the AC-VAE hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimiser step (Runner.train inner loop, runners/pytorch_runner_vae.py:311-324):
+forward (Cnn10 encoder -> posterior -> prior/decoder loop) -> CE + 0.5*KL + 1.0*MSE -> backward ->
+global-norm clip -> Adam, on BASELINE.json configs[1]: B=32 clips per GPU, T=1000 frames, F=64 mel bins,
+22-token captions, vocab 5000, E=H=512, fp32, synthetic seeded data, random-init weights.  Weak scaling:
+every rank processes its own 32-clip batch; gradients are averaged over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, T, F, V, L, E = 32, 1000, 64, 5000, 22, 512
+HOP_S = 0.010  # assumed log-mel hop (PANNs/Cnn10 convention; the reference never states it: SURVEY §8(d))
+ENC_FWD_GFLOP_PER_CLIP = 26.03   # conv MACs x2 of Cnn10 at T=1000
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md, Peak FP32 (matrix)
+
+
+def build_model():
+    import torch
+    from acvae_amd.decoder import VAERNNBahdanauAttnDecoder
+    from acvae_amd.encoder import Cnn10
+    from acvae_amd.vae_model import Hybrid_VAEModel
+    torch.manual_seed(1)
+    dec = VAERNNBahdanauAttnDecoder(vocab_size=V, enc_mem_size=E, embed_size=E, hidden_size=E, dropout=0.0,
+                                    num_layers=1, rnn_type="GRU", attn_size=E)
+    return Hybrid_VAEModel(Cnn10(F, 512), dec, posterior_model="PosteriorRNN_hybrid",
+                           posterior_args={"hidden_size": E}, prior_model="PriorRNN", prior_args={"hidden_size": E})
+
+
+def synthetic(seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, T, F, generator=g)
+    caps = torch.zeros(B, L)
+    caps[:, 0] = 1; caps[:, -1] = 2
+    caps[:, 1:-1] = torch.randint(4, V, (B, L - 2), generator=g).float()
+    import numpy as np
+    return feats, caps, np.full(B, T, dtype=np.int64), np.full(B, L, dtype=np.int64)
+
+
+def host_cores():
+    """CPU cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (the GPU
+    box reports 256 logical CPUs but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference, validated against it: oracle/) timed on this box's host
+    cores on a bounded sample: ONE full optimiser step of the same workload (B=32, T=1000) after a tiny warm-up."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import acvae_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(1); random.seed(1)
+    state = {k: (torch.randn(s) * 0.05 if len(s) > 1 else torch.zeros(s)) if "num_batches" not in k else torch.zeros((), dtype=torch.long)
+             for k, s in O.state_shapes(V, E, E, None, E, 512).items()}
+    for k in state:
+        if k.endswith("running_var") or (".bn" in k and k.endswith("weight")):
+            state[k] = torch.ones_like(state[k])
+    tr = O.OracleTrainer(state, V)
+    f, c, fl, cl = O.synthetic_batch(2, 64, V, 8, seed=2)
+    tr.step(f, fl, c, cl)                                    # warm-up (allocator, thread pool)
+    feats, caps, feat_lens, cap_lens = synthetic(1)
+    t0 = time.perf_counter()
+    tr.step(feats, feat_lens, caps, cap_lens)
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full optimiser step of the same workload (B={B}, T={T}, V={V}) after a B=2,T=64 warm-up step; "
+                      f"{dt:.2f} s on {cores} host threads (torch-CPU ops)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")                      # "nccl" is RCCL on ROCm
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from acvae_amd import _lib
+    from acvae_amd.trainer import TrainStep, max_over_ranks
+
+    model = build_model().cuda().train()
+    ts = TrainStep(model, V, lr=5e-4, max_grad_norm=1.0, smoothing=0.1, alpha=1.0)
+    feats, caps, feat_lens, cap_lens = synthetic(1 + rank)
+    feats = feats.cuda()
+
+    def step():
+        random.seed(0)   # scheduled-sampling draws (ss_ratio = 1: always teacher forcing, as in epoch 1 of the reference)
+        return ts.step(feats, feat_lens.copy(), caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5)
+
+    for _ in range(args.warmup):
+        parts = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.lib().acvae_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        parts = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt, device="cuda")
+    # live per-kernel timing of the dominant kernel family (HIP events on the launch stream)
+    import ctypes
+    ms, cnt = ctypes.c_double(), ctypes.c_int64()
+    _lib.lib().acvae_prof_read(0, ctypes.byref(ms), ctypes.byref(cnt))
+    igemm_ms, igemm_n = ms.value, cnt.value
+    _lib.lib().acvae_prof_read(1, ctypes.byref(ms), ctypes.byref(cnt))
+    wgrad_ms, wgrad_n = ms.value, cnt.value
+    _lib.lib().acvae_prof_enable(0)
+    loss = float(parts["loss"])
+
+    if rank == 0:
+        n_gpus = world
+        caps_per_s = n_gpus * B * args.steps / dt
+        frames_per_s = caps_per_s * T
+        # dominant kernel: conv3x3 implicit GEMM on fp32 MFMA.  Per step it is launched 14 times: 7 forward convs
+        # (all but the Cin=1 first conv) + 7 data gradients (all but the one into the Cin=1 input).  Algorithmic
+        # flops of those launches: 2 x (26.03 - 0.074) GFLOP per clip (forward + data-gradient share the shape).
+        flops_per_step = 2 * (ENC_FWD_GFLOP_PER_CLIP - 0.074) * 1e9 * B * (T / 1000.0)
+        launches_per_step = igemm_n / max(1, args.steps)
+        avg_ms = igemm_ms / max(1, igemm_n)
+        achieved = flops_per_step * args.steps / (igemm_ms * 1e-3) / 1e12 if igemm_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_conv_igemm.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "train-step captions/s (and audio-sec/s) at B=32, 1/2/4/8 MI355X",
+            "value": caps_per_s, "unit": "captions/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: per-GPU batch B={B}, T={T} frames, F={F} mel, {L}-token captions "
+                                   f"(Tc={L - 1} decode steps), vocab {V}, E=H=A={E}, fp32; full optimiser step "
+                                   "(fwd + CE/KL/MSE loss + bwd + global-norm clip + Adam), ss_ratio=1, dis_ratio=0",
+                       "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}" if n_gpus > 1 else "single",
+                       "frames_per_s": frames_per_s, "audio_s_per_s": frames_per_s * HOP_S, "hop_s_assumed": HOP_S,
+                       "loss_last_step": loss},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (conv3x3 implicit GEMM fwd+dgrad, fp32 MFMA)",
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
+                         "algorithmic_gflop_per_launch": flops_per_step / 1e9 / max(1.0, launches_per_step),
+                         "wgrad_avg_launch_ms": wgrad_ms / max(1, wgrad_n), "wgrad_launches_per_step": wgrad_n / max(1, args.steps)},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,7 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless its name ends in _host.
  *   - the caller owns every buffer, workspaces included; the library never allocates or frees device
- *     memory and keeps no mutable global state.
+ *     memory and keeps no mutable global state (except the opt-in timing ring, acvae_prof_*).
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises.
  *   - return 0 on success, a negative ACVAE_E* code for bad arguments, or a positive hipError_t.
  *   - fp32 everywhere ("dtype f32"), token ids / lengths int64 (as torch.long).
@@ -193,6 +193,28 @@ int acvae_decode_bwd(const void* const* params, void* const* grads, const float*
                      int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc, void* stream);
 /* float caption ids (collate pads with torch.zeros -> float32, caption_dataset.py:293) -> int64 */
 int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A10  runners/pytorch_runner_vae.py:321-324: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step over
+ * one flat fp32 buffer.  acvae_grad_norm writes ||grad_scale * g||_2 to a device scalar (grad_scale = 1/world
+ * after a SUM all-reduce); acvae_adam_step applies coef = min(1, max_grad_norm / (norm + 1e-6)) (skipped when
+ * total_norm is NULL or max_grad_norm <= 0) and the bias-corrected Adam update in one pass.
+ * ------------------------------------------------------------------------------------------- */
+int64_t acvae_grad_norm_partials(void);
+int acvae_grad_norm(const float* grads, int64_t n, float grad_scale, float* partials, float* out_norm, void* stream);
+int acvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                    float max_grad_norm, const float* total_norm, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Opt-in kernel timing (bench.py's live roofline figure): while enabled, the conv launches are bracketed
+ * by HIP events on their stream; acvae_prof_read waits for them and returns the summed duration and the
+ * launch count of a tag, then clears it.  Tags: 0 = conv3x3 implicit GEMM (forward + data gradient),
+ * 1 = conv3x3 weight gradient.  This ring is the only mutable state in the library and exists only
+ * while enabled.  total_ms_host / launches_host are HOST pointers.
+ * ------------------------------------------------------------------------------------------- */
+int acvae_prof_enable(int enable);
+int acvae_prof_read(int tag, double* total_ms_host, int64_t* launches_host);
 
 #ifdef __cplusplus
 }
