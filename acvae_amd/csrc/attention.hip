@@ -76,75 +76,138 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(
   }
 }
 
-// Backward: one workgroup per clip n, looping over that clip's Tq queries so that the += into
-// dencproj[n] / denc[n] is race-free and deterministic.  tanh is recomputed (cheaper than saving
-// [R,S,A]).
+// Backward in three launches (all deterministic, no atomics):
+//   score : one workgroup per query row -> dscore[r][s] = w_s * (dctx.enc_s - sum_j w_j dctx.enc_j)   (0 at masked s)
+//   accum : grid (clip, chunk of ATB_CH frames): the workgroup OWNS dencproj/denc rows of its frames, keeps the
+//           encproj tile and the running sums in registers while it walks the clip's Tq queries (tanh is
+//           recomputed: cheaper than saving [R,S,A]), then does ONE += per element; writes per-chunk partials of
+//           dq and dv
+//   reduce: dq[r] = sum_chunk dq_part, dv_part[n] += sum_chunk dv_chunk   (fixed order)
 constexpr int ATB_THREADS = 512;
+constexpr int ATB_CH = 8;     // frames per chunk
+constexpr int ATB_SLOTS = 4;  // A, E <= ATB_SLOTS * ATB_THREADS
 
-__global__ __launch_bounds__(ATB_THREADS) void attn_bwd_kernel(
-    const float* __restrict__ dctx, long dc_sn, long dc_sj, const float* __restrict__ qproj, long q_sn, long q_sj,
-    const float* __restrict__ encproj, const float* __restrict__ enc, const int64_t* __restrict__ lens,
-    const float* __restrict__ v, const float* __restrict__ weights, long w_sn, long w_sj, float* __restrict__ dqproj,
-    long dq_sn, long dq_sj, float* __restrict__ dencproj, float* __restrict__ denc, float* __restrict__ dv_part,
-    int Tq, int S, int A, int E) {
-  extern __shared__ float smem[];  // [S] dscore, [S] w, [16] red
-  float* ds = smem;
-  float* ws = smem + S;
-  float* red = smem + 2 * S;
-  const int n = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ATB_THREADS / 64;
-  const float* P = encproj + (long)n * S * A;
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_score_kernel(
+    const float* __restrict__ dctx, long dc_sn, long dc_sj, const float* __restrict__ enc,
+    const int64_t* __restrict__ lens, const float* __restrict__ weights, long w_sn, long w_sj,
+    float* __restrict__ dscore, int Tq, int S, int E) {
+  extern __shared__ float smem[];  // [S] dw, [16] red
+  float* dw = smem;
+  float* red = smem + S;
+  const int n = blockIdx.x / Tq, j = blockIdx.x % Tq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ATT_THREADS / 64;
+  const float* dc = dctx + n * dc_sn + j * dc_sj;
+  const float* w = weights + n * w_sn + j * w_sj;
   const float* Hn = enc + (long)n * S * E;
-  float* dP = dencproj + (long)n * S * A;
-  float* dH = denc + (long)n * S * E;
   const int len = (int)lens[n];
-  // per-thread dv accumulators for a = threadIdx.x + k*ATB_THREADS (A <= 4*ATB_THREADS)
-  float dvacc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < Tq; ++j) {
-    const float* dc = dctx + n * dc_sn + j * dc_sj;
-    const float* w = weights + n * w_sn + j * w_sj;
-    const float* q = qproj + n * q_sn + j * q_sj;
-    float* dq = dqproj + n * dq_sn + j * dq_sj;
-    __syncthreads();
-    // dw_s = dctx . enc_s  (wave per frame)
-    for (int s = wave; s < S; s += nw) {
-      float acc = 0.f;
-      for (int e = lane; e < E; e += 64) acc += dc[e] * Hn[(long)s * E + e];
-      acc = wave_sum(acc);
-      if (lane == 0) { ds[s] = acc; ws[s] = w[s]; }
-    }
-    __syncthreads();
-    float dot = 0.f;
-    for (int s = threadIdx.x; s < S; s += ATB_THREADS) dot += ws[s] * ds[s];
-    dot = block_sum(dot, red);
-    __syncthreads();
-    // dscore_s; masked_fill blocks the gradient at s >= len (matters only when len == 0)
-    for (int s = threadIdx.x; s < S; s += ATB_THREADS) ds[s] = (s < len) ? ws[s] * (ds[s] - dot) : 0.f;
-    __syncthreads();
-    // denc[n,s,e] += w_s * dctx_e
-    for (int e = threadIdx.x; e < E; e += ATB_THREADS) {
-      const float d = dc[e];
-      for (int s = 0; s < S; ++s) dH[(long)s * E + e] += ws[s] * d;
-    }
-    // du = dscore_s * v_a * (1 - tanh^2) ; dP += du ; dq = sum_s du ; dv += sum_s dscore_s * tanh
-    int k = 0;
-    for (int a = threadIdx.x; a < A; a += ATB_THREADS, ++k) {
-      const float qa = q[a], va = v[a];
-      float dqa = 0.f, dva = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const float th = tanhf(qa + P[(long)s * A + a]);
-        const float g = ds[s];
-        const float du = g * va * (1.f - th * th);
-        dP[(long)s * A + a] += du;
-        dqa += du;
-        dva += g * th;
-      }
-      dq[a] = dqa;
-      dvacc[k] += dva;
+  for (int s = wave; s < S; s += nw) {
+    float acc = 0.f;
+    for (int e = lane; e < E; e += 64) acc += dc[e] * Hn[(long)s * E + e];
+    acc = wave_sum(acc);
+    if (lane == 0) dw[s] = acc;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int s = threadIdx.x; s < S; s += ATT_THREADS) dot += w[s] * dw[s];
+  dot = block_sum(dot, red);
+  float* out = dscore + (long)blockIdx.x * S;
+  // masked_fill blocks the gradient at s >= len (matters only when len == 0)
+  for (int s = threadIdx.x; s < S; s += ATT_THREADS) out[s] = (s < len) ? w[s] * (dw[s] - dot) : 0.f;
+}
+
+__global__ __launch_bounds__(ATB_THREADS) void attn_bwd_accum_kernel(
+    const float* __restrict__ dctx, long dc_sn, long dc_sj, const float* __restrict__ qproj, long q_sn, long q_sj,
+    const float* __restrict__ encproj, const float* __restrict__ v, const float* __restrict__ weights, long w_sn,
+    long w_sj, const float* __restrict__ dscore, float* __restrict__ dq_part, float* __restrict__ dv_chunk,
+    float* __restrict__ dencproj, float* __restrict__ denc, int Tq, int S, int A, int E, int nchunk) {
+  __shared__ float sds[ATB_CH], sw[ATB_CH];
+  const int n = blockIdx.x, ch = blockIdx.y;
+  const int s0 = ch * ATB_CH;
+  const int cnt = min(ATB_CH, S - s0);
+  const float* P = encproj + ((long)n * S + s0) * A;
+  float pt[ATB_CH][ATB_SLOTS], dPa[ATB_CH][ATB_SLOTS], dHa[ATB_CH][ATB_SLOTS], dva[ATB_SLOTS], va[ATB_SLOTS];
+#pragma unroll
+  for (int k = 0; k < ATB_SLOTS; ++k) {
+    const int a = threadIdx.x + k * ATB_THREADS;
+    dva[k] = 0.f;
+    va[k] = a < A ? v[a] : 0.f;
+#pragma unroll
+    for (int c = 0; c < ATB_CH; ++c) {
+      pt[c][k] = (a < A && c < cnt) ? P[(long)c * A + a] : 0.f;
+      dPa[c][k] = 0.f; dHa[c][k] = 0.f;
     }
   }
-  int k = 0;
-  for (int a = threadIdx.x; a < A; a += ATB_THREADS, ++k) dv_part[(long)n * A + a] += dvacc[k];
+  for (int j = 0; j < Tq; ++j) {
+    const long r = (long)n * Tq + j;
+    __syncthreads();
+    if (threadIdx.x < ATB_CH) {
+      const bool ok = (int)threadIdx.x < cnt;
+      sds[threadIdx.x] = ok ? dscore[r * S + s0 + threadIdx.x] : 0.f;
+      sw[threadIdx.x] = ok ? weights[n * w_sn + j * w_sj + s0 + threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    const float* q = qproj + n * q_sn + j * q_sj;
+    const float* dc = dctx + n * dc_sn + j * dc_sj;
+#pragma unroll
+    for (int k = 0; k < ATB_SLOTS; ++k) {
+      const int a = threadIdx.x + k * ATB_THREADS;
+      if (a < A) {
+        const float qa = q[a];
+        float dqa = 0.f;
+#pragma unroll
+        for (int c = 0; c < ATB_CH; ++c) {
+          const float th = tanhf(qa + pt[c][k]);
+          const float g = sds[c];
+          const float du = g * va[k] * (1.f - th * th);
+          dPa[c][k] += du;
+          dqa += du;
+          dva[k] += g * th;
+        }
+        dq_part[(r * nchunk + ch) * A + a] = dqa;
+      }
+      const int e = threadIdx.x + k * ATB_THREADS;
+      if (e < E) {
+        const float d = dc[e];
+#pragma unroll
+        for (int c = 0; c < ATB_CH; ++c) dHa[c][k] += sw[c] * d;
+      }
+    }
+  }
+  float* dP = dencproj + ((long)n * S + s0) * A;
+  float* dH = denc + ((long)n * S + s0) * E;
+#pragma unroll
+  for (int k = 0; k < ATB_SLOTS; ++k) {
+    const int a = threadIdx.x + k * ATB_THREADS;
+    if (a < A) {
+      dv_chunk[((long)n * nchunk + ch) * A + a] = dva[k];
+#pragma unroll
+      for (int c = 0; c < ATB_CH; ++c)
+        if (c < cnt) dP[(long)c * A + a] += dPa[c][k];
+    }
+    if (a < E) {
+#pragma unroll
+      for (int c = 0; c < ATB_CH; ++c)
+        if (c < cnt) dH[(long)c * E + a] += dHa[c][k];
+    }
+  }
+}
+
+__global__ void attn_bwd_reduce_kernel(const float* __restrict__ dq_part, const float* __restrict__ dv_chunk,
+                                       float* __restrict__ dqproj, long dq_sn, long dq_sj,
+                                       float* __restrict__ dv_part, int Tq, int A, int nchunk) {
+  const int n = blockIdx.x / Tq, j = blockIdx.x % Tq;
+  const long r = blockIdx.x;
+  float* dq = dqproj + n * dq_sn + j * dq_sj;
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    float acc = 0.f;
+    for (int c = 0; c < nchunk; ++c) acc += dq_part[(r * nchunk + c) * A + a];
+    dq[a] = acc;
+    if (j == 0) {
+      float dv = 0.f;
+      for (int c = 0; c < nchunk; ++c) dv += dv_chunk[((long)n * nchunk + c) * A + a];
+      dv_part[(long)n * A + a] += dv;
+    }
+  }
 }
 
 }  // namespace
@@ -165,19 +228,35 @@ extern "C" int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, co
   return ACVAE_OK;
 }
 
+extern "C" int64_t acvae_attn_bwd_workspace_bytes(int N, int Tq, int S, int A) {
+  if (N <= 0 || Tq <= 0 || S <= 0 || A <= 0) return -1;
+  const long nchunk = (S + ATB_CH - 1) / ATB_CH;
+  return ((long)N * Tq * S + (long)N * Tq * nchunk * A + (long)N * nchunk * A + 64) * (int64_t)sizeof(float);
+}
+
 extern "C" int acvae_attn_bwd(const float* dctx, int64_t dc_sn, int64_t dc_sj, const float* qproj, int64_t q_sn,
                               int64_t q_sj, const float* encproj, const float* enc, const int64_t* lens,
                               const float* v, const float* weights, int64_t w_sn, int64_t w_sj, float* dqproj,
-                              int64_t dq_sn, int64_t dq_sj, float* dencproj, float* denc, float* dv_part, int N,
-                              int Tq, int S, int A, int E, void* stream) {
-  if (!dctx || !qproj || !encproj || !enc || !lens || !v || !weights || !dqproj || !dencproj || !denc || !dv_part)
+                              int64_t dq_sn, int64_t dq_sj, float* dencproj, float* denc, float* dv_part, float* ws,
+                              int64_t ws_bytes, int N, int Tq, int S, int A, int E, void* stream) {
+  if (!dctx || !qproj || !encproj || !enc || !lens || !v || !weights || !dqproj || !dencproj || !denc || !dv_part ||
+      !ws)
     return ACVAE_EINVAL;
   if (N <= 0 || Tq <= 0 || S <= 0 || A <= 0 || E <= 0) return ACVAE_EINVAL;
-  if (S > 8192 || A > 4 * ATB_THREADS) return ACVAE_EUNSUPPORTED;
-  const size_t shm = (size_t)(2 * S + 16) * sizeof(float);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(N), dim3(ATB_THREADS), shm, (hipStream_t)stream, dctx, dc_sn, dc_sj, qproj,
-                     q_sn, q_sj, encproj, enc, lens, v, weights, w_sn, w_sj, dqproj, dq_sn, dq_sj, dencproj, denc,
-                     dv_part, Tq, S, A, E);
+  if (S > 8192 || A > ATB_SLOTS * ATB_THREADS || E > ATB_SLOTS * ATB_THREADS) return ACVAE_EUNSUPPORTED;
+  if (ws_bytes < acvae_attn_bwd_workspace_bytes(N, Tq, S, A)) return ACVAE_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = (S + ATB_CH - 1) / ATB_CH;
+  float* dscore = ws;
+  float* dq_part = dscore + (long)N * Tq * S;
+  float* dv_chunk = dq_part + (long)N * Tq * nchunk * A;
+  hipLaunchKernelGGL(attn_bwd_score_kernel, dim3(N * Tq), dim3(ATT_THREADS), (size_t)(S + 16) * sizeof(float), st,
+                     dctx, dc_sn, dc_sj, enc, lens, weights, w_sn, w_sj, dscore, Tq, S, E);
+  hipLaunchKernelGGL(attn_bwd_accum_kernel, dim3(N, nchunk), dim3(ATB_THREADS), 0, st, dctx, dc_sn, dc_sj, qproj, q_sn,
+                     q_sj, encproj, v, weights, w_sn, w_sj, dscore, dq_part, dv_chunk, dencproj, denc, Tq, S, A, E,
+                     nchunk);
+  hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(N * Tq), dim3(256), 0, st, dq_part, dv_chunk, dqproj, dq_sn, dq_sj,
+                     dv_part, Tq, A, nchunk);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

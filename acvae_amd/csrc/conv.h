@@ -24,6 +24,8 @@ int bn_finalize(const float* partials, int P, int C, double count, const float* 
                 float* running_mean, float* running_var, int64_t* nbt, int training, float* scale, float* shift,
                 float* mean, float* invstd, double* dpart, hipStream_t st);
 long colsum_scratch_doubles(int width);
+// deterministic column sums of x[P][width] (ld == width): out[i] = sum_p x[p][i]; entries >= split (if > 0) go to out2
+int colsum2(const float* x, int P, int width, double* dpart, float* out, float* out2, int split, hipStream_t st);
 int conv1_first_blocks(int N, int T);
 int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, float* Y,
                     float* partials, int N, int T, int F, hipStream_t st);

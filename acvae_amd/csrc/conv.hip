@@ -42,29 +42,34 @@ struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
       }
     }
   }
-  __device__ __forceinline__ void load(int, int kstep, int, float4* regs) const {
+  __device__ __forceinline__ void issue(int, int kstep, int, Pending& p) const {
     const int k0 = kstep * BK;
     const int tap = k0 / C;
     const int ci = k0 - tap * C + (threadIdx.x & 7) * 4;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     const long off = (long)(dy * W + dx) * C + ci;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (scale) {
-      sc = *reinterpret_cast<const float4*>(scale + ci);
-      sh = *reinterpret_cast<const float4*>(shift + ci);
+      p.sc = *reinterpret_cast<const float4*>(scale + ci);
+      p.sh = *reinterpret_cast<const float4*>(shift + ci);
     }
+    p.mask = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int hh = ph[j] + dy, ww = pw[j] + dx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-        v = *reinterpret_cast<const float4*>(X + pbase[j] + off);
-        if (scale) {
-          v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
-          v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
-        }
+      const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+      p.v[j] = *reinterpret_cast<const float4*>(ok ? X + pbase[j] + off : X);   // always a legal address
+      p.mask |= (ok ? 1u : 0u) << j;
+    }
+  }
+  __device__ __forceinline__ void finish(int, Pending& p) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = p.v[j];
+      if (scale) {
+        v.x = fmaxf(v.x * p.sc.x + p.sh.x, 0.f); v.y = fmaxf(v.y * p.sc.y + p.sh.y, 0.f);
+        v.z = fmaxf(v.z * p.sc.z + p.sh.z, 0.f); v.w = fmaxf(v.w * p.sc.w + p.sh.w, 0.f);
       }
-      regs[j] = v;
+      p.v[j] = ((p.mask >> j) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 };
@@ -91,24 +96,31 @@ struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
     }
   }
   template <int WT>
-  __device__ __forceinline__ void load(int, int k0, float4* regs) const {
+  __device__ __forceinline__ void issue(int, int k0, Pending& p) const {
     constexpr int TPR = WT / 4, RPI = 256 / TPR, ITS = BKT / RPI;
+    p.mask = 0;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-      const int p = k0 + threadIdx.x / TPR + it * RPI;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (colok && p < M) {
-        const int w = p % W, h = (p / W) % H;
-        const int hh = h + dy, ww = w + dx;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-          v = *reinterpret_cast<const float4*>(X + ((long)p + dy * W + dx) * C + ci);
-          if (scale) {
-            v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
-            v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
-          }
-        }
+      const int px = k0 + threadIdx.x / TPR + it * RPI;
+      bool ok = colok && px < M;
+      const int w = px % W, h = (px / W) % H;
+      const int hh = h + dy, ww = w + dx;
+      ok = ok && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      p.v[it] = *reinterpret_cast<const float4*>(ok ? X + ((long)px + dy * W + dx) * C + ci : X);
+      p.mask |= (ok ? 1u : 0u) << it;
+    }
+  }
+  template <int WT>
+  __device__ __forceinline__ void finish(Pending& p) const {
+    constexpr int ITS = BKT / (256 / (WT / 4));
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      float4 v = p.v[it];
+      if (scale) {
+        v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+        v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
       }
-      regs[it] = v;
+      p.v[it] = ((p.mask >> it) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 };
@@ -561,13 +573,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { red[threadIdx.x * 8 + k] = s[k]; red[threadIdx.x * 8 + 4 + k] = q[k]; }
+  for (int k = 0; k < 4; ++k) { red[k * 256 + threadIdx.x] = s[k]; red[(4 + k) * 256 + threadIdx.x] = q[k]; }
   __syncthreads();
   if (threadIdx.x < C4) {
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < npl; ++j)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] += red[(j * C4 + threadIdx.x) * 8 + k];
+      for (int k = 0; k < 8; ++k) a[k] += red[k * 256 + j * C4 + threadIdx.x];
     float* out = partials + (long)blockIdx.x * 2 * C;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { out[c + k] = a[k]; out[C + c + k] = a[4 + k]; }
@@ -751,8 +763,8 @@ int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hi
 }
 int bn0_partials_rows(long rows) { return cdiv(rows, 256); }
 
-static int colsum2(const float* partials, int P, int width, double* dpart, float* out, float* out2, int split,
-                   hipStream_t st) {
+int colsum2(const float* partials, int P, int width, double* dpart, float* out, float* out2, int split,
+            hipStream_t st) {
   const int R = P < CS_R ? (P < 1 ? 1 : P) : CS_R;
   hipLaunchKernelGGL(colsum_stage1_kernel, dim3(cdiv(width, 64), R), dim3(256), 0, st, partials, P, width, dpart);
   hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(width, 64)), dim3(64), 0, st, dpart, R, width, out, out2, split);
@@ -806,7 +818,7 @@ int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* 
   return ACVAE_OK;
 }
 
-constexpr int BNB_PIX = 2048;
+constexpr int BNB_PIX = 512;
 int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, BNB_PIX); }
 int bn_bwd(const float* Y, const float* dO, bool pool, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,

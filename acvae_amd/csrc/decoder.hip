@@ -62,7 +62,7 @@ struct PostLayout {
   // saved
   long words, x, hidden, save_f, save_r, hprev_f, hprev_r, argmax, saved_total;
   // scratch
-  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, tn, scratch_total;
+  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, tn, dpart, scratch_total;
   long tn_floats;
 };
 int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
@@ -92,6 +92,7 @@ int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
   t2 = tn_ws_floats(3 * Hq, Hq, (int)R); if (t2 > tn) tn = t2;
   L.tn_floats = tn;
   L.tn = c.take(tn);
+  L.dpart = c.take(2 * acvae::colsum_scratch_doubles(2 * E > 3 * Hq ? 2 * E : 3 * Hq));
   L.scratch_total = c.off;
   return ACVAE_OK;
 }
@@ -106,7 +107,8 @@ struct DecLayout {
   // bwd scratch
   long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a,
-      dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, scratch_bwd;
+      dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, scratch_bwd;
+  long attws_bytes;
   long tn_floats;
 };
 int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLayout& L) {
@@ -148,6 +150,12 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   mx(E, Eenc, N * S);
   L.tn_floats = tn;
   L.tn = b.take(tn);
+  {
+    int w = V; if (4 * Hp > w) w = 4 * Hp; if (3 * H > w) w = 3 * H; if (2 * E > w) w = 2 * E; if (A > w) w = A;
+    L.dpart = b.take(2 * acvae::colsum_scratch_doubles(w));
+  }
+  L.attws_bytes = acvae_attn_bwd_workspace_bytes(N, Tc, S, A > E ? A : E);
+  L.attws = b.take(L.attws_bytes / 4 + 64);
   L.scratch_bwd = b.off;
   return ACVAE_OK;
 }
@@ -225,6 +233,7 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
+  double* dpart = (double*)(sc + L.dpart);
   const int64_t* words = (const int64_t*)(sv + L.words);
   float* X = sv + L.x;
   float* hid = sv + L.hidden;
@@ -238,7 +247,7 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
     ACVAE_TRY(acvae::pool_bwd(d_q_means_utt, lens1, (const int*)(sv + L.argmax), dhid, (long)Tc * 2 * Hq, 2 * Hq, 1, N,
                               Tc, 2 * Hq, st));
   ACVAE_TRY(gemm_tn(dml, 2 * E, hid, 2 * Hq, G(TP_Q_TML_W), 2 * Hq, 2 * E, 2 * Hq, R, tn, st));
-  ACVAE_TRY(acvae::colsum_rows(dml, 2 * E, R, 2 * E, G(TP_Q_TML_B), 0, st));
+  ACVAE_TRY(acvae::colsum2(dml, R, 2 * E, dpart, G(TP_Q_TML_B), nullptr, 0, st));
   float* dx = sc + L.dx;
   for (int dir = 0; dir < 2; ++dir) {
     const int o = dir * 4;
@@ -260,9 +269,9 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
       float* tmp = dh; dh = dh2; dh2 = tmp;
     }
     ACVAE_TRY(gemm_tn(dgi, 3 * Hq, X, E, G(TP_Q_WIH + o), E, 3 * Hq, E, R, tn, st));
-    ACVAE_TRY(acvae::colsum_rows(dgi, 3 * Hq, R, 3 * Hq, G(TP_Q_BIH + o), 0, st));
+    ACVAE_TRY(acvae::colsum2(dgi, R, 3 * Hq, dpart, G(TP_Q_BIH + o), nullptr, 0, st));
     ACVAE_TRY(gemm_tn(dgh, 3 * Hq, hprev, Hq, G(TP_Q_WHH + o), Hq, 3 * Hq, Hq, R, tn, st));
-    ACVAE_TRY(acvae::colsum_rows(dgh, 3 * Hq, R, 3 * Hq, G(TP_Q_BHH + o), 0, st));
+    ACVAE_TRY(acvae::colsum2(dgh, R, 3 * Hq, dpart, G(TP_Q_BHH + o), nullptr, 0, st));
     ACVAE_TRY(transp(P(TP_Q_WIH + o), E, wt, 3 * Hq, 3 * Hq, E, st));                     // [E][3Hq]
     ACVAE_TRY(gemm(dgi, 3 * Hq, wt, 3 * Hq, nullptr, dx, E, R, E, 3 * Hq, dir, st));
   }
@@ -470,6 +479,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   const int R = N * Tc, Hp = E;
   const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
+  double* dpart = (double*)(sc + L.dpart);
   const int64_t* words = (const int64_t*)(sv + L.words);
   float* mem = sv + L.mem;
   float* rnn_d = sv + L.rnn_d;
@@ -500,7 +510,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     const float* hidp = sv + L.pool_hid;
     ACVAE_TRY(gemm(d_p_means_utt, 2 * E, wt_mlo, 2 * E, nullptr, dhid, H, N, H, 2 * E, 0, st));
     ACVAE_TRY(gemm_tn(d_p_means_utt, 2 * E, hidp, H, G(TP_MLO_W), H, 2 * E, H, N, tn, st));
-    ACVAE_TRY(acvae::colsum_rows(d_p_means_utt, 2 * E, N, 2 * E, G(TP_MLO_B), 0, st));
+    ACVAE_TRY(acvae::colsum2(d_p_means_utt, N, 2 * E, dpart, G(TP_MLO_B), nullptr, 0, st));
     ACVAE_TRY(acvae::pool_bwd(dhid, lens1, (const int*)(sv + L.pool_arg), d_out, (long)Tc * H, H, 1, N, Tc, H, st));
   } else {
     ACVAE_TRY(zero(G(TP_MLO_W), (long)2 * E * H, st));
@@ -509,7 +519,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   if (d_logits) {
     ACVAE_TRY(gemm(d_logits, V, wt_cls, V, nullptr, d_out, H, R, H, V, 1, st));
     ACVAE_TRY(gemm_tn(d_logits, V, outputs, H, G(TP_DEC_CLS_W), H, V, H, R, tn, st));
-    ACVAE_TRY(acvae::colsum_rows(d_logits, V, R, V, G(TP_DEC_CLS_B), 0, st));
+    ACVAE_TRY(acvae::colsum2(d_logits, R, V, dpart, G(TP_DEC_CLS_B), nullptr, 0, st));
   } else {
     ACVAE_TRY(zero(G(TP_DEC_CLS_W), (long)V * H, st));
     ACVAE_TRY(zero(G(TP_DEC_CLS_B), V, st));
@@ -541,7 +551,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
                    3 * H, 0, st));
     ACVAE_TRY(acvae_attn_bwd(dctx, E, 0, qd + (long)t * A, (long)Tc * A, A, sv + L.encproj_d, mem, mem_lens,
                              P(TP_DEC_ATT_V), attn_w + (long)t * S, (long)Tc * S, S, dqd + (long)t * A, (long)Tc * A, A,
-                             dencproj, dmem, dvpart, N, 1, S, A, E, st));
+                             dencproj, dmem, dvpart, sc + L.attws, L.attws_bytes, N, 1, S, A, E, st));
     // dh_prev = dh*z + dgh . W_hh + dqd . W_att[:, :H]
     ACVAE_TRY(gemm2(dgh + (long)t * 3 * H, (long)Tc * 3 * H, wt_dhh, 3 * H, 3 * H, dqd + (long)t * A, (long)Tc * A,
                     wt_datt, A, A, nullptr, dh2, H, N, H, 1, st));
@@ -549,14 +559,14 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   }
   // batched parameter gradients of the decoder
   ACVAE_TRY(gemm_tn(dgi, 3 * H, rnn_d, 3 * E, G(TP_DEC_WIH), 3 * E, 3 * H, 3 * E, R, tn, st));
-  ACVAE_TRY(acvae::colsum_rows(dgi, 3 * H, R, 3 * H, G(TP_DEC_BIH), 0, st));
+  ACVAE_TRY(acvae::colsum2(dgi, R, 3 * H, dpart, G(TP_DEC_BIH), nullptr, 0, st));
   ACVAE_TRY(gemm_tn(dgh, 3 * H, hprev_d, H, G(TP_DEC_WHH), H, 3 * H, H, R, tn, st));
-  ACVAE_TRY(acvae::colsum_rows(dgh, 3 * H, R, 3 * H, G(TP_DEC_BHH), 0, st));
+  ACVAE_TRY(acvae::colsum2(dgh, R, 3 * H, dpart, G(TP_DEC_BHH), nullptr, 0, st));
   // attention parameters: W = [query half | memory half]
   ACVAE_TRY(gemm_tn(dqd, A, hprev_d, H, G(TP_DEC_ATT_W), E + H, A, H, R, tn, st));
   ACVAE_TRY(gemm_tn(dencproj, A, mem, E, G(TP_DEC_ATT_W) + H, E + H, A, E, N * S, tn, st));
-  ACVAE_TRY(acvae::colsum_rows(dencproj, A, N * S, A, G(TP_DEC_ATT_B), 0, st));
-  ACVAE_TRY(acvae::colsum_rows(dvpart, A, N, A, G(TP_DEC_ATT_V), 0, st));
+  ACVAE_TRY(acvae::colsum2(dencproj, N * S, A, dpart, G(TP_DEC_ATT_B), nullptr, 0, st));
+  ACVAE_TRY(acvae::colsum2(dvpart, N, A, dpart, G(TP_DEC_ATT_V), nullptr, 0, st));
   ACVAE_TRY(gemm(dencproj, A, wt_datt + (long)H * A, A, nullptr, dmem, E, N * S, E, A, 1, st));
   // d(rnn_input) for the embedding and z columns
   float* drnn = sc + L.drnn;
@@ -615,10 +625,10 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   }
   // batched parameter gradients of the prior
   ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn, st));
-  ACVAE_TRY(acvae::colsum_rows(dml_all, 2 * E, R, 2 * E, G(TP_P_ML_B), 0, st));
+  ACVAE_TRY(acvae::colsum2(dml_all, R, 2 * E, dpart, G(TP_P_ML_B), nullptr, 0, st));
   ACVAE_TRY(gemm_tn(dgates, 4 * Hp, rnn_p, 3 * E, G(TP_P_WIH), 3 * E, 4 * Hp, 3 * E, R, tn, st));
-  ACVAE_TRY(acvae::colsum_rows(dgates, 4 * Hp, R, 4 * Hp, G(TP_P_BIH), 0, st));
-  ACVAE_TRY(acvae::colsum_rows(dgates, 4 * Hp, R, 4 * Hp, G(TP_P_BHH), 0, st));
+  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart, G(TP_P_BIH), nullptr, 0, st));
+  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart, G(TP_P_BHH), nullptr, 0, st));
   ACVAE_TRY(gemm_tn(dgates, 4 * Hp, hpprev, Hp, G(TP_P_WHH), Hp, 4 * Hp, Hp, R, tn, st));
   // d[emb; ctx] of the prior
   ACVAE_TRY(gemm(dgates, 4 * Hp, wt_pih, 4 * Hp, nullptr, drnn, 3 * E, R, 2 * E, 4 * Hp, 0, st));   // cols 0:2E of drnn[R,3E]
@@ -628,13 +638,13 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   ACVAE_TRY(zero(dvpart, (long)N * E, st));
   ACVAE_TRY(acvae_attn_bwd(drnn + E, (long)Tc * 3 * E, 3 * E, sv + L.qp, (long)Tc * E, E, sv + L.encproj_p, mem,
                            mem_lens, P(TP_P_ATT_V), sv + L.attw_p, (long)Tc * S, S, dqp, (long)Tc * E, E, dencproj, dmem,
-                           dvpart, N, Tc, S, E, E, st));
+                           dvpart, sc + L.attws, L.attws_bytes, N, Tc, S, E, E, st));
   // d emb_p = drnn[:, 0:E] + dqp . W_att[:, :E]
   ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn, 3 * E, R, E, E, 1, st));
   ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn, st));
   ACVAE_TRY(gemm_tn(dencproj, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn, st));
-  ACVAE_TRY(acvae::colsum_rows(dencproj, E, N * S, E, G(TP_P_ATT_B), 0, st));
-  ACVAE_TRY(acvae::colsum_rows(dvpart, E, N, E, G(TP_P_ATT_V), 0, st));
+  ACVAE_TRY(acvae::colsum2(dencproj, N * S, E, dpart, G(TP_P_ATT_B), nullptr, 0, st));
+  ACVAE_TRY(acvae::colsum2(dvpart, N, E, dpart, G(TP_P_ATT_V), nullptr, 0, st));
   ACVAE_TRY(gemm(dencproj, E, wt_patt + (long)E * E, E, nullptr, dmem, E, N * S, E, E, 1, st));
   ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, st));
   ACVAE_TRY(acvae::embed_scatter(words_c, drnn, 3 * E, G(TP_P_EMB), V, R, E, st));
@@ -643,7 +653,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(transp(P(TP_LN_W), Eenc, wt_ln, E, E, Eenc, st));                          // [Eenc][E]
     ACVAE_TRY(gemm(dmem, E, wt_ln, E, nullptr, d_mem_in, Eenc, N * S, Eenc, E, 0, st));
     ACVAE_TRY(gemm_tn(dmem, E, mem_in, Eenc, G(TP_LN_W), Eenc, E, Eenc, N * S, tn, st));
-    ACVAE_TRY(acvae::colsum_rows(dmem, E, N * S, E, G(TP_LN_B), 0, st));
+    ACVAE_TRY(acvae::colsum2(dmem, N * S, E, dpart, G(TP_LN_B), nullptr, 0, st));
   } else {
     ACVAE_TRY(acvae::copy_rows(d_mem_in, E, dmem, E, N * S, E, st));
   }

@@ -24,37 +24,63 @@ constexpr int LDS_LD = BK + 4;  // floats per LDS row
 constexpr int NT_THREADS = 256;
 
 template <int BN>
-struct NtSmem {
-  float a[2][BM * LDS_LD];
-  float b[2][BN * LDS_LD];
+struct alignas(16) NtSmem {
+  alignas(16) float a[2][BM * LDS_LD];
+  alignas(16) float b[2][BN * LDS_LD];
 };
 
-// ---- plain row-major operand loader: rows r0.., 4 rows per thread (r = (tid>>3) + 32*j), float4 at k = kstep*32 + (tid&7)*4
+// Operand loaders are split in two phases so that the global loads of K-step k+1 are all in flight while the
+// MFMAs of K-step k run: issue() only computes (clamped, always-legal) addresses and starts the loads;
+// finish() — called after the MFMAs, just before the LDS stores — applies masks / activations.  Nothing in
+// issue() may consume a loaded value (that would force an s_waitcnt vmcnt(0) in front of the MFMAs).
+struct Pending {
+  float4 v[4];
+  float4 sc, sh;      // optional per-channel affine (conv loaders)
+  unsigned mask;      // VEC4: bit j = row j valid; scalar: bits 4j..4j+3 = elements of row j valid
+};
+
+// ---- plain row-major operand loader: 4 rows per thread (r = row0 + (tid>>3) + 32*j), float4 at k = kstep*32 + (tid&7)*4
 template <bool VEC4>
 struct PlainLoader {
   const float* base;
   long ld;
   int rows, K;
   __device__ __forceinline__ void init(int) {}
-  __device__ __forceinline__ void load(int row0, int kstep, int nrow_iters, float4* regs) const {
+  __device__ __forceinline__ void issue(int row0, int kstep, int nrow_iters, Pending& p) const {
     const int c = (threadIdx.x & 7) * 4 + kstep * BK;
+    p.mask = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j >= nrow_iters) break;
       const int r = row0 + (threadIdx.x >> 3) + 32 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows) {
-        const float* p = base + (long)r * ld + c;
-        if (VEC4) {
-          if (c + 4 <= K) v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (c + 0 < K) v.x = p[0];
-          if (c + 1 < K) v.y = p[1];
-          if (c + 2 < K) v.z = p[2];
-          if (c + 3 < K) v.w = p[3];
-        }
+      if (VEC4) {
+        const bool ok = (r < rows) && (c + 4 <= K);
+        const float* q = ok ? base + (long)r * ld + c : base;
+        p.v[j] = *reinterpret_cast<const float4*>(q);
+        p.mask |= (ok ? 1u : 0u) << j;
+      } else {
+        const bool rok = r < rows;
+        const float* q = base + (rok ? (long)r * ld : 0);
+        const bool o0 = rok && c + 0 < K, o1 = rok && c + 1 < K, o2 = rok && c + 2 < K, o3 = rok && c + 3 < K;
+        p.v[j].x = q[o0 ? c + 0 : 0]; p.v[j].y = q[o1 ? c + 1 : 0];
+        p.v[j].z = q[o2 ? c + 2 : 0]; p.v[j].w = q[o3 ? c + 3 : 0];
+        p.mask |= ((o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u)) << (4 * j);
       }
-      regs[j] = v;
+    }
+  }
+  __device__ __forceinline__ void finish(int nrow_iters, Pending& p) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j >= nrow_iters) break;
+      if (VEC4) {
+        if (!((p.mask >> j) & 1u)) p.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const unsigned m = p.mask >> (4 * j);
+        if (!(m & 1u)) p.v[j].x = 0.f;
+        if (!(m & 2u)) p.v[j].y = 0.f;
+        if (!(m & 4u)) p.v[j].z = 0.f;
+        if (!(m & 8u)) p.v[j].w = 0.f;
+      }
     }
   }
 };
@@ -110,27 +136,29 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[4];
+  Pending pa, pb;
   al.init(row0);
   bl.init(col0);
   const int srow = tid >> 3, scol = (tid & 7) * 4;
   auto stash = [&](int buf) {
+    al.finish(4, pa);
+    bl.finish(BROWS, pb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&sm.a[buf][(srow + 32 * j) * LDS_LD + scol]) = ra[j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&sm.a[buf][(srow + 32 * j) * LDS_LD + scol]) = pa.v[j];
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + 32 * j) * LDS_LD + scol]) = rb[j];
+    for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + 32 * j) * LDS_LD + scol]) = pb.v[j];
   };
 
-  al.load(row0, 0, 4, ra);
-  bl.load(col0, 0, BROWS, rb);
+  al.issue(row0, 0, 4, pa);
+  bl.issue(col0, 0, BROWS, pb);
   stash(0);
   __syncthreads();
 
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < nk) {
-      al.load(row0, ks + 1, 4, ra);
-      bl.load(col0, ks + 1, BROWS, rb);
+      al.issue(row0, ks + 1, 4, pa);
+      bl.issue(col0, ks + 1, BROWS, pb);
     }
     const float* As = sm.a[cur] + (wm * 64 + li) * LDS_LD + 4 * lh;
     const float* Bs = sm.b[cur] + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
@@ -171,9 +199,9 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
 constexpr int BKT = 16;
 
 template <int WM, int WN>
-struct TnSmem {
-  float a[2][BKT * 64 * WM];
-  float b[2][BKT * 64 * WN];
+struct alignas(16) TnSmem {
+  alignas(16) float a[2][BKT * 64 * WM];
+  alignas(16) float b[2][BKT * 64 * WN];
 };
 
 // plain k-major loader: tile [BKT][W] floats, W = 64*WX; thread loads float4 at k = (tid / (W/4)) + it*(256/(W/4)), col = (tid % (W/4))*4
@@ -185,27 +213,44 @@ struct PlainKMajorLoader {
   template <int W>
   __device__ __forceinline__ void init(int) {}
   template <int W>
-  __device__ __forceinline__ void load(int col0, int k0, float4* regs) const {
+  __device__ __forceinline__ void issue(int col0, int k0, Pending& p) const {
     constexpr int TPR = W / 4;           // threads per k-row
     constexpr int ROWS_PER_IT = 256 / TPR;
     constexpr int ITS = BKT / ROWS_PER_IT;
     const int c = col0 + (threadIdx.x % TPR) * 4;
+    p.mask = 0;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       const int k = k0 + threadIdx.x / TPR + it * ROWS_PER_IT;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K) {
-        const float* p = base + (long)k * ld + c;
-        if (VEC4) {
-          if (c + 4 <= cols) v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (c + 0 < cols) v.x = p[0];
-          if (c + 1 < cols) v.y = p[1];
-          if (c + 2 < cols) v.z = p[2];
-          if (c + 3 < cols) v.w = p[3];
-        }
+      if (VEC4) {
+        const bool ok = (k < K) && (c + 4 <= cols);
+        const float* q = ok ? base + (long)k * ld + c : base;
+        p.v[it] = *reinterpret_cast<const float4*>(q);
+        p.mask |= (ok ? 1u : 0u) << it;
+      } else {
+        const bool kok = k < K;
+        const float* q = base + (kok ? (long)k * ld : 0);
+        const bool o0 = kok && c + 0 < cols, o1 = kok && c + 1 < cols, o2 = kok && c + 2 < cols, o3 = kok && c + 3 < cols;
+        p.v[it].x = q[o0 ? c + 0 : 0]; p.v[it].y = q[o1 ? c + 1 : 0];
+        p.v[it].z = q[o2 ? c + 2 : 0]; p.v[it].w = q[o3 ? c + 3 : 0];
+        p.mask |= ((o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u)) << (4 * it);
       }
-      regs[it] = v;
+    }
+  }
+  template <int W>
+  __device__ __forceinline__ void finish(Pending& p) const {
+    constexpr int ITS = BKT / (256 / (W / 4));
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      if (VEC4) {
+        if (!((p.mask >> it) & 1u)) p.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const unsigned m = p.mask >> (4 * it);
+        if (!(m & 1u)) p.v[it].x = 0.f;
+        if (!(m & 2u)) p.v[it].y = 0.f;
+        if (!(m & 4u)) p.v[it].z = 0.f;
+        if (!(m & 8u)) p.v[it].w = 0.f;
+      }
     }
   }
 };
@@ -230,32 +275,35 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[AITS], rb[BITS];
+  static_assert(AITS <= 4 && BITS <= 4, "Pending holds 4 float4");
+  Pending pa, pb;
   al.template init<TM>(row0);
   bl.template init<TN_>(col0);
   auto stash = [&](int buf) {
+    al.template finish<TM>(pa);
+    bl.template finish<TN_>(pb);
 #pragma unroll
     for (int it = 0; it < AITS; ++it) {
       const int k = tid / (TM / 4) + it * (256 / (TM / 4));
-      *reinterpret_cast<float4*>(&sm.a[buf][k * TM + (tid % (TM / 4)) * 4]) = ra[it];
+      *reinterpret_cast<float4*>(&sm.a[buf][k * TM + (tid % (TM / 4)) * 4]) = pa.v[it];
     }
 #pragma unroll
     for (int it = 0; it < BITS; ++it) {
       const int k = tid / (TN_ / 4) + it * (256 / (TN_ / 4));
-      *reinterpret_cast<float4*>(&sm.b[buf][k * TN_ + (tid % (TN_ / 4)) * 4]) = rb[it];
+      *reinterpret_cast<float4*>(&sm.b[buf][k * TN_ + (tid % (TN_ / 4)) * 4]) = pb.v[it];
     }
   };
   if (nk > 0) {
-    al.template load<TM>(row0, k_begin, ra);
-    bl.template load<TN_>(col0, k_begin, rb);
+    al.template issue<TM>(row0, k_begin, pa);
+    bl.template issue<TN_>(col0, k_begin, pb);
     stash(0);
   }
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < nk) {
-      al.template load<TM>(row0, k_begin + (ks + 1) * BKT, ra);
-      bl.template load<TN_>(col0, k_begin + (ks + 1) * BKT, rb);
+      al.template issue<TM>(row0, k_begin + (ks + 1) * BKT, pa);
+      bl.template issue<TN_>(col0, k_begin + (ks + 1) * BKT, pb);
     }
     const float* As = sm.a[cur] + lh * TM + wm * 64 + 2 * li;
     const float* Bs = sm.b[cur] + lh * TN_ + wn * 64 + 2 * li;
@@ -319,17 +367,18 @@ __device__ __forceinline__ float4 sk_load(const float* p, int k, int K) {
 template <bool VEC4>
 __device__ __forceinline__ void sk_accumulate(f32x16& acc, const float* A, long lda, const float* B, long ldb, int M,
                                               int N, int K, int m0, int n0, int wave, int li, int lh) {
-  const bool aval = (m0 + li) < M, bval = (n0 + li) < N;
-  const float* ap = A + (long)(aval ? m0 + li : 0) * lda;
-  const float* bp = B + (long)(bval ? n0 + li : 0) * ldb;
+  // rows beyond M / N are never stored, so their lanes may read row 0 instead of being zeroed (no branches)
+  const float* ap = A + (long)((m0 + li) < M ? m0 + li : 0) * lda + 4 * lh;
+  const float* bp = B + (long)((n0 + li) < N ? n0 + li : 0) * ldb + 4 * lh;
   const int G = (K + 7) / 8;
-  for (int g = wave; g < G; g += 4 * SK_WAVES) {
+  const int Gfull = VEC4 ? K / 8 : 0;   // k-groups that need no bounds check
+  int g = wave;
+  for (; g + 3 * SK_WAVES < Gfull; g += 4 * SK_WAVES) {
     float4 a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int k = (g + u * SK_WAVES) * 8 + 4 * lh;
-      a[u] = aval ? sk_load<VEC4>(ap, k, K) : make_float4(0.f, 0.f, 0.f, 0.f);  // k >= K reads give zeros
-      b[u] = bval ? sk_load<VEC4>(bp, k, K) : make_float4(0.f, 0.f, 0.f, 0.f);
+      a[u] = *reinterpret_cast<const float4*>(ap + (g + u * SK_WAVES) * 8);
+      b[u] = *reinterpret_cast<const float4*>(bp + (g + u * SK_WAVES) * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -338,6 +387,15 @@ __device__ __forceinline__ void sk_accumulate(f32x16& acc, const float* A, long 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
     }
+  }
+  for (; g < G; g += SK_WAVES) {
+    const int k = g * 8 + 4 * lh;
+    const float4 a = sk_load<VEC4>(ap - 4 * lh, k, K);   // k >= K reads give zeros
+    const float4 b = sk_load<VEC4>(bp - 4 * lh, k, K);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
   }
 }
 

@@ -53,11 +53,13 @@ int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, const float* 
                    int64_t w_sn, int64_t w_sj, int N, int Tq, int S, int A, int E, void* stream);
 /* Backward of the above for upstream dctx (attention weights carry no gradient on this path).
  * dencproj [N,S,A] and denc [N,S,E] are ACCUMULATED into (+=); dv_part [N,A] is accumulated into;
- * dqproj rows are written. */
+ * dqproj rows are written.  `ws`: scratch of acvae_attn_bwd_workspace_bytes(N,Tq,S,A). */
+int64_t acvae_attn_bwd_workspace_bytes(int N, int Tq, int S, int A);
 int acvae_attn_bwd(const float* dctx, int64_t dc_sn, int64_t dc_sj, const float* qproj, int64_t q_sn, int64_t q_sj,
                    const float* encproj, const float* enc, const int64_t* lens, const float* v,
                    const float* weights, int64_t w_sn, int64_t w_sj, float* dqproj, int64_t dq_sn, int64_t dq_sj,
-                   float* dencproj, float* denc, float* dv_part, int N, int Tq, int S, int A, int E, void* stream);
+                   float* dencproj, float* denc, float* dv_part, float* ws, int64_t ws_bytes, int N, int Tq, int S,
+                   int A, int E, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reparameterisation  z = eps * exp(.5*logvar) + mu   models/text_encoder.py:196-197,259-262.

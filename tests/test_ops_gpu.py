@@ -137,8 +137,10 @@ def test_attention_backward_vs_oracle_autograd():
     dq = torch.empty(N, Tq, A, device="cuda")
     dP = torch.zeros(N, S_, A, device="cuda"); dH = torch.zeros(N, S_, E, device="cuda")
     dv = torch.zeros(N, A, device="cuda")
+    wsb = _lib.call("acvae_attn_bwd_workspace_bytes", N, Tq, S_, A)
+    ws = torch.empty(wsb // 4, device="cuda")
     _lib.call("acvae_attn_bwd", dev(dctx), Tq * E, E, q, Tq * A, A, p, e, dev(lens), dev(v.detach()), w, Tq * S_, S_,
-              dq, Tq * A, A, dP, dH, dv, N, Tq, S_, A, E, S())
+              dq, Tq * A, A, dP, dH, dv, ws, wsb, N, Tq, S_, A, E, S())
     close(dq, Q.grad, 1e-4, 1e-5); close(dP, P.grad, 1e-4, 1e-5)
     close(dH, denc_direct, 1e-4, 1e-5); close(dv.sum(0), v.grad, 1e-4, 1e-5)
 
