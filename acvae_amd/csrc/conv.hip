@@ -29,10 +29,11 @@ struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
   int H, W, C, M;
   int ph[4], pw[4];
   long pbase[4];
+  static constexpr int AROWS = BM / RPP;
   __device__ __forceinline__ void init(int row0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int p = row0 + (threadIdx.x >> 3) + 32 * j;
+    for (int j = 0; j < AROWS; ++j) {
+      const int p = row0 + (ltid() / KT) + RPP * j;
       if (p < M) {
         pw[j] = p % W;
         ph[j] = (p / W) % H;
@@ -45,7 +46,7 @@ struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
   __device__ __forceinline__ void issue(int, int kstep, int, Pending& p) const {
     const int k0 = kstep * BK;
     const int tap = k0 / C;
-    const int ci = k0 - tap * C + (threadIdx.x & 7) * 4;
+    const int ci = k0 - tap * C + (ltid() % KT) * 4;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     const long off = (long)(dy * W + dx) * C + ci;
     if (scale) {
@@ -54,7 +55,7 @@ struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
     }
     p.mask = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AROWS; ++j) {
       const int hh = ph[j] + dy, ww = pw[j] + dx;
       const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
       p.v[j] = *reinterpret_cast<const float4*>(ok ? X + pbase[j] + off : X);   // always a legal address
@@ -63,7 +64,7 @@ struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
   }
   __device__ __forceinline__ void finish(int, Pending& p) const {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AROWS; ++j) {
       float4 v = p.v[j];
       if (scale) {
         v.x = fmaxf(v.x * p.sc.x + p.sh.x, 0.f); v.y = fmaxf(v.y * p.sc.y + p.sh.y, 0.f);
@@ -132,7 +133,8 @@ struct ConvStatsEpilogue {
   int Cout;
   template <int BN, int NTN>
   __device__ __forceinline__ void run(const f32x16 (&acc)[2][NTN], int row0, int col0, int wm, int wn, int li, int lh,
-                                      int M, int N, float* lds) const {
+                                      int M, int N, float* lds, bool compute_wave) const {
+    if (compute_wave)
 #pragma unroll
     for (int j = 0; j < NTN; ++j) {
       const int nl = wn * (BN / 2) + j * 32 + li;
@@ -170,11 +172,13 @@ struct ConvStatsEpilogue {
 };
 
 template <int BN>
-__global__ __launch_bounds__(NT_THREADS, 2) void conv_igemm_kernel(ConvRowLoader al, const float* __restrict__ Wp,
+__global__ __launch_bounds__(NT_BLOCK_THREADS, 2) void conv_igemm_kernel(ConvRowLoader al, const float* __restrict__ Wp,
                                                                    ConvStatsEpilogue ep, int M, int Cout, int K) {
   __shared__ NtSmem<BN> sm;
   PlainLoader<true> bl{Wp, K, Cout, K};
-  nt_block<BN>(al, bl, M, Cout, K, blockIdx.x, blockIdx.y, ep, sm);
+  int bm, bn;
+  xcd_tile(gridDim.x, gridDim.y, bm, bn);
+  nt_block<BN>(al, bl, M, Cout, K, bm, bn, ep, sm);
 }
 
 template <int WM, int WN>
@@ -697,10 +701,10 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
   if (Cout <= 64) {
     dim3 grid(cdiv(M, BM), cdiv(Cout, 64));
-    hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(NT_THREADS), 0, st, al, Wp, ep, M, Cout, K);
+    hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(NT_BLOCK_THREADS), 0, st, al, Wp, ep, M, Cout, K);
   } else {
     dim3 grid(cdiv(M, BM), cdiv(Cout, 128));
-    hipLaunchKernelGGL(conv_igemm_kernel<128>, grid, dim3(NT_THREADS), 0, st, al, Wp, ep, M, Cout, K);
+    hipLaunchKernelGGL(conv_igemm_kernel<128>, grid, dim3(NT_BLOCK_THREADS), 0, st, al, Wp, ep, M, Cout, K);
   }
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();

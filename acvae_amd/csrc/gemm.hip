@@ -9,7 +9,7 @@ namespace {
 using namespace mfma;
 
 template <int BN, bool VEC4>
-__global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ A, long lda,
+__global__ __launch_bounds__(NT_BLOCK_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ A, long lda,
                                                                 const float* __restrict__ B, long ldb,
                                                                 const float* __restrict__ bias, float* __restrict__ C,
                                                                 long ldc, int M, int N, int K, int accumulate) {
@@ -17,7 +17,9 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const float* __r
   PlainLoader<VEC4> al{A, lda, M, K}, bl{B, ldb, N, K};
   PlainEpilogue ep{C, ldc, bias, accumulate};
   // blockIdx.x walks M fastest so that consecutive blocks (dealt round-robin to XCDs) share the B panel
-  nt_block<BN>(al, bl, M, N, K, blockIdx.x, blockIdx.y, ep, sm);
+  int bm, bn;
+  xcd_tile(gridDim.x, gridDim.y, bm, bn);
+  nt_block<BN>(al, bl, M, N, K, bm, bn, ep, sm);
 }
 
 template <int WM, int WN, bool VEC4>
@@ -120,7 +122,7 @@ int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t l
   const bool bn64 = (N <= 64);
   dim3 grid(cdiv(M, BM), cdiv(N, bn64 ? 64 : 128));
 #define LAUNCH_NT(BN_, V_)                                                                                     \
-  hipLaunchKernelGGL((gemm_nt_kernel<BN_, V_>), grid, dim3(NT_THREADS), 0, st, A1, lda1, B1, ldb1, bias, C, ldc, M, \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN_, V_>), grid, dim3(NT_BLOCK_THREADS), 0, st, A1, lda1, B1, ldb1, bias, C, ldc, M, \
                      N, K1, accumulate)
   if (bn64) { if (vec) LAUNCH_NT(64, true); else LAUNCH_NT(64, false); }
   else      { if (vec) LAUNCH_NT(128, true); else LAUNCH_NT(128, false); }

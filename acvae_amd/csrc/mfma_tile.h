@@ -18,10 +18,18 @@
 
 namespace mfma {
 
+#ifndef ACVAE_BK
+#define ACVAE_BK 32
+#endif
+#ifndef ACVAE_NT_OCC
+#define ACVAE_NT_OCC 2          // workgroups per CU the NT kernels are register-budgeted for
+#endif
 constexpr int BM = 128;
-constexpr int BK = 32;
+constexpr int BK = ACVAE_BK;
 constexpr int LDS_LD = BK + 4;  // floats per LDS row
-constexpr int NT_THREADS = 256;
+constexpr int NT_THREADS = 256;   // loader (and compute) threads per workgroup
+constexpr int KT = BK / 4;      // float4 columns per tile row (threads per row)
+constexpr int RPP = NT_THREADS / KT;  // rows loaded per pass
 
 template <int BN>
 struct alignas(16) NtSmem {
@@ -33,6 +41,34 @@ struct alignas(16) NtSmem {
 // MFMAs of K-step k run: issue() only computes (clamped, always-legal) addresses and starts the loads;
 // finish() — called after the MFMAs, just before the LDS stores — applies masks / activations.  Nothing in
 // issue() may consume a loaded value (that would force an s_waitcnt vmcnt(0) in front of the MFMAs).
+// Loader threads: in the warp-specialised kernel only wavefronts 4..7 load; their lane id within the loader
+// group is threadIdx.x - NT_LOADER_BASE.
+#ifndef ACVAE_NT_WS
+#define ACVAE_NT_WS 1
+#endif
+#if ACVAE_NT_WS
+#define NT_LOADER_BASE 256
+#define NT_BLOCK_THREADS 512
+#else
+#define NT_LOADER_BASE 0
+#define NT_BLOCK_THREADS 256
+#endif
+__device__ __forceinline__ int ltid() { return (int)threadIdx.x - NT_LOADER_BASE; }
+
+// XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin to the 8 XCDs (observed,
+// not contractual: only speed depends on it), so give each XCD a CONTIGUOUS run of the tile sequence; neighbouring
+// M-tiles share im2col halo rows / operand panels and then meet in the same 4 MiB L2.  Bijective for any count.
+__device__ __forceinline__ void xcd_tile(int nm, int nn, int& bm, int& bn) {
+  const int total = nm * nn;
+  const int b = blockIdx.x + blockIdx.y * nm;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  // XCD x owns q (+1 if x < r) consecutive tiles starting at x*q + min(x, r)
+  const int t = xcd * q + (xcd < r ? xcd : r) + idx;
+  bm = t % nm;
+  bn = t / nm;
+}
+
 struct Pending {
   float4 v[4];
   float4 sc, sh;      // optional per-channel affine (conv loaders)
@@ -47,12 +83,12 @@ struct PlainLoader {
   int rows, K;
   __device__ __forceinline__ void init(int) {}
   __device__ __forceinline__ void issue(int row0, int kstep, int nrow_iters, Pending& p) const {
-    const int c = (threadIdx.x & 7) * 4 + kstep * BK;
+    const int c = (ltid() % KT) * 4 + kstep * BK;
     p.mask = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j >= nrow_iters) break;
-      const int r = row0 + (threadIdx.x >> 3) + 32 * j;
+      const int r = row0 + (ltid() / KT) + RPP * j;
       if (VEC4) {
         const bool ok = (r < rows) && (c + 4 <= K);
         const float* q = ok ? base + (long)r * ld + c : base;
@@ -95,7 +131,8 @@ struct PlainEpilogue {
   int accumulate;
   template <int BN, int NTN>
   __device__ __forceinline__ void run(const f32x16 (&acc)[2][NTN], int row0, int col0, int wm, int wn, int li, int lh,
-                                      int M, int N, float*) const {
+                                      int M, int N, float*, bool compute_wave) const {
+    if (!compute_wave) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -121,7 +158,9 @@ template <int BN, class ALoader, class BLoader, class Epilogue>
 __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, int K, int block_m, int block_n,
                                          const Epilogue& ep, NtSmem<BN>& sm) {
   constexpr int NTN = BN / 64;  // MFMA tiles per wave along N
-  constexpr int BROWS = BN / 32;  // B row iterations per thread
+  constexpr int AROWS = BM / RPP;  // A row iterations per thread
+  constexpr int BROWS = BN / RPP;  // B row iterations per thread
+  static_assert(AROWS <= 4 && BROWS <= 4 && BROWS >= 1, "Pending holds 4 float4");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -136,30 +175,20 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Pending pa, pb;
+#if !ACVAE_NT_WS
   al.init(row0);
   bl.init(col0);
-  const int srow = tid >> 3, scol = (tid & 7) * 4;
-  auto stash = [&](int buf) {
-    al.finish(4, pa);
+#endif
+  const int srow = tid / KT, scol = (tid % KT) * 4;
+  [[maybe_unused]] auto stash = [&](int buf, Pending& pa, Pending& pb) {
+    al.finish(AROWS, pa);
     bl.finish(BROWS, pb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&sm.a[buf][(srow + 32 * j) * LDS_LD + scol]) = pa.v[j];
+    for (int j = 0; j < AROWS; ++j) *reinterpret_cast<float4*>(&sm.a[buf][(srow + RPP * j) * LDS_LD + scol]) = pa.v[j];
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + 32 * j) * LDS_LD + scol]) = pb.v[j];
+    for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + RPP * j) * LDS_LD + scol]) = pb.v[j];
   };
-
-  al.issue(row0, 0, 4, pa);
-  bl.issue(col0, 0, BROWS, pb);
-  stash(0);
-  __syncthreads();
-
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) {
-      al.issue(row0, ks + 1, 4, pa);
-      bl.issue(col0, ks + 1, BROWS, pb);
-    }
+  auto compute = [&](int cur) {
     const float* As = sm.a[cur] + (wm * 64 + li) * LDS_LD + 4 * lh;
     const float* Bs = sm.b[cur] + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
 #pragma unroll
@@ -179,12 +208,107 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (ks + 1 < nk) stash(cur ^ 1);
+  };
+
+#if ACVAE_NT_WS
+  // Warp-specialised schedule: wavefronts 0-3 (one per SIMD) only read LDS and issue MFMAs; wavefronts 4-7 (their
+  // SIMD partners) only load, activate and store the next tile.  Two identical waves sharing a SIMD finish their MFMA
+  // phase together and then both stall the matrix pipe while they stage (measured: 124 vs 148 TFLOP/s without
+  // staging); with split roles the matrix pipe always has a wave ready and the staging VALU/VMEM work co-issues.
+  if (wave >= 4) {
+    // loader wavefronts: two register sets, tiles requested TWO K-steps before they are written to the 2-deep LDS ring
+    Pending pa0, pb0, pa1, pb1;
+    al.init(row0);
+    bl.init(col0);
+    const int lt = ltid();
+    const int srow_l = lt / KT, scol_l = (lt % KT) * 4;
+    auto stash_l = [&](int buf, Pending& pa, Pending& pb) {
+      al.finish(AROWS, pa);
+      bl.finish(BROWS, pb);
+#pragma unroll
+      for (int j = 0; j < AROWS; ++j)
+        *reinterpret_cast<float4*>(&sm.a[buf][(srow_l + RPP * j) * LDS_LD + scol_l]) = pa.v[j];
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j)
+        *reinterpret_cast<float4*>(&sm.b[buf][(srow_l + RPP * j) * LDS_LD + scol_l]) = pb.v[j];
+    };
+    al.issue(row0, 0, AROWS, pa0);
+    bl.issue(col0, 0, BROWS, pb0);
+    if (nk > 1) {
+      al.issue(row0, 1, AROWS, pa1);
+      bl.issue(col0, 1, BROWS, pb1);
+    }
+    stash_l(0, pa0, pb0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+      if (ks + 2 < nk) {
+        al.issue(row0, ks + 2, AROWS, pa0);
+        bl.issue(col0, ks + 2, BROWS, pb0);
+      }
+      if (ks + 1 < nk) stash_l(1, pa1, pb1);
+      __syncthreads();
+      if (ks + 1 >= nk) break;
+      if (ks + 3 < nk) {
+        al.issue(row0, ks + 3, AROWS, pa1);
+        bl.issue(col0, ks + 3, BROWS, pb1);
+      }
+      if (ks + 2 < nk) stash_l(0, pa0, pb0);
+      __syncthreads();
+    }
+  } else {
+#ifdef ACVAE_WS_PRIO
+    __builtin_amdgcn_s_setprio(ACVAE_WS_PRIO);   // matrix waves win issue arbitration against their loader partners
+#endif
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+      compute(ks & 1);
+      __syncthreads();
+    }
+#ifdef ACVAE_WS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  }
+#else
+  // Global loads run TWO K-steps ahead of the MFMAs (two register sets, statically named so nothing is
+  // dynamically indexed), the LDS ring is two deep: tile ks+2 is requested before the MFMAs of tile ks, tile ks+1
+  // (requested one iteration earlier) is activated + written to LDS after them.  One barrier per K-step.
+  Pending pa0, pb0, pa1, pb1;
+  al.issue(row0, 0, AROWS, pa0);
+  bl.issue(col0, 0, BROWS, pb0);
+  if (nk > 1) {
+    al.issue(row0, 1, AROWS, pa1);
+    bl.issue(col0, 1, BROWS, pb1);
+  }
+  stash(0, pa0, pb0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ks += 2) {
+    // even step: compute tile ks from LDS[0]; slot 0 registers are free -> request tile ks+2 into them
+    if (ks + 2 < nk) {
+      al.issue(row0, ks + 2, AROWS, pa0);
+      bl.issue(col0, ks + 2, BROWS, pb0);
+    }
+    compute(0);
+    if (ks + 1 < nk) stash(1, pa1, pb1);
+    __syncthreads();
+    if (ks + 1 >= nk) break;
+    // odd step: compute tile ks+1 from LDS[1]; request tile ks+3 into slot 1
+    if (ks + 3 < nk) {
+      al.issue(row0, ks + 3, AROWS, pa1);
+      bl.issue(col0, ks + 3, BROWS, pb1);
+    }
+    compute(1);
+    if (ks + 2 < nk) stash(0, pa0, pb0);
     __syncthreads();
   }
 
+#endif
+
   // all waves are past the last LDS read (barrier above): LDS is free for the epilogue
-  ep.template run<BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0]);
+#if ACVAE_NT_WS
+  ep.template run<BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], wave < 4);
+#else
+  ep.template run<BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], true);
+#endif
 }
 
 

@@ -18,8 +18,9 @@ _SCRATCH = {}
 
 
 def scratch_buffer(nbytes, device):
-    """Grow-only per-device scratch (contents are dead between library calls)."""
-    key = (device.type, device.index)
+    """Grow-only scratch per (device, stream): contents are dead between library calls, and calls on one stream
+    are ordered, so one buffer per stream is enough (the posterior runs on a side stream beside the encoder)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         _SCRATCH[key] = buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -11,6 +11,7 @@ reparameterisations — SURVEY F9 —, ``torch.rand(1)`` per step when dis_ratio
 outputs and wires three autograd nodes (encoder, posterior, decode loop), each ONE call into
 libacvae_hip.so for forward and one for backward.
 """
+import os
 import random
 import weakref
 
@@ -100,6 +101,7 @@ class Hybrid_VAEModel(CaptionModel):
             nn.init.xavier_uniform_(self.ln.weight)
         nn.init.xavier_uniform_(self.mean_log_out.weight)
         self.qnet._owner = weakref.ref(self)
+        self.use_side_stream = os.environ.get("ACVAE_SIDE_STREAM", "1") != "0"
         self.noise = None          # optional replay: dict(eps_q=[N,Tc,E], eps_p=[Tc,N,E]) consumed by the next forward
         self._grad_views = None    # {param: flat-gradient view}, set by the train-step harness
         self._grad_ready_cb = None # called with "text" once every text-side gradient has been written
@@ -133,6 +135,11 @@ class Hybrid_VAEModel(CaptionModel):
         self._grad_views = views
         self.encoder._grad_views = views
 
+    def _side_stream(self, main):
+        if getattr(self, "_side", None) is None or self._side.device != main.device:
+            self._side = torch.cuda.Stream(device=main.device)
+        return self._side
+
     # ---- reference API
     def train_forward(self, encoded, caps, cap_lens, **kwargs):
         return self.stepwise_forward(encoded, caps, cap_lens, **kwargs)
@@ -148,8 +155,25 @@ class Hybrid_VAEModel(CaptionModel):
         """models/vae_model.py:732-760"""
         if len(input) == 4:
             feats, feat_lens, caps, cap_lens = input
+            # The posterior (42 serial BiGRU steps of tiny kernels) does not depend on the encoder: run it on a side
+            # HIP stream beside the MFMA-bound encoder; autograd replays its backward on that stream too, where it
+            # overlaps with the encoder backward.
+            main = torch.cuda.current_stream()
+            side = self._side_stream(main) if self.use_side_stream else main
+            eps_q = None if self.noise is None else self.noise.get("eps_q")
+            if eps_q is None:                                      # same generator order as the reference: the
+                lens1 = np.asarray(cap_lens) - 1                   # posterior's randn precedes the per-step draws
+                eps_q = torch.randn(feats.shape[0], int(lens1.max()), self.decoder.embed_size)
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                qnetout = self.qnet(caps, cap_lens, eps=eps_q)
             encoded = self.encoder(feats, feat_lens)
-            qnetout = self.qnet(caps, cap_lens, eps=None if self.noise is None else self.noise.get("eps_q"))
+            if side is not main:
+                main.wait_stream(side)
+                for v in qnetout.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(main)
             encoded.update(qnetout)
             return self.train_forward(encoded, caps, cap_lens, **kwargs)
         if len(input) == 2:
