@@ -47,4 +47,6 @@ int relu_dropout(float* x, int total, DropoutSpec drop, hipStream_t st);
 // gemm.hip
 int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1, const float* A2,
                        int64_t lda2, const float* B2, int64_t ldb2, int K2, const float* bias, float* C, int64_t ldc,
-                       int M, int N, int accumulate, hipStream_t st);
+                       int M, int N, int accumulate, hipStream_t st, float* skws = nullptr);
+long acvae_skinny_ws_floats();
+int acvae_skinny_ws_reset(float* ws, hipStream_t st);

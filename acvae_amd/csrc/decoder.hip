@@ -24,16 +24,23 @@ struct Bump {
   long take(long n) { const long o = off; off = (off + n + 63) & ~63L; return o; }
 };
 
+// call context: the stream plus the split-K workspace of the skinny GEMM (converts to hipStream_t for everything else)
+struct Ctx {
+  hipStream_t s;
+  float* skws;
+  operator hipStream_t() const { return s; }
+};
 inline int gemm(const float* A, long lda, const float* B, long ldb, const float* bias, float* C, long ldc, int M, int N,
-                int K, int acc, hipStream_t st) {
-  return acvae_gemm_nt_dual(A, lda, B, ldb, K, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, acc, st);
+                int K, int acc, const Ctx& st) {
+  return acvae_gemm_nt_dual(A, lda, B, ldb, K, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, acc, st.s, st.skws);
 }
 inline int gemm2(const float* A1, long lda1, const float* B1, long ldb1, int K1, const float* A2, long lda2,
                  const float* B2, long ldb2, int K2, const float* bias, float* C, long ldc, int M, int N, int acc,
-                 hipStream_t st) {
-  if (M <= 64) return acvae_gemm_nt_dual(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, bias, C, ldc, M, N, acc, st);
-  ACVAE_TRY(acvae_gemm_nt_dual(A1, lda1, B1, ldb1, K1, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, acc, st));
-  return acvae_gemm_nt_dual(A2, lda2, B2, ldb2, K2, nullptr, 0, nullptr, 0, 0, nullptr, C, ldc, M, N, 1, st);
+                 const Ctx& st) {
+  if (M <= 64)
+    return acvae_gemm_nt_dual(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, bias, C, ldc, M, N, acc, st.s, st.skws);
+  ACVAE_TRY(acvae_gemm_nt_dual(A1, lda1, B1, ldb1, K1, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, acc, st.s, st.skws));
+  return acvae_gemm_nt_dual(A2, lda2, B2, ldb2, K2, nullptr, 0, nullptr, 0, 0, nullptr, C, ldc, M, N, 1, st.s, st.skws);
 }
 struct TnWs { float* p; long bytes; };
 inline int gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K, TnWs ws,
@@ -62,7 +69,7 @@ struct PostLayout {
   // saved
   long words, x, hidden, save_f, save_r, hprev_f, hprev_r, argmax, saved_total;
   // scratch
-  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, tn, dpart, scratch_total;
+  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, tn, dpart, skws, scratch_total;
   long tn_floats;
 };
 int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
@@ -93,6 +100,7 @@ int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
   L.tn_floats = tn;
   L.tn = c.take(tn);
   L.dpart = c.take(2 * acvae::colsum_scratch_doubles(2 * E > 3 * Hq ? 2 * E : 3 * Hq));
+  L.skws = c.take(acvae_skinny_ws_floats());
   L.scratch_total = c.off;
   return ACVAE_OK;
 }
@@ -103,7 +111,7 @@ struct DecLayout {
   long words, mem, encproj_d, encproj_p, qd, qp, attw_p, rnn_d, rnn_p, gru_save, hprev_d, lstm_save, c_all, hp_all,
       hpprev, lse, pool_arg, pool_hid, unfinished, saved_total;
   // fwd scratch
-  long gi_d, gh_d, gates_p, ml, h0, scratch_fwd;
+  long skws, gi_d, gh_d, gates_p, ml, h0, scratch_fwd;
   // bwd scratch
   long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a,
@@ -127,10 +135,12 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   L.unfinished = s.take(N);
   L.saved_total = s.off;
   Bump f;
+  L.skws = f.take(acvae_skinny_ws_floats());   // same offset (0) in the forward and backward scratch maps
   L.gi_d = f.take(R * 3 * H); L.gh_d = f.take((long)N * 3 * H); L.gates_p = f.take(R * 4 * Hp);
   L.ml = f.take((long)N * 2 * E); L.h0 = f.take((long)N * (H > Hp ? H : Hp));
   L.scratch_fwd = f.off;
   Bump b;
+  b.take(acvae_skinny_ws_floats());            // skinny split-K workspace at offset 0 (L.skws)
   L.wt_cls = b.take((long)H * V + 64); L.wt_dih = b.take((long)3 * E * 3 * H); L.wt_dhh = b.take((long)H * 3 * H);
   L.wt_datt = b.take((long)(E + H) * A); L.wt_pih = b.take((long)3 * E * 4 * Hp); L.wt_phh = b.take((long)Hp * 4 * Hp);
   L.wt_pml = b.take((long)Hp * 2 * E); L.wt_patt = b.take((long)2 * E * E); L.wt_mlo = b.take((long)H * 2 * E);
@@ -183,9 +193,10 @@ extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* cap
   if (!params || !caps || !lens1 || !eps_q || !q_means || !q_logs || !q_z || !q_means_utt || !saved_v || !scratch_v)
     return ACVAE_EINVAL;
   if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_total * 4) return ACVAE_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
+  Ctx st{(hipStream_t)stream, sc + L.skws};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   const int R = N * Tc;
   int64_t* words = (int64_t*)(sv + L.words);
@@ -226,9 +237,10 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   ACVAE_TRY(post_layout(N, Tc, E, Hq, V, L));
   if (!params || !grads || !lens1 || !eps_q || !q_logs || !saved_v || !scratch_v) return ACVAE_EINVAL;
   if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_total * 4) return ACVAE_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
+  Ctx st{(hipStream_t)stream, sc + L.skws};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc;
@@ -310,9 +322,10 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
   if (train && (!lens1 || !q_z || !ss_flags_host || !dis_flags_host || !p_means_utt)) return ACVAE_EINVAL;
   if (train && H != E) return ACVAE_EUNSUPPORTED;  // mean_log_out = Linear(embed_size, .) is fed the GRU output
   if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_fwd * 4) return ACVAE_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
+  Ctx st{(hipStream_t)stream, sc + L.skws};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   const int R = N * Tc, Hp = E;
   const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
@@ -471,9 +484,10 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
       !p_logs || !d_mem_in || !d_q_z || !saved_v || !scratch_v)
     return ACVAE_EINVAL;
   if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_bwd * 4) return ACVAE_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
+  Ctx st{(hipStream_t)stream, sc + L.skws};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc, Hp = E;

@@ -2,6 +2,7 @@
 // input/hidden projections, mean/log-variance heads, vocabulary classifier) and their gradients.
 // Replaces torch.nn.Linear / F.linear at models/attn_model.py:32, models/decoder.py:198,
 // models/text_encoder.py:192,255, models/vae_model.py:726 and the GEMMs inside nn.GRU / nn.LSTM.
+#include <cstdlib>
 #include "mfma_tile.h"
 #include "../../include/acvae_hip.h"
 
@@ -48,31 +49,72 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, long slab_str
   }
 }
 
+// gridDim.z = S K-slices per output tile.  S == 1: the block owns the tile.  S > 1: every slice writes its partial
+// tile to a slab and takes a ticket; the block that draws the last ticket sums the S slabs IN SLICE ORDER (so the
+// result does not depend on which block was last: deterministic) and runs the epilogue.  Hand-off = the agent-scope
+// release/acquire counter recipe of cdna_hip_programming.md §6 Guideline 16; the counter is reset by the reducer
+// (and zeroed once per composite call by the host: acvae_skinny_ws_reset).
+constexpr int SK_MAX_TILES = 1024;
 template <bool VEC4>
 __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const float* __restrict__ A1, long lda1,
                                                                  const float* __restrict__ B1, long ldb1, int K1,
                                                                  const float* __restrict__ A2, long lda2,
                                                                  const float* __restrict__ B2, long ldb2, int K2,
                                                                  const float* __restrict__ bias, float* __restrict__ C,
-                                                                 long ldc, int M, int N, int accumulate) {
+                                                                 long ldc, int M, int N, int accumulate,
+                                                                 float* __restrict__ slabs, unsigned* __restrict__ cnt) {
   __shared__ float red[SK_WAVES][32][33];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int S = gridDim.z, z = blockIdx.z;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  sk_accumulate<VEC4>(acc, A1, lda1, B1, ldb1, M, N, K1, m0, n0, wave, li, lh);
-  if (A2) sk_accumulate<VEC4>(acc, A2, lda2, B2, ldb2, M, N, K2, m0, n0, wave, li, lh);
+  // K-groups (of 8) are dealt round-robin to the S*8 (slice, wave) pairs
+  sk_accumulate<VEC4>(acc, A1, lda1, B1, ldb1, M, N, K1, m0, n0, z * SK_WAVES + wave, S * SK_WAVES, li, lh);
+  if (A2) sk_accumulate<VEC4>(acc, A2, lda2, B2, ldb2, M, N, K2, m0, n0, z * SK_WAVES + wave, S * SK_WAVES, li, lh);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
   __syncthreads();
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  float* my = slabs + ((long)tile * S + z) * 1024;
+  if (S > 1) {
+    for (int e = threadIdx.x; e < 1024; e += SK_THREADS) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) v += red[w][e >> 5][e & 31];
+      my[e] = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(&cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == (unsigned)(S - 1));
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+  }
+  const float* base = slabs + (long)tile * S * 1024;
   for (int e = threadIdx.x; e < 1024; e += SK_THREADS) {
     const int mm = e >> 5, nn = e & 31;
     const int m = m0 + mm, n = n0 + nn;
     if (m < M && n < N) {
       float v = 0.f;
+      if (S > 1) {
+        for (int q = 0; q < S; ++q) v += base[(long)q * 1024 + e];
+      } else {
 #pragma unroll
-      for (int w = 0; w < SK_WAVES; ++w) v += red[w][mm][nn];
+        for (int w = 0; w < SK_WAVES; ++w) v += red[w][mm][nn];
+      }
       if (bias) v += bias[n];
       float* p = C + (long)m * ldc + n;
       if (accumulate) v += *p;
@@ -101,21 +143,41 @@ inline bool vec_ok(const float* p, int64_t ld, int k) { return aligned16(p) && (
 }  // namespace
 
 // Internal C++ entry (also used by the composite encoder/decoder drivers).
+long acvae_skinny_ws_floats() { return SK_MAX_TILES + (long)SK_MAX_TILES * 1024; }
+int acvae_skinny_ws_reset(float* ws, hipStream_t st) {   // zero the ticket counters (first SK_MAX_TILES words)
+  return hipMemsetAsync(ws, 0, SK_MAX_TILES * sizeof(unsigned), st) == hipSuccess ? ACVAE_OK : (int)hipGetLastError();
+}
+
 int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1, const float* A2,
                        int64_t lda2, const float* B2, int64_t ldb2, int K2, const float* bias, float* C, int64_t ldc,
-                       int M, int N, int accumulate, hipStream_t st) {
+                       int M, int N, int accumulate, hipStream_t st, float* skws) {
   if (!A1 || !B1 || !C || M <= 0 || N <= 0 || K1 <= 0) return ACVAE_EINVAL;
   if (A2 && (!B2 || K2 <= 0)) return ACVAE_EINVAL;
   bool vec = vec_ok(A1, lda1, K1) && vec_ok(B1, ldb1, K1);
   if (A2) vec = vec && vec_ok(A2, lda2, K2) && vec_ok(B2, ldb2, K2);
   if (M <= 64 || A2) {
-    dim3 grid(cdiv(N, 32), cdiv(M, 32));
+    const int tiles = cdiv(N, 32) * cdiv(M, 32);
+    // split K over more workgroups when there are few tiles and K is long (the serial decode/BPTT steps)
+    int S = 1;
+    const int Ktot = K1 + (A2 ? K2 : 0);
+    static const bool splitk_on = !(getenv("ACVAE_SKINNY_SPLITK") && getenv("ACVAE_SKINNY_SPLITK")[0] == '0');  // tuning switch
+    if (skws && splitk_on && tiles < 128) {
+      S = 192 / tiles;
+      const int maxs = Ktot / 256;       // keep >= 256 k per slice
+      if (S > maxs) S = maxs;
+      if (S > 8) S = 8;
+      if (S < 1) S = 1;
+      if ((long)tiles * S > SK_MAX_TILES) S = 1;
+    }
+    dim3 grid(cdiv(N, 32), cdiv(M, 32), S);
+    unsigned* cnt = (unsigned*)skws;
+    float* slabs = skws ? skws + SK_MAX_TILES : nullptr;
     if (vec)
       hipLaunchKernelGGL(gemm_skinny_kernel<true>, grid, dim3(SK_THREADS), 0, st, A1, lda1, B1, ldb1, K1, A2, lda2, B2,
-                         ldb2, K2, bias, C, ldc, M, N, accumulate);
+                         ldb2, K2, bias, C, ldc, M, N, accumulate, slabs, cnt);
     else
       hipLaunchKernelGGL(gemm_skinny_kernel<false>, grid, dim3(SK_THREADS), 0, st, A1, lda1, B1, ldb1, K1, A2, lda2,
-                         B2, ldb2, K2, bias, C, ldc, M, N, accumulate);
+                         B2, ldb2, K2, bias, C, ldc, M, N, accumulate, slabs, cnt);
     ACVAE_LAUNCH_CHECK();
     return ACVAE_OK;
   }
@@ -134,7 +196,7 @@ int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t l
 extern "C" int acvae_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
                              int64_t ldc, int M, int N, int K, int accumulate, void* stream) {
   return acvae_gemm_nt_dual(A, lda, B, ldb, K, nullptr, 0, nullptr, 0, 0, bias, C, ldc, M, N, accumulate,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, nullptr);
 }
 
 static int tn_splits(int M, int N, int K) {

@@ -490,19 +490,19 @@ __device__ __forceinline__ float4 sk_load(const float* p, int k, int K) {
 
 template <bool VEC4>
 __device__ __forceinline__ void sk_accumulate(f32x16& acc, const float* A, long lda, const float* B, long ldb, int M,
-                                              int N, int K, int m0, int n0, int wave, int li, int lh) {
+                                              int N, int K, int m0, int n0, int wave, int nwaves, int li, int lh) {
   // rows beyond M / N are never stored, so their lanes may read row 0 instead of being zeroed (no branches)
   const float* ap = A + (long)((m0 + li) < M ? m0 + li : 0) * lda + 4 * lh;
   const float* bp = B + (long)((n0 + li) < N ? n0 + li : 0) * ldb + 4 * lh;
   const int G = (K + 7) / 8;
   const int Gfull = VEC4 ? K / 8 : 0;   // k-groups that need no bounds check
   int g = wave;
-  for (; g + 3 * SK_WAVES < Gfull; g += 4 * SK_WAVES) {
+  for (; g + 3 * nwaves < Gfull; g += 4 * nwaves) {
     float4 a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      a[u] = *reinterpret_cast<const float4*>(ap + (g + u * SK_WAVES) * 8);
-      b[u] = *reinterpret_cast<const float4*>(bp + (g + u * SK_WAVES) * 8);
+      a[u] = *reinterpret_cast<const float4*>(ap + (long)(g + u * nwaves) * 8);
+      b[u] = *reinterpret_cast<const float4*>(bp + (long)(g + u * nwaves) * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -512,7 +512,7 @@ __device__ __forceinline__ void sk_accumulate(f32x16& acc, const float* A, long 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
     }
   }
-  for (; g < G; g += SK_WAVES) {
+  for (; g < G; g += nwaves) {
     const int k = g * 8 + 4 * lh;
     const float4 a = sk_load<VEC4>(ap - 4 * lh, k, K);   // k >= K reads give zeros
     const float4 b = sk_load<VEC4>(bp - 4 * lh, k, K);
