@@ -678,3 +678,109 @@ extern "C" int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, vo
   if (!caps || !out || n <= 0) return ACVAE_EINVAL;
   return acvae::caps_to_long(caps, out, (long)n, (hipStream_t)stream);
 }
+
+// ==========================================================================================
+// single decode steps (inference only): the per-step API of the reference's pnet / decoder modules, used by the
+// beam search (models/vae_model.py:896-995) and by anyone calling the sub-modules directly
+// ==========================================================================================
+namespace {
+struct StepLayout { long skws, encproj, rnn, q, gates, gh, ml, words, total; };
+int step_layout(int N, int S, int E, int H, int A, int V, StepLayout& L) {
+  if (N <= 0 || S <= 0 || E <= 0 || H <= 0 || A <= 0 || V <= 1) return ACVAE_EINVAL;
+  Bump b;
+  L.skws = b.take(acvae_skinny_ws_floats());
+  L.encproj = b.take((long)N * S * (A > E ? A : E));
+  L.rnn = b.take((long)N * 3 * E);
+  L.q = b.take((long)N * (A > E ? A : E));
+  L.gates = b.take((long)N * 4 * E);
+  L.gh = b.take((long)N * 3 * H);
+  L.ml = b.take((long)N * 2 * E);
+  L.words = b.take((long)N * 2);
+  L.total = b.off;
+  return ACVAE_OK;
+}
+}  // namespace
+
+extern "C" int64_t acvae_step_scratch_bytes(int N, int S, int E, int H, int A, int V) {
+  StepLayout L;
+  return step_layout(N, S, E, H, A, V, L) == ACVAE_OK ? L.total * 4 : -1;
+}
+
+// encproj = mem . W[:, hs_dec:]^T + b for the decoder attention (which = 0) or the prior attention (which = 1)
+extern "C" int acvae_attn_precompute(const void* const* params, int which, const float* mem, float* encproj, int N,
+                                     int S, int E, int H, int A, void* stream) {
+  if (!params || !mem || !encproj || N <= 0 || S <= 0) return ACVAE_EINVAL;
+  Ctx st{(hipStream_t)stream, nullptr};
+  auto P = [&](int i) { return (const float*)params[i]; };
+  if (which == 0) return gemm(mem, E, P(TP_DEC_ATT_W) + H, E + H, P(TP_DEC_ATT_B), encproj, A, N * S, A, E, 0, st);
+  return gemm(mem, E, P(TP_P_ATT_W) + E, 2 * E, P(TP_P_ATT_B), encproj, E, N * S, E, E, 0, st);
+}
+
+extern "C" int acvae_prior_step_fwd(const void* const* params, const int64_t* word, const float* mem,
+                                    const int64_t* mem_lens, const float* encproj_p, const float* h_prev,
+                                    const float* c_prev, const float* last_z, const float* eps, float* mean, float* logv,
+                                    float* z, float* h_out, float* c_out, float* attw, void* scratch_v,
+                                    int64_t scratch_bytes, int N, int S, int E, int V, void* stream) {
+  StepLayout L;
+  ACVAE_TRY(step_layout(N, S, E, E, E, V, L));
+  if (!params || !word || !mem || !mem_lens || !h_prev || !c_prev || !last_z || !eps || !mean || !logv || !z ||
+      !h_out || !c_out || !attw || !scratch_v)
+    return ACVAE_EINVAL;
+  if (scratch_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  float* sc = (float*)scratch_v;
+  Ctx st{(hipStream_t)stream, sc + L.skws};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  auto P = [&](int i) { return (const float*)params[i]; };
+  const int Hp = E;
+  float* rnn = sc + L.rnn;
+  float* q = sc + L.q;
+  float* gates = sc + L.gates;
+  float* ml = sc + L.ml;
+  const float* ep = encproj_p;
+  if (!ep) {
+    ACVAE_TRY(gemm(mem, E, P(TP_P_ATT_W) + E, 2 * E, P(TP_P_ATT_B), sc + L.encproj, E, N * S, E, E, 0, st));
+    ep = sc + L.encproj;
+  }
+  ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_P_EMB), V, rnn, 3 * E, N, E, st));
+  ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_ATT_W), 2 * E, nullptr, q, E, N, E, E, 0, st));
+  ACVAE_TRY(acvae_attn_fwd(q, E, 0, ep, mem, mem_lens, P(TP_P_ATT_V), rnn + E, 3 * E, 0, attw, S, 0, N, 1, S, E, E, st));
+  ACVAE_TRY(acvae::copy_rows(rnn + 2 * E, 3 * E, last_z, E, N, E, st));
+  ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_WIH), 3 * E, P(TP_P_BIH), gates, 4 * Hp, N, 4 * Hp, 3 * E, 0, st));
+  ACVAE_TRY(gemm(h_prev, Hp, P(TP_P_WHH), Hp, P(TP_P_BHH), gates, 4 * Hp, N, 4 * Hp, Hp, 1, st));
+  ACVAE_TRY(acvae::lstm_fwd(gates, 4 * Hp, c_prev, Hp, h_out, Hp, c_out, Hp, nullptr, 0, N, Hp, st));
+  ACVAE_TRY(gemm(h_out, Hp, P(TP_P_ML_W), Hp, P(TP_P_ML_B), ml, 2 * E, N, 2 * E, Hp, 0, st));
+  return acvae_reparam_fwd(ml, 2 * E, eps, E, mean, logv, z, E, nullptr, 0, N, E, st);
+}
+
+extern "C" int acvae_decoder_step_fwd(const void* const* params, const int64_t* word, const float* h_prev,
+                                      const float* mem, const int64_t* mem_lens, const float* encproj_d, const float* z,
+                                      float* logits, float* h_out, float* attw, float* rnn_input, void* scratch_v,
+                                      int64_t scratch_bytes, int N, int S, int E, int H, int A, int V, void* stream) {
+  StepLayout L;
+  ACVAE_TRY(step_layout(N, S, E, H, A, V, L));
+  if (!params || !word || !h_prev || !mem || !mem_lens || !z || !logits || !h_out || !attw || !rnn_input || !scratch_v)
+    return ACVAE_EINVAL;
+  if (scratch_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  float* sc = (float*)scratch_v;
+  Ctx st{(hipStream_t)stream, sc + L.skws};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  auto P = [&](int i) { return (const float*)params[i]; };
+  float* q = sc + L.q;
+  float* gi = sc + L.gates;
+  float* gh = sc + L.gh;
+  const float* ed = encproj_d;
+  if (!ed) {
+    ACVAE_TRY(gemm(mem, E, P(TP_DEC_ATT_W) + H, E + H, P(TP_DEC_ATT_B), sc + L.encproj, A, N * S, A, E, 0, st));
+    ed = sc + L.encproj;
+  }
+  ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_DEC_EMB), V, rnn_input, 3 * E, N, E, st));
+  ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_ATT_W), E + H, nullptr, q, A, N, A, H, 0, st));
+  ACVAE_TRY(acvae_attn_fwd(q, A, 0, ed, mem, mem_lens, P(TP_DEC_ATT_V), rnn_input + E, 3 * E, 0, attw, S, 0, N, 1, S, A,
+                           E, st));
+  ACVAE_TRY(acvae::copy_rows(rnn_input + 2 * E, 3 * E, z, E, N, E, st));
+  ACVAE_TRY(gemm(rnn_input, 3 * E, P(TP_DEC_WIH), 3 * E, P(TP_DEC_BIH), gi, 3 * H, N, 3 * H, 3 * E, 0, st));
+  ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_WHH), H, P(TP_DEC_BHH), gh, 3 * H, N, 3 * H, H, 0, st));
+  ACVAE_TRY(acvae::gru_fwd(gi, 3 * H, gh, 3 * H, h_prev, H, h_out, H, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, N,
+                           H, st));
+  return gemm(h_out, H, P(TP_DEC_CLS_W), H, P(TP_DEC_CLS_B), logits, V, N, V, H, 0, st);
+}

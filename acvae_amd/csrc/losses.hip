@@ -247,6 +247,55 @@ __global__ __launch_bounds__(EW_THREADS) void ce_bwd_kernel(const float* __restr
   for (int c = threadIdx.x; c < V; c += EW_THREADS) d[c] = g * (expf(x[c] - l) - (c == tg ? on : off));
 }
 
+
+// ------------------------------------------------------------------ beam-search helpers (N1)
+// out[n,c] = logits[n,c] - lse[n] + prev[n]      (log_softmax + accumulated beam log-prob, vae_model.py:909-912)
+__global__ void logprob_add_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ lse,
+                                   const float* __restrict__ prev, float* __restrict__ out, int N, int V) {
+  const long total = (long)N * V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / V), c = (int)(i % V);
+    out[i] = logits[n * ld + c] - lse[n] + (prev ? prev[n] : 0.f);
+  }
+}
+// flat top-k (k <= 16) of x[0..n), sorted descending, ties -> lower index first (torch.topk(sorted=True) order for
+// distinct values); one workgroup, k selection passes.  Also emits idx / V and idx % V.
+__global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict__ x, long n, int k, int V,
+                                                         float* __restrict__ vals, int64_t* __restrict__ idx,
+                                                         int64_t* __restrict__ row, int64_t* __restrict__ col) {
+  __shared__ float rv[16];
+  __shared__ long ri[16];
+  __shared__ float sel_v[16];
+  __shared__ long sel_i[16];
+  for (int j = 0; j < k; ++j) {
+    float bv = -INFINITY;
+    long bi = 0x7fffffffffffffffL;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+      const float v = x[i];
+      bool taken = false;
+      for (int q = 0; q < j; ++q) taken = taken || (sel_i[q] == i);
+      if (!taken && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const long oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = bv; ri[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+        if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+      sel_v[j] = bv; sel_i[j] = bi;
+      vals[j] = bv; idx[j] = bi;
+      if (row) row[j] = bi / V;
+      if (col) col[j] = bi % V;
+    }
+    __syncthreads();
+  }
+}
+
 inline int grid_for(long n, int per_block) {
   long b = (n + per_block - 1) / per_block;
   return (int)(b < 1 ? 1 : (b > RED_BLOCKS_MAX ? RED_BLOCKS_MAX : b));
@@ -357,6 +406,24 @@ extern "C" int acvae_ls_ce_bwd(const float* logits, int64_t ld_n, int64_t ld_t, 
   if ((reduction == 0 && !grad_rows) || (reduction != 0 && !grad_out)) return ACVAE_EINVAL;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(N * T), dim3(EW_THREADS), 0, (hipStream_t)stream, logits, ld_n, ld_t, targets,
                      tg_sn, lens1, lse, smoothing, reduction, grad_out, grad_rows, dlogits, N, T, V);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_logprob_add(const float* logits, int64_t ld, const float* lse, const float* prev, float* out, int N,
+                                 int V, void* stream) {
+  if (!logits || !lse || !out || N <= 0 || V <= 0) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(logprob_add_kernel, dim3(grid_for((long)N * V, EW_THREADS)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, logits, ld, lse, prev, out, N, V);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx, int64_t* row,
+                               int64_t* col, void* stream) {
+  if (!x || !vals || !idx || n <= 0 || k <= 0 || k > 16 || k > n || V <= 0) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(topk_flat_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, k, V, vals, idx, row,
+                     col);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

@@ -5,7 +5,9 @@ arithmetic lives in libacvae_hip.so and is driven by Hybrid_VAEModel through acv
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .attn_model import Seq2SeqAttention
+from .encoder import ptr_table, scratch_buffer
 
 
 class BaseDecoder(nn.Module):
@@ -62,11 +64,36 @@ class VAERNNBahdanauAttnDecoder(RNNDecoder):
         attn_size = kwargs.get("attn_size", self.model.hidden_size)
         self.attn = Seq2SeqAttention(enc_mem_size, self.model.hidden_size, attn_size)
         self.mem_size = enc_mem_size
+        self._owner = None          # weakref to the Hybrid_VAEModel (set by it)
         if self.embed_size != enc_mem_size:
             # the reference sizes the GRU input as embed + 2*enc_mem but feeds [emb(E); ctx(mem); z(E)] (:171,:188)
             raise ValueError("VAERNNBahdanauAttnDecoder needs embed_size == enc_mem_size (SURVEY §8)")
 
     def forward(self, **kwargs):
-        raise NotImplementedError(
-            "single-step decoder calls are fused into acvae_decode_fwd on the HIP path; call "
-            "Hybrid_VAEModel.forward (training or method='greedy' inference)")
+        """One decode step (inference, no gradient): models/decoder.py:175-203.  word [N,1] (or [N]), state [1,N,H],
+        enc_mem [N,S,E], enc_mem_lens [N], z [N,E] -> {"state","output","logits","weights","rnn_input"}.
+        Training goes through Hybrid_VAEModel.forward, where the whole loop is one fused call."""
+        if self._owner is None:
+            raise RuntimeError("VAERNNBahdanauAttnDecoder.forward needs the parameters of its Hybrid_VAEModel "
+                               "(the HIP library addresses the text side as one table)")
+        owner = self._owner()
+        enc_mem = kwargs["enc_mem"]
+        _lib.require_cuda(enc_mem)
+        dev = enc_mem.device
+        enc_mem = enc_mem.contiguous().float()
+        N, S, E = enc_mem.shape
+        H, A, V = self.model.hidden_size, self.attn.attn_size, self.vocab_size
+        w = kwargs["word"].reshape(-1).to(device=dev, dtype=torch.long).contiguous()
+        h_prev = kwargs["state"].reshape(N, H).to(dev).contiguous().float()
+        z = kwargs["z"].reshape(N, E).to(dev).contiguous().float()
+        lens = torch.as_tensor(kwargs["enc_mem_lens"]).to(device=dev, dtype=torch.long).contiguous()
+        with torch.no_grad():
+            encproj = owner._encproj(0, enc_mem)
+            logits = torch.empty(N, V, device=dev); h_out = torch.empty(N, H, device=dev)
+            attw = torch.empty(N, S, device=dev); rnn_in = torch.empty(N, 3 * E, device=dev)
+            sb = _lib.call("acvae_step_scratch_bytes", N, S, E, H, A, V)
+            scratch = scratch_buffer(sb, dev)
+            _lib.call("acvae_decoder_step_fwd", ptr_table(owner._text_table()), w, h_prev, enc_mem, lens, encproj, z,
+                      logits, h_out, attw, rnn_in, scratch, sb, N, S, E, H, A, V, _lib.current_stream())
+        return {"state": h_out.unsqueeze(0), "output": h_out.unsqueeze(1), "logits": logits.unsqueeze(1),
+                "weights": attw, "rnn_input": rnn_in.unsqueeze(1)}

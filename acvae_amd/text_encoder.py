@@ -170,12 +170,39 @@ class PriorRNN(PriorBaseEncoder):
                                bidirectional=False, batch_first=True)
         self.mean_log_out = nn.Linear(self.hidden_size, 2 * embed_size)
         self.init()
+        self._owner = None
 
     def init_hidden(self, bs, device):
         z = lambda: torch.zeros(self.num_layers, bs, self.embed_size, device=device)
         return (z(), z())
 
-    def forward(self, word, enc_mem, hiddens_state, last_z, lens):
-        raise NotImplementedError(
-            "single-step prior calls are fused into acvae_decode_fwd on the HIP path; call "
-            "Hybrid_VAEModel.forward (training or method='greedy' inference)")
+    def forward(self, word, enc_mem, hiddens_state, last_z, lens, eps=None):
+        """One prior step (inference, no gradient): models/text_encoder.py:247-268.  word [N,1], enc_mem [N,S,E],
+        hiddens_state (h, c) each [1,N,E], last_z [N,E], lens [N] -> {"mean","log","hiddens_state","z"}.
+        eps: optional N(0,1) draw; default torch.randn on the CPU generator (:259)."""
+        if self._owner is None:
+            raise RuntimeError("PriorRNN.forward needs the parameters of its Hybrid_VAEModel")
+        owner = self._owner()
+        _lib.require_cuda(enc_mem)
+        dev = enc_mem.device
+        enc_mem = enc_mem.contiguous().float()
+        N, S, E = enc_mem.shape
+        V = self.vocab_size
+        w = word.reshape(-1).to(device=dev, dtype=torch.long).contiguous()
+        h_prev = hiddens_state[0].reshape(N, E).to(dev).contiguous().float()
+        c_prev = hiddens_state[1].reshape(N, E).to(dev).contiguous().float()
+        last_z = last_z.reshape(N, E).to(dev).contiguous().float()
+        lens_d = torch.as_tensor(lens).to(device=dev, dtype=torch.long).contiguous()
+        if eps is None:
+            eps = torch.randn(N, E)
+        eps = eps.to(dev).contiguous().float()
+        with torch.no_grad():
+            encproj = owner._encproj(1, enc_mem)
+            mean, logv, z, h, c = (torch.empty(N, E, device=dev) for _ in range(5))
+            attw = torch.empty(N, S, device=dev)
+            H, A = owner.decoder.model.hidden_size, owner.decoder.attn.attn_size
+            sb = _lib.call("acvae_step_scratch_bytes", N, S, E, H, A, V)
+            scratch = scratch_buffer(sb, dev)
+            _lib.call("acvae_prior_step_fwd", ptr_table(owner._text_table()), w, enc_mem, lens_d, encproj, h_prev,
+                      c_prev, last_z, eps, mean, logv, z, h, c, attw, scratch, sb, N, S, E, V, _lib.current_stream())
+        return {"mean": mean, "log": logv, "hiddens_state": (h.unsqueeze(0), c.unsqueeze(0)), "z": z}

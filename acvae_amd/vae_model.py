@@ -101,6 +101,9 @@ class Hybrid_VAEModel(CaptionModel):
             nn.init.xavier_uniform_(self.ln.weight)
         nn.init.xavier_uniform_(self.mean_log_out.weight)
         self.qnet._owner = weakref.ref(self)
+        self.pnet._owner = weakref.ref(self)
+        self.decoder._owner = weakref.ref(self)
+        self._encproj_cache = {}
         self.use_side_stream = os.environ.get("ACVAE_SIDE_STREAM", "1") != "0"
         self.noise = None          # optional replay: dict(eps_q=[N,Tc,E], eps_p=[Tc,N,E]) consumed by the next forward
         self._grad_views = None    # {param: flat-gradient view}, set by the train-step harness
@@ -135,6 +138,78 @@ class Hybrid_VAEModel(CaptionModel):
         self._grad_views = views
         self.encoder._grad_views = views
 
+    def _encproj(self, which, enc_mem):
+        """Hoisted encoder half of an attention (0: decoder.attn, 1: pnet.word_attn) for single-step calls; cached per
+        memory tensor so a beam-search loop projects the clip once instead of once per step."""
+        key = (which, enc_mem.data_ptr(), tuple(enc_mem.shape), enc_mem._version)
+        hit = self._encproj_cache.get(which)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        N, S, E = enc_mem.shape
+        H, A = self.decoder.model.hidden_size, self.decoder.attn.attn_size
+        out = torch.empty(N, S, A if which == 0 else E, device=enc_mem.device)
+        _lib.call("acvae_attn_precompute", ptr_table(self._text_table()), which, enc_mem, out, N, S, E, H, A,
+                  _lib.current_stream())
+        self._encproj_cache[which] = (key, out, enc_mem)      # keep enc_mem alive so its address cannot be reused
+        return out
+
+    @torch.no_grad()
+    def beam_search(self, encoded, max_length, beam_size):
+        """Validation beam search, models/vae_model.py:896-995: clip by clip, beams expanded over the flat
+        beam*V log-probabilities, states re-gathered by prev_word_inds; returns beam 0 (the reference never fills
+        done_beams, :986-995).  Host logic as in the reference; every tensor op is a library call."""
+        mem_all = encoded["audio_embeds"].contiguous()
+        dev = mem_all.device
+        if hasattr(self, "ln"):                              # vae_model.py:754-755
+            Nn, Ss, Ee = mem_all.shape
+            proj = torch.empty(Nn, Ss, self.decoder.embed_size, device=dev)
+            _lib.call("acvae_gemm_nt", mem_all, Ee, self.ln.weight, Ee, self.ln.bias, proj, self.decoder.embed_size,
+                      Nn * Ss, self.decoder.embed_size, Ee, 0, _lib.current_stream())
+            mem_all = proj
+        lens_all = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long)
+        N, S, E = mem_all.shape
+        H, V = self.decoder.model.hidden_size, self.vocab_size
+        replay = self.noise.get("eps_beam") if self.noise is not None else None
+        self.noise = None
+        seqs_out = torch.full((N, max_length), self.end_idx, dtype=torch.long, device=dev)
+        attn_out = torch.zeros(N, S, max_length, device=dev)
+        st = _lib.current_stream
+        for i in range(N):
+            mem = mem_all[i].unsqueeze(0).repeat(beam_size, 1, 1).contiguous()
+            lens = lens_all[i].repeat(beam_size)
+            state = self.decoder.init_hidden(beam_size).to(dev)
+            hid = self.pnet.init_hidden(beam_size, dev)
+            last_z = torch.zeros(beam_size, E, device=dev)
+            top_k = torch.zeros(beam_size, device=dev)
+            lse = torch.empty(beam_size, device=dev)
+            scores = torch.empty(beam_size, V, device=dev)
+            vals = torch.empty(beam_size, device=dev)
+            idx, prev, nxt = (torch.empty(beam_size, dtype=torch.long, device=dev) for _ in range(3))
+            seqs = attw = None
+            for t in range(max_length):
+                if t == 0:
+                    w = torch.full((beam_size,), self.start_idx, dtype=torch.long, device=dev)
+                else:
+                    w = nxt.clone()
+                    state = state[:, prev].contiguous()
+                    hid = (hid[0][:, prev].contiguous(), hid[1][:, prev].contiguous())
+                    last_z = last_z[prev].contiguous()
+                eps = replay[i, t] if replay is not None else None
+                pn = self.pnet(w.unsqueeze(1), mem, hid, last_z, lens, eps=eps)
+                dn = self.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
+                logits = dn["logits"].squeeze(1)
+                _lib.call("acvae_row_logsoftmax_argmax", logits, V, V, None, None, lse, 1, 1, beam_size, 1, V, st())
+                _lib.call("acvae_logprob_add", logits, V, lse, top_k, scores, beam_size, V, st())
+                _lib.call("acvae_topk_flat", scores, beam_size * V, beam_size, V, vals, idx, prev, nxt, st())
+                top_k = vals.clone()
+                seqs = nxt.unsqueeze(1).clone() if t == 0 else torch.cat([seqs[prev], nxt.unsqueeze(1)], dim=1)
+                w_t = dn["weights"].unsqueeze(2)                              # [beam,S,1]
+                attw = w_t if t == 0 else torch.cat([attw, w_t], dim=2)[prev]
+                state, hid, last_z = dn["state"], pn["hiddens_state"], pn["z"]
+            seqs_out[i] = seqs[0]
+            attn_out[i] = attw[0]
+        return {"seqs": seqs_out, "attn_weights": attn_out}
+
     def _side_stream(self, main):
         if getattr(self, "_side", None) is None or self._side.device != main.device:
             self._side = torch.cuda.Stream(device=main.device)
@@ -146,9 +221,12 @@ class Hybrid_VAEModel(CaptionModel):
 
     def inference_forward(self, encoded, **kwargs):
         method = kwargs.get("method", "greedy")
+        max_length = kwargs.get("max_length", self.max_length)
+        if method == "beam":                                              # vae_model.py:884-886
+            return self.beam_search(encoded, max_length, kwargs.get("beam_size", 3))
         if method != "greedy":
             raise NotImplementedError(f"inference method {method!r}: the HIP path implements greedy decoding with "
-                                      "z ~ prior (beam / dbs / sampling are SURVEY §8(f) next rows)")
+                                      "z ~ prior and beam search (dbs / gumbel / multinomial are SURVEY §8(f) next rows)")
         return self.stepwise_forward(encoded, None, None, **kwargs)
 
     def forward(self, *input, **kwargs):

@@ -218,6 +218,31 @@ int acvae_adam_step(float* params, const float* grads, float* exp_avg, float* ex
 int acvae_prof_enable(int enable);
 int acvae_prof_read(int tag, double* total_ms_host, int64_t* launches_host);
 
+/* ---------------------------------------------------------------------------------------------
+ * Single decode steps (inference, no gradients): the per-call API of the reference's sub-modules,
+ *   PriorRNN.forward(word, enc_mem, hiddens_state, last_z, lens)            models/text_encoder.py:247-268
+ *   VAERNNBahdanauAttnDecoder.forward(word=, state=, enc_mem=, enc_mem_lens=, z=)   models/decoder.py:175-203
+ * as used by the validation beam search (models/vae_model.py:896-995).  encproj_* may be NULL
+ * (computed into scratch) or the result of acvae_attn_precompute (hoisted out of the step loop).  word int64 [N].
+ * acvae_logprob_add / acvae_topk_flat are the beam bookkeeping of vae_model.py:909-916 (log_softmax + running beam
+ * score; flat top-k over beam*V with idx / V and idx % V).
+ * ------------------------------------------------------------------------------------------- */
+int64_t acvae_step_scratch_bytes(int N, int S, int E, int H, int A, int V);
+int acvae_attn_precompute(const void* const* params, int which, const float* mem, float* encproj, int N, int S, int E,
+                          int H, int A, void* stream);
+int acvae_prior_step_fwd(const void* const* params, const int64_t* word, const float* mem, const int64_t* mem_lens,
+                         const float* encproj_p, const float* h_prev, const float* c_prev, const float* last_z,
+                         const float* eps, float* mean, float* logv, float* z, float* h_out, float* c_out, float* attw,
+                         void* scratch, int64_t scratch_bytes, int N, int S, int E, int V, void* stream);
+int acvae_decoder_step_fwd(const void* const* params, const int64_t* word, const float* h_prev, const float* mem,
+                           const int64_t* mem_lens, const float* encproj_d, const float* z, float* logits, float* h_out,
+                           float* attw, float* rnn_input, void* scratch, int64_t scratch_bytes, int N, int S, int E,
+                           int H, int A, int V, void* stream);
+int acvae_logprob_add(const float* logits, int64_t ld, const float* lse, const float* prev, float* out, int N, int V,
+                      void* stream);
+int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx, int64_t* row, int64_t* col,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

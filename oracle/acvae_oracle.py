@@ -404,6 +404,48 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
 
 
 # ----------------------------------------------------------------------------
+# N1  Hybrid_VAEModel.beam_search   models/vae_model.py:896-995 (validation, beam_size=3)
+# ----------------------------------------------------------------------------
+def beam_search(state, feats, feat_lens, beam_size=3, max_length=MAX_LENGTH, eps=None):
+    """Instance-by-instance beam search; returns seqs i64 [N,max_length] (beam 0 of each clip; `done_beams` is
+    never filled in the reference, :986-995).  eps (optional): [N, max_length, beam, E] replay of the randn draws."""
+    enc = cnn10_forward(state, feats, feat_lens, training=False)
+    if "ln.weight" in state:
+        enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
+    mem_all, lens_all = enc["audio_embeds"], enc["audio_embeds_lens"]
+    N = mem_all.shape[0]
+    E = state["decoder.word_embeddings.weight"].shape[1]
+    H = state["decoder.model.weight_hh_l0"].shape[1]
+    V = state["decoder.classifier.weight"].shape[0]
+    seqs_out = torch.full((N, max_length), END_IDX, dtype=torch.long)
+    for i in range(N):
+        mem = mem_all[i].unsqueeze(0).repeat(beam_size, 1, 1)
+        lens = lens_all[i].repeat(beam_size)
+        h = mem.new_zeros(beam_size, H)
+        hc = (mem.new_zeros(beam_size, E), mem.new_zeros(beam_size, E))
+        last_z = mem.new_zeros(beam_size, E)
+        top_k_logprobs = mem.new_zeros(beam_size)
+        seqs = None
+        for t in range(max_length):
+            if t == 0:
+                w = torch.full((beam_size,), START_IDX, dtype=torch.long)
+            else:
+                w = next_w
+                h = h[prev]; hc = (hc[0][prev], hc[1][prev]); last_z = last_z[prev]
+            pr = prior_step(state, w.unsqueeze(1), mem, hc, last_z, lens, None if eps is None else eps[i, t])
+            d = decoder_step(state, w.unsqueeze(1), h, mem, lens, pr["z"])
+            logprobs = torch.log_softmax(d["logits"], dim=1)
+            logprobs = top_k_logprobs.unsqueeze(1).expand_as(logprobs) + logprobs
+            top_k_logprobs, top_k_words = logprobs.view(-1).topk(beam_size, 0, True, True)
+            prev = torch.div(top_k_words, V, rounding_mode="trunc")
+            next_w = top_k_words % V
+            seqs = next_w.unsqueeze(1) if t == 0 else torch.cat([seqs[prev], next_w.unsqueeze(1)], dim=1)
+            h, hc, last_z = d["state"], pr["hiddens_state"], pr["z"]
+        seqs_out[i] = seqs[0]
+    return seqs_out
+
+
+# ----------------------------------------------------------------------------
 # A8/A9/A13 losses ; A10 loss assembly + optimiser
 # ----------------------------------------------------------------------------
 def label_smoothing_loss(logit, target, classes, smoothing):

@@ -245,6 +245,25 @@ def g7_decode(ref):
     save("g7_decode", **d)
 
 
+def g9_beam(ref):
+    """G9: validation beam search, beam_size=3 (models/vae_model.py:896-995), eval mode."""
+    V, E, beam = 50, 64, 3
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    model = ref_shim.build_reference_model(ref, V, E, E)
+    load_state_into(model, state)
+    model.eval()
+    feats, _, feat_lens, _ = O.synthetic_batch(3, 96, V, 8, seed=9, ragged=True)
+    torch.manual_seed(90)
+    with torch.no_grad():
+        ro = model(feats, feat_lens.copy(), method="beam", beam_size=beam)
+    torch.manual_seed(90)                       # the only generator calls are pnet's randn([beam,E]) per clip, per step
+    eps = torch.stack([torch.stack([torch.randn(beam, E) for _ in range(O.MAX_LENGTH)]) for _ in range(3)])
+    with torch.no_grad():
+        oo = O.beam_search({k: v.clone() for k, v in state.items()}, feats, feat_lens.copy(), beam, O.MAX_LENGTH, eps)
+    assert torch.equal(ro["seqs"], oo), (ro["seqs"], oo)
+    save("g9_beam", dims=np.array([3, 96, V, E, beam]), feats=feats, feat_lens=feat_lens, eps=eps, seqs=ro["seqs"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.load()
@@ -253,6 +272,7 @@ def main():
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)
     train_fixture(ref, "g6c_train_step_e512", 2, 64, 300, 512, 7, False, 0, seed=26, keep_tensors=False)
     g7_decode(ref)
+    g9_beam(ref)
     # G8: BASELINE config 1 shape; scalars only, noise re-drawn in the test from the stored seed.
     train_fixture(ref, "g8_config1_scalars", 8, 500, 5000, 512, 22, False, 0, seed=8, keep_tensors=False,
                   keep_noise=False)

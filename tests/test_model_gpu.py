@@ -173,3 +173,38 @@ def test_scheduled_sampling_forward_vs_oracle():
     assert np.array_equal(out["seqs"].cpu().numpy(), oo["seqs"].numpy())
     for k in ("logits", "p_means", "p_z", "p_means_utt", "attn_weights"):
         close(out[k], oo[k], 1e-4, 2e-5, what=k)
+
+
+def test_g9_beam_search_token_exact():
+    """N1: validation beam search (beam_size=3) against the reference's own output."""
+    g = load_golden("g9_beam")
+    _, _, V, E, beam = (int(x) for x in g["dims"])
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    model = build_model(V, E, state)
+    model.eval()
+    model.noise = dict(eps_beam=T(g["eps"]))
+    with torch.no_grad():
+        o = model(T(g["feats"]).cuda(), g["feat_lens"].copy(), method="beam", beam_size=beam)
+    assert np.array_equal(o["seqs"].cpu().numpy(), g["seqs"])
+
+
+def test_single_step_modules_vs_oracle():
+    """A4/A5 per-call API: pnet.forward / decoder.forward one step at a time."""
+    V, E, N, S = 40, 64, 5, 9
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    model = build_model(V, E, state).eval()
+    g = torch.Generator().manual_seed(2)
+    mem = torch.randn(N, S, E, generator=g); lens = torch.tensor([9, 7, 4, 2, 1])
+    word = torch.randint(0, V, (N, 1), generator=g)
+    h = torch.randn(1, N, E, generator=g); hp = torch.randn(1, N, E, generator=g); cp = torch.randn(1, N, E, generator=g)
+    lz = torch.randn(N, E, generator=g); eps = torch.randn(N, E, generator=g)
+    with torch.no_grad():
+        op = O.prior_step(state, word, mem, (hp[0], cp[0]), lz, lens, eps)
+        od = O.decoder_step(state, word, h[0], mem, lens, op["z"])
+        hp_ = model.pnet(word, mem.cuda(), (hp.cuda(), cp.cuda()), lz.cuda(), lens, eps=eps)
+        hd_ = model.decoder(word=word, state=h.cuda(), enc_mem=mem.cuda(), enc_mem_lens=lens, z=hp_["z"])
+    close(hp_["mean"], op["mean"], what="prior mean"); close(hp_["z"], op["z"], what="prior z")
+    close(hp_["hiddens_state"][0][0], op["hiddens_state"][0], what="prior h")
+    close(hp_["hiddens_state"][1][0], op["hiddens_state"][1], what="prior c")
+    close(hd_["logits"][:, 0], od["logits"], 1e-4, 2e-5, what="dec logits"); close(hd_["state"][0], od["state"], what="dec h")
+    close(hd_["weights"], od["weights"], what="dec attn"); close(hd_["rnn_input"][:, 0], od["rnn_input"], what="rnn_input")

@@ -131,3 +131,12 @@ def test_g7_decode_token_exact():
             o = O.hybrid_forward({k: v.clone() for k, v in state.items()}, f, list(g[tag + "_lens"]), training=False,
                                  noise=dict(eps_p=T(g[tag + "_noise_eps_p"])))
         assert np.array_equal(o["seqs"].numpy(), g[tag + "_seqs"])
+
+
+def test_g9_beam_search_token_exact():
+    g = load_golden("g9_beam")
+    _, _, V, E, beam = (int(x) for x in g["dims"])
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    with torch.no_grad():
+        seqs = O.beam_search(state, T(g["feats"]), g["feat_lens"].copy(), beam, O.MAX_LENGTH, T(g["eps"]))
+    assert np.array_equal(seqs.numpy(), g["seqs"])
