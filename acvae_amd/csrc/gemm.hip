@@ -161,8 +161,10 @@ int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t l
     int S = 1;
     const int Ktot = K1 + (A2 ? K2 : 0);
     static const bool splitk_on = !(getenv("ACVAE_SKINNY_SPLITK") && getenv("ACVAE_SKINNY_SPLITK")[0] == '0');  // tuning switch
-    if (skws && splitk_on && tiles < 128) {
-      S = 192 / tiles;
+    // Only the long-K, few-tile products of the BPTT steps gain: the release/acquire hand-off costs a few us
+    // (measured: 48 tiles x K=512 went 6.8 -> 9.8 us with S=2, 16 tiles x K=2048 went 25 -> 13.7 us with S=8).
+    if (skws && splitk_on && tiles <= 16 && Ktot >= 1024) {
+      S = 128 / tiles;
       const int maxs = Ktot / 256;       // keep >= 256 k per slice
       if (S > maxs) S = maxs;
       if (S > 8) S = 8;

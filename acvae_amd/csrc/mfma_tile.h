@@ -496,22 +496,32 @@ __device__ __forceinline__ void sk_accumulate(f32x16& acc, const float* A, long 
   const float* bp = B + (long)((n0 + li) < N ? n0 + li : 0) * ldb + 4 * lh;
   const int G = (K + 7) / 8;
   const int Gfull = VEC4 ? K / 8 : 0;   // k-groups that need no bounds check
+  // The loop is latency-bound (weights arrive from the Infinity Cache / HBM: ~1-2 us per dependent round), so keep
+  // SK_U k-groups = 2*SK_U float4 loads in flight per lane and predicate instead of branching: a slot past the end
+  // re-reads group 0 and is zeroed by a select.
+  constexpr int SK_U = 8;
   int g = wave;
-  for (; g + 3 * nwaves < Gfull; g += 4 * nwaves) {
-    float4 a[4], b[4];
+  for (; g < Gfull; g += SK_U * nwaves) {
+    float4 a[SK_U], b[SK_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = *reinterpret_cast<const float4*>(ap + (long)(g + u * nwaves) * 8);
-      b[u] = *reinterpret_cast<const float4*>(bp + (long)(g + u * nwaves) * 8);
+    for (int u = 0; u < SK_U; ++u) {
+      const int gu = g + u * nwaves;
+      const long off = (gu < Gfull) ? (long)gu * 8 : 0;
+      a[u] = *reinterpret_cast<const float4*>(ap + off);
+      b[u] = *reinterpret_cast<const float4*>(bp + off);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    for (int u = 0; u < SK_U; ++u) {
+      const bool ok = (g + u * nwaves) < Gfull;
+      const float4 av = ok ? a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[u].w, acc, 0, 0, 0);
     }
   }
+  // tail groups (K % 8 != 0) or the scalar path: bounds-checked loads
+  g = Gfull + ((wave - Gfull % nwaves) % nwaves + nwaves) % nwaves;
   for (; g < G; g += nwaves) {
     const int k = g * 8 + 4 * lh;
     const float4 a = sk_load<VEC4>(ap - 4 * lh, k, K);   // k >= K reads give zeros
