@@ -197,8 +197,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, 
                                     int Cin) {
   const long total = (long)Cout * 9 * Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    for (int z = 0; z < nsplit; ++z) acc += slab[z * total + i];
+    // four independent partial sums keep 4 loads in flight; the combination order is fixed -> deterministic
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int z = 0;
+    for (; z + 3 < nsplit; z += 4) {
+      a0 += slab[(long)z * total + i]; a1 += slab[(long)(z + 1) * total + i];
+      a2 += slab[(long)(z + 2) * total + i]; a3 += slab[(long)(z + 3) * total + i];
+    }
+    for (; z < nsplit; ++z) a0 += slab[(long)z * total + i];
+    const float acc = (a0 + a1) + (a2 + a3);
     const int co = (int)(i / (9 * Cin)), rem = (int)(i % (9 * Cin));
     const int tap = rem / Cin, ci = rem % Cin;
     dW[((long)co * Cin + ci) * 9 + tap] = acc;
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void bn0_stats_kernel(const float* __restrict_
 
 // Column sums of a [P][width] fp32 partial matrix in two fixed-order stages (deterministic):
 // stage 1: grid (width/64, R) blocks, block r sums rows p = r, r+R, ... in fp64 -> dpart[r][width].
-constexpr int CS_R = 64;
+constexpr int CS_R = 16;
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ partials, int P, int width,
                                                             double* __restrict__ dpart) {
   __shared__ double red[4][64];
@@ -715,7 +722,7 @@ int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, BM); 
 static int wgrad_splits(int M, int Cout, int NC) {
   const bool narrow = Cout <= 64;
   const long tiles = (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
-  int s = (int)(2048 / tiles);
+  int s = (int)(1024 / tiles);
   const int maxs = cdiv(M, 16 * BKT);
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;

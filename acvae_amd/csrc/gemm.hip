@@ -155,7 +155,10 @@ int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t l
   if (A2 && (!B2 || K2 <= 0)) return ACVAE_EINVAL;
   bool vec = vec_ok(A1, lda1, K1) && vec_ok(B1, ldb1, K1);
   if (A2) vec = vec && vec_ok(A2, lda2, K2) && vec_ok(B2, ldb2, K2);
-  if (M <= 64 || A2) {
+  // The 128-row tile kernel needs >= ~100 workgroups to fill the chip; mid-sized products (M = N*Tc = 672 rows
+  // against 512..2048 columns) would launch 24-96 of them and run 100-140 us, so they take the 32x32-tile kernel too.
+  const long big_blocks = (long)cdiv(M, BM) * cdiv(N, N <= 64 ? 64 : 128);
+  if (M <= 64 || A2 || (big_blocks < 100 && M <= 4096)) {
     const int tiles = cdiv(N, 32) * cdiv(M, 32);
     // split K over more workgroups when there are few tiles and K is long (the serial decode/BPTT steps)
     int S = 1;

@@ -56,15 +56,30 @@ __global__ void embed_gather_kernel(const int64_t* __restrict__ words, long w_st
 // word sums all its duplicates in row order: deterministic, no atomics.  dTable must be zeroed by the caller.
 __global__ void embed_scatter_kernel(const int64_t* __restrict__ words, const float* __restrict__ d, long ld_d,
                                      float* __restrict__ dtable, int V, int rows, int E) {
+  extern __shared__ unsigned flags[];   // bitmap over rows: 1 where words[q] == w  (rows/32 + 1 words) + 1 word "earlier"
   const int r = blockIdx.x;
   const long w = words[r];
   if (w < 0 || w >= V) return;
-  for (int q = 0; q < r; ++q)
-    if (words[q] == w) return;  // not the first occurrence (uniform across the block)
+  const int nw = (rows + 31) / 32;
+  for (int i = threadIdx.x; i <= nw; i += TH) flags[i] = 0u;
+  __syncthreads();
+  for (int q = threadIdx.x; q < rows; q += TH)
+    if (words[q] == w) {
+      if (q < r) flags[nw] = 1u;                       // an earlier row owns this word (benign race: all write 1)
+      else atomicOr(&flags[q >> 5], 1u << (q & 31));
+    }
+  __syncthreads();
+  if (flags[nw]) return;                                // uniform across the block
   for (int e = threadIdx.x; e < E; e += TH) {
     float a = 0.f;
-    for (int q = r; q < rows; ++q)
-      if (words[q] == w) a += d[q * ld_d + e];
+    for (int i = r >> 5; i < nw; ++i) {                 // ascending row order: deterministic
+      unsigned m = flags[i];
+      while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        a += d[(long)(i * 32 + b) * ld_d + e];
+      }
+    }
     dtable[w * E + e] += a;
   }
 }
@@ -273,7 +288,8 @@ int embed_gather(const int64_t* words, long w_stride, const float* table, int V,
 }
 int embed_scatter(const int64_t* words_contig, const float* d, long ld_d, float* dtable, int V, int rows, int E,
                   hipStream_t st) {
-  LAUNCH(embed_scatter_kernel, rows, words_contig, d, ld_d, dtable, V, rows, E);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(TH), (size_t)((rows + 31) / 32 + 2) * sizeof(unsigned), st,
+                     words_contig, d, ld_d, dtable, V, rows, E);
   ACVAE_LAUNCH_CHECK(); return ACVAE_OK;
 }
 int gather_words(const int64_t* src, long s_sn, long s_st, int64_t* dst, int N, int T, hipStream_t st) {
