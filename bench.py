@@ -104,10 +104,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # test hooks (one-GPU rehearsal of the multi-rank path): every rank on device 0 over gloo
+    rehearsal = os.environ.get("ACVAE_BENCH_REHEARSAL") == "1"
+    torch.cuda.set_device(0 if rehearsal else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")                      # "nccl" is RCCL on ROCm
+        dist.init_process_group("gloo" if rehearsal else "nccl")   # "nccl" is RCCL on ROCm
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
