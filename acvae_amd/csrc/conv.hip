@@ -22,18 +22,20 @@ namespace {
 using namespace mfma;
 
 // ------------------------------------------------------------------ im2col loaders
-struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
+template <int NR>
+struct ConvRowLoader {  // NT A-operand: tile rows = output pixels (NR per loader thread), k = (tap, ci)
   const float* X;
   const float* scale;  // nullable: act = identity
   const float* shift;
   int H, W, C, M;
-  int ph[4], pw[4];
-  long pbase[4];
-  static constexpr int AROWS = BM / RPP;
-  __device__ __forceinline__ void init(int row0) {
+  int ph[NR], pw[NR];
+  long pbase[NR];
+  int cq;
+  __device__ __forceinline__ void init(int row0, int lt) {
+    cq = (lt % KT) * 4;
 #pragma unroll
-    for (int j = 0; j < AROWS; ++j) {
-      const int p = row0 + (ltid() / KT) + RPP * j;
+    for (int j = 0; j < NR; ++j) {
+      const int p = row0 + (lt / KT) + RPP * j;
       if (p < M) {
         pw[j] = p % W;
         ph[j] = (p / W) % H;
@@ -43,10 +45,10 @@ struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
       }
     }
   }
-  __device__ __forceinline__ void issue(int, int kstep, int, Pending& p) const {
+  __device__ __forceinline__ void issue(int, int kstep, int, Pending<NR>& p) const {
     const int k0 = kstep * BK;
-    const int tap = k0 / C;
-    const int ci = k0 - tap * C + (ltid() % KT) * 4;
+    const int tap = k0 / C;            // wave-uniform: a K-step never straddles taps (32 | C)
+    const int ci = k0 - tap * C + cq;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     const long off = (long)(dy * W + dx) * C + ci;
     if (scale) {
@@ -55,16 +57,16 @@ struct ConvRowLoader {  // NT A-operand: rows = output pixels, k = (tap, ci)
     }
     p.mask = 0;
 #pragma unroll
-    for (int j = 0; j < AROWS; ++j) {
+    for (int j = 0; j < NR; ++j) {
       const int hh = ph[j] + dy, ww = pw[j] + dx;
       const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
       p.v[j] = *reinterpret_cast<const float4*>(ok ? X + pbase[j] + off : X);   // always a legal address
       p.mask |= (ok ? 1u : 0u) << j;
     }
   }
-  __device__ __forceinline__ void finish(int, Pending& p) const {
+  __device__ __forceinline__ void finish(Pending<NR>& p) const {
 #pragma unroll
-    for (int j = 0; j < AROWS; ++j) {
+    for (int j = 0; j < NR; ++j) {
       float4 v = p.v[j];
       if (scale) {
         v.x = fmaxf(v.x * p.sc.x + p.sh.x, 0.f); v.y = fmaxf(v.y * p.sc.y + p.sh.y, 0.f);
@@ -97,7 +99,7 @@ struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
     }
   }
   template <int WT>
-  __device__ __forceinline__ void issue(int, int k0, Pending& p) const {
+  __device__ __forceinline__ void issue(int, int k0, Pending<4>& p) const {
     constexpr int TPR = WT / 4, RPI = 256 / TPR, ITS = BKT / RPI;
     p.mask = 0;
 #pragma unroll
@@ -112,7 +114,7 @@ struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
     }
   }
   template <int WT>
-  __device__ __forceinline__ void finish(Pending& p) const {
+  __device__ __forceinline__ void finish(Pending<4>& p) const {
     constexpr int ITS = BKT / (256 / (WT / 4));
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
@@ -131,31 +133,33 @@ struct ConvStatsEpilogue {
   float* Y;          // [M][Cout]
   float* partials;   // [gridM][2][Cout] or nullptr
   int Cout;
-  template <int BN, int NTN>
+  template <int BMT, int BN, int NTN>
   __device__ __forceinline__ void run(const f32x16 (&acc)[2][NTN], int row0, int col0, int wm, int wn, int li, int lh,
-                                      int M, int N, float* lds, bool compute_wave) const {
-    if (compute_wave)
+                                      int M, int N, float* lds, bool matrix_wave) const {
+    constexpr int WMS = BMT / 64;   // matrix waves along M
+    if (matrix_wave) {
 #pragma unroll
-    for (int j = 0; j < NTN; ++j) {
-      const int nl = wn * (BN / 2) + j * 32 + li;
-      const int n = col0 + nl;
-      float s = 0.f, q = 0.f;
+      for (int j = 0; j < NTN; ++j) {
+        const int nl = wn * (BN / 2) + j * 32 + li;
+        const int n = col0 + nl;
+        float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const float v = acc[i][j][r];
-          if (m < M && n < N) Y[(long)m * Cout + n] = v;
-          s += v;          // rows >= M were staged as zeros -> contribute 0
-          q += v * v;
-        }
-      if (partials) {
-        s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 32, 64);
-        if (lh == 0) {
-          lds[(wm * 2 + 0) * BN + nl] = s;
-          lds[(wm * 2 + 1) * BN + nl] = q;
+          for (int r = 0; r < 16; ++r) {
+            const int m = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float v = acc[i][j][r];
+            if (m < M && n < N) Y[(long)m * Cout + n] = v;
+            s += v;          // rows >= M were staged as zeros -> contribute 0
+            q += v * v;
+          }
+        if (partials) {
+          s += __shfl_xor(s, 32, 64);
+          q += __shfl_xor(q, 32, 64);
+          if (lh == 0) {
+            lds[(wm * 2 + 0) * BN + nl] = s;
+            lds[(wm * 2 + 1) * BN + nl] = q;
+          }
         }
       }
     }
@@ -163,22 +167,26 @@ struct ConvStatsEpilogue {
       __syncthreads();
       const int t = threadIdx.x;
       if (t < BN && col0 + t < N) {
-        float* out = partials + (long)(row0 / BM) * 2 * Cout + col0 + t;
-        out[0] = lds[0 * BN + t] + lds[2 * BN + t];
-        out[Cout] = lds[1 * BN + t] + lds[3 * BN + t];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WMS; ++w) { s += lds[(w * 2 + 0) * BN + t]; q += lds[(w * 2 + 1) * BN + t]; }
+        float* out = partials + (long)(row0 / BMT) * 2 * Cout + col0 + t;
+        out[0] = s;
+        out[Cout] = q;
       }
     }
   }
 };
 
-template <int BN>
-__global__ __launch_bounds__(NT_BLOCK_THREADS, 2) void conv_igemm_kernel(ConvRowLoader al, const float* __restrict__ Wp,
-                                                                   ConvStatsEpilogue ep, int M, int Cout, int K) {
-  __shared__ NtSmem<BN> sm;
-  PlainLoader<true> bl{Wp, K, Cout, K};
+// BMT x BN tile; the A operand (im2col rows) carries the previous layer's BatchNorm+ReLU when al.scale != nullptr.
+template <int BMT, int BN>
+__global__ __launch_bounds__(nt_threads<BMT>(), (BMT / 32 + 4) / 4) void conv_igemm_kernel(
+    ConvRowLoader<BMT / 32> al, const float* __restrict__ Wp, ConvStatsEpilogue ep, int M, int Cout, int K) {
+  __shared__ NtSmem<BMT, BN> sm;
+  PlainLoader<true, BN / 32> bl{Wp, K, Cout, K};
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  nt_block<BN>(al, bl, M, Cout, K, bm, bn, ep, sm);
+  nt_block<BMT, BN>(al, bl, M, Cout, K, bm, bn, ep, sm);
 }
 
 template <int WM, int WN>
@@ -697,27 +705,32 @@ inline int ew_grid(long n) {
 // =============================================================================================
 namespace acvae {
 
+// M-tile height of the conv kernels.  256-row tiles (8 matrix waves, 1 workgroup per CU, -25 % operand traffic per
+// flop) were tried and measured SLOWER (encoder fwd 9.2 vs 8.2 ms): a single workgroup per CU has nobody to cover its
+// barrier bubbles.  128 rows x 2 workgroups per CU it is.
+constexpr int CONV_BMT = 128;
+
 int conv3x3_igemm(const float* X, const float* scale, const float* shift, const float* Wp, float* Y, float* partials,
                   int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   if (!X || !Wp || !Y) return ACVAE_EINVAL;
   if (Cin % 32 != 0 || Cout % 4 != 0) return ACVAE_EUNSUPPORTED;
   if (!aligned16(X) || !aligned16(Wp) || !aligned16(Y)) return ACVAE_EALIGN;
   const int M = N * H * W, K = 9 * Cin;
-  ConvRowLoader al{X, scale, shift, H, W, Cin, M};
+  ConvRowLoader<CONV_BMT / 32> al{X, scale, shift, H, W, Cin, M};
   ConvStatsEpilogue ep{Y, partials, Cout};
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
   if (Cout <= 64) {
-    dim3 grid(cdiv(M, BM), cdiv(Cout, 64));
-    hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(NT_BLOCK_THREADS), 0, st, al, Wp, ep, M, Cout, K);
+    dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 64));
+    hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 64>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
   } else {
-    dim3 grid(cdiv(M, BM), cdiv(Cout, 128));
-    hipLaunchKernelGGL(conv_igemm_kernel<128>, grid, dim3(NT_BLOCK_THREADS), 0, st, al, Wp, ep, M, Cout, K);
+    dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 128));
+    hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 128>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
   }
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
-int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, BM); }
+int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, CONV_BMT); }
 
 static int wgrad_splits(int M, int Cout, int NC) {
   const bool narrow = Cout <= 64;

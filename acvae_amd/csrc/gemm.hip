@@ -10,17 +10,18 @@ namespace {
 using namespace mfma;
 
 template <int BN, bool VEC4>
-__global__ __launch_bounds__(NT_BLOCK_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ A, long lda,
-                                                                const float* __restrict__ B, long ldb,
-                                                                const float* __restrict__ bias, float* __restrict__ C,
-                                                                long ldc, int M, int N, int K, int accumulate) {
-  __shared__ NtSmem<BN> sm;
-  PlainLoader<VEC4> al{A, lda, M, K}, bl{B, ldb, N, K};
+__global__ __launch_bounds__(nt_threads<128>(), 2) void gemm_nt_kernel(const float* __restrict__ A, long lda,
+                                                                     const float* __restrict__ B, long ldb,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ C, long ldc, int M, int N,
+                                                                     int K, int accumulate) {
+  __shared__ NtSmem<128, BN> sm;
+  PlainLoader<VEC4, 4> al{A, lda, M, K};
+  PlainLoader<VEC4, BN / 32> bl{B, ldb, N, K};
   PlainEpilogue ep{C, ldc, bias, accumulate};
-  // blockIdx.x walks M fastest so that consecutive blocks (dealt round-robin to XCDs) share the B panel
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  nt_block<BN>(al, bl, M, N, K, bm, bn, ep, sm);
+  nt_block<128, BN>(al, bl, M, N, K, bm, bn, ep, sm);
 }
 
 template <int WM, int WN, bool VEC4>
@@ -157,7 +158,7 @@ int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t l
   if (A2) vec = vec && vec_ok(A2, lda2, K2) && vec_ok(B2, ldb2, K2);
   // The 128-row tile kernel needs >= ~100 workgroups to fill the chip; mid-sized products (M = N*Tc = 672 rows
   // against 512..2048 columns) would launch 24-96 of them and run 100-140 us, so they take the 32x32-tile kernel too.
-  const long big_blocks = (long)cdiv(M, BM) * cdiv(N, N <= 64 ? 64 : 128);
+  const long big_blocks = (long)cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
   if (M <= 64 || A2 || (big_blocks < 100 && M <= 4096)) {
     const int tiles = cdiv(N, 32) * cdiv(M, 32);
     // split K over more workgroups when there are few tiles and K is long (the serial decode/BPTT steps)
@@ -187,9 +188,9 @@ int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t l
     return ACVAE_OK;
   }
   const bool bn64 = (N <= 64);
-  dim3 grid(cdiv(M, BM), cdiv(N, bn64 ? 64 : 128));
+  dim3 grid(cdiv(M, 128), cdiv(N, bn64 ? 64 : 128));
 #define LAUNCH_NT(BN_, V_)                                                                                     \
-  hipLaunchKernelGGL((gemm_nt_kernel<BN_, V_>), grid, dim3(NT_BLOCK_THREADS), 0, st, A1, lda1, B1, ldb1, bias, C, ldc, M, \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN_, V_>), grid, dim3(nt_threads<128>()), 0, st, A1, lda1, B1, ldb1, bias, C, ldc, M, \
                      N, K1, accumulate)
   if (bn64) { if (vec) LAUNCH_NT(64, true); else LAUNCH_NT(64, false); }
   else      { if (vec) LAUNCH_NT(128, true); else LAUNCH_NT(128, false); }

@@ -18,42 +18,29 @@
 
 namespace mfma {
 
-#ifndef ACVAE_BK
-#define ACVAE_BK 32
-#endif
-#ifndef ACVAE_NT_OCC
-#define ACVAE_NT_OCC 2          // workgroups per CU the NT kernels are register-budgeted for
-#endif
-constexpr int BM = 128;
-constexpr int BK = ACVAE_BK;
-constexpr int LDS_LD = BK + 4;  // floats per LDS row
-constexpr int NT_THREADS = 256;   // loader (and compute) threads per workgroup
-constexpr int KT = BK / 4;      // float4 columns per tile row (threads per row)
-constexpr int RPP = NT_THREADS / KT;  // rows loaded per pass
+constexpr int BK = 32;            // K-step
+constexpr int LDS_LD = BK + 4;    // floats per LDS row (+4 pad: every ds_read_b128 lane group covers 64 distinct banks)
+constexpr int KT = BK / 4;        // float4 columns per tile row = loader threads per row
+constexpr int NT_LOADERS = 256;   // loader threads per workgroup (4 wavefronts)
+constexpr int RPP = NT_LOADERS / KT;  // tile rows fetched per pass of the loader threads (32)
 
-template <int BN>
+// NT block kernel (C[M,N] = A[M,K] . B[N,K]^T), warp-specialised:
+//   BMT x BN block tile (BMT = 128 or 256, BN = 128 or 64), K-step 32;
+//   wavefronts 0 .. BMT/32-1 are MATRIX waves in a (BMT/64) x 2 grid, each owning a 64 x BN/2 tile
+//   (2 x BN/64 MFMA tiles): they only read LDS and issue MFMAs;
+//   the last 4 wavefronts are LOADER waves: they fetch the next tile global -> registers, apply the operand's
+//   activation, and store it into the other half of a two-deep LDS ring.  One barrier per K-step.
+// (Two identical waves sharing a SIMD finish their MFMA phase together and then both leave the matrix pipe idle
+//  while they stage: 124 vs 148 TFLOP/s measured without staging; with split roles the pipe always has a wave ready.)
+// A lane reads 4 consecutive k with one ds_read_b128 and feeds 4 MFMAs with it: in MFMA e of k-group g, lanes 0-31
+// supply k = 8g+e and lanes 32-63 supply k = 8g+4+e for BOTH operands — a legal permutation of the summation index.
+template <int BMT, int BN>
 struct alignas(16) NtSmem {
-  alignas(16) float a[2][BM * LDS_LD];
+  alignas(16) float a[2][BMT * LDS_LD];
   alignas(16) float b[2][BN * LDS_LD];
 };
-
-// Operand loaders are split in two phases so that the global loads of K-step k+1 are all in flight while the
-// MFMAs of K-step k run: issue() only computes (clamped, always-legal) addresses and starts the loads;
-// finish() — called after the MFMAs, just before the LDS stores — applies masks / activations.  Nothing in
-// issue() may consume a loaded value (that would force an s_waitcnt vmcnt(0) in front of the MFMAs).
-// Loader threads: in the warp-specialised kernel only wavefronts 4..7 load; their lane id within the loader
-// group is threadIdx.x - NT_LOADER_BASE.
-#ifndef ACVAE_NT_WS
-#define ACVAE_NT_WS 1
-#endif
-#if ACVAE_NT_WS
-#define NT_LOADER_BASE 256
-#define NT_BLOCK_THREADS 512
-#else
-#define NT_LOADER_BASE 0
-#define NT_BLOCK_THREADS 256
-#endif
-__device__ __forceinline__ int ltid() { return (int)threadIdx.x - NT_LOADER_BASE; }
+template <int BMT>
+constexpr int nt_threads() { return (BMT / 32 + 4) * 64; }
 
 // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin to the 8 XCDs (observed,
 // not contractual: only speed depends on it), so give each XCD a CONTIGUOUS run of the tile sequence; neighbouring
@@ -63,36 +50,39 @@ __device__ __forceinline__ void xcd_tile(int nm, int nn, int& bm, int& bn) {
   const int b = blockIdx.x + blockIdx.y * nm;
   const int q = total >> 3, r = total & 7;
   const int xcd = b & 7, idx = b >> 3;
-  // XCD x owns q (+1 if x < r) consecutive tiles starting at x*q + min(x, r)
-  const int t = xcd * q + (xcd < r ? xcd : r) + idx;
+  const int t = xcd * q + (xcd < r ? xcd : r) + idx;   // XCD x owns q (+1 if x < r) consecutive tiles
   bm = t % nm;
   bn = t / nm;
 }
 
+// Operand loaders work in two phases so that the global loads of K-step k+1 are in flight while the matrix waves
+// run K-step k: issue() only computes (clamped, always-legal) addresses and starts the loads; finish() applies
+// masks / activations just before the LDS stores.  Nothing in issue() may consume a loaded value.
+// A loader thread lt (0..255) owns tile rows (lt / 8) + 32*j and the float4 column lt % 8.
+template <int ROWS>
 struct Pending {
-  float4 v[4];
+  float4 v[ROWS];
   float4 sc, sh;      // optional per-channel affine (conv loaders)
   unsigned mask;      // VEC4: bit j = row j valid; scalar: bits 4j..4j+3 = elements of row j valid
 };
 
-// ---- plain row-major operand loader: 4 rows per thread (r = row0 + (tid>>3) + 32*j), float4 at k = kstep*32 + (tid&7)*4
-template <bool VEC4>
+// plain row-major operand: NR = rows per loader thread (tile rows / 32)
+template <bool VEC4, int NR>
 struct PlainLoader {
+  static_assert(VEC4 || NR <= 8, "scalar mask holds 8 rows");
   const float* base;
   long ld;
   int rows, K;
-  __device__ __forceinline__ void init(int) {}
-  __device__ __forceinline__ void issue(int row0, int kstep, int nrow_iters, Pending& p) const {
-    const int c = (ltid() % KT) * 4 + kstep * BK;
+  __device__ __forceinline__ void init(int, int) {}
+  __device__ __forceinline__ void issue(int row0, int kstep, int lt, Pending<NR>& p) const {
+    const int c = (lt % KT) * 4 + kstep * BK;
     p.mask = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j >= nrow_iters) break;
-      const int r = row0 + (ltid() / KT) + RPP * j;
+    for (int j = 0; j < NR; ++j) {
+      const int r = row0 + (lt / KT) + RPP * j;
       if (VEC4) {
         const bool ok = (r < rows) && (c + 4 <= K);
-        const float* q = ok ? base + (long)r * ld + c : base;
-        p.v[j] = *reinterpret_cast<const float4*>(q);
+        p.v[j] = *reinterpret_cast<const float4*>(ok ? base + (long)r * ld + c : base);
         p.mask |= (ok ? 1u : 0u) << j;
       } else {
         const bool rok = r < rows;
@@ -104,10 +94,9 @@ struct PlainLoader {
       }
     }
   }
-  __device__ __forceinline__ void finish(int nrow_iters, Pending& p) const {
+  __device__ __forceinline__ void finish(Pending<NR>& p) const {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j >= nrow_iters) break;
+    for (int j = 0; j < NR; ++j) {
       if (VEC4) {
         if (!((p.mask >> j) & 1u)) p.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
@@ -122,17 +111,18 @@ struct PlainLoader {
 };
 
 // ---- epilogues -------------------------------------------------------------------------------
-// An epilogue's run() receives the wave's accumulators; element (i, j, r) of a wave at (wm, wn) is
+// An epilogue's run() receives the matrix wave's accumulators; element (i, j, r) of the wave at (wm, wn) is
 //   m = row0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*lh,   n = col0 + wn*(BN/2) + j*32 + li.
+// It is called by EVERY wavefront (loader waves pass matrix_wave = false) so that it may use barriers.
 struct PlainEpilogue {
   float* C;
   long ldc;
   const float* bias;
   int accumulate;
-  template <int BN, int NTN>
+  template <int BMT, int BN, int NTN>
   __device__ __forceinline__ void run(const f32x16 (&acc)[2][NTN], int row0, int col0, int wm, int wn, int li, int lh,
-                                      int M, int N, float*, bool compute_wave) const {
-    if (!compute_wave) return;
+                                      int M, int N, float*, bool matrix_wave) const {
+    if (!matrix_wave) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -153,18 +143,18 @@ struct PlainEpilogue {
   }
 };
 
-// The block-level mainloop.  ALoader must provide load(row0, kstep, 4, regs).
-template <int BN, class ALoader, class BLoader, class Epilogue>
+template <int BMT, int BN, class ALoader, class BLoader, class Epilogue>
 __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, int K, int block_m, int block_n,
-                                         const Epilogue& ep, NtSmem<BN>& sm) {
-  constexpr int NTN = BN / 64;  // MFMA tiles per wave along N
-  constexpr int AROWS = BM / RPP;  // A row iterations per thread
-  constexpr int BROWS = BN / RPP;  // B row iterations per thread
-  static_assert(AROWS <= 4 && BROWS <= 4 && BROWS >= 1, "Pending holds 4 float4");
+                                         const Epilogue& ep, NtSmem<BMT, BN>& sm) {
+  constexpr int NTN = BN / 64;     // MFMA tiles per matrix wave along N
+  constexpr int NMW = BMT / 32;    // matrix wavefronts (BMT/64 x 2)
+  constexpr int AR = BMT / RPP;    // A rows per loader thread
+  constexpr int BR = BN / RPP;     // B rows per loader thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const bool matrix_wave = wave < NMW;
+  const int wm = (wave >> 1) % (BMT / 64), wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int row0 = block_m * BM, col0 = block_n * BN;
+  const int row0 = block_m * BMT, col0 = block_n * BN;
   const int nk = (K + BK - 1) / BK;
 
   f32x16 acc[2][NTN];
@@ -175,142 +165,64 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#if !ACVAE_NT_WS
-  al.init(row0);
-  bl.init(col0);
-#endif
-  const int srow = tid / KT, scol = (tid % KT) * 4;
-  [[maybe_unused]] auto stash = [&](int buf, Pending& pa, Pending& pb) {
-    al.finish(AROWS, pa);
-    bl.finish(BROWS, pb);
+  if (!matrix_wave) {
+    // ------------------------------------------------------------------ loader wavefronts
+    const int lt = tid - NMW * 64;
+    const int srow = lt / KT, scol = (lt % KT) * 4;
+    Pending<AR> pa;
+    Pending<BR> pb;
+    al.init(row0, lt);
+    bl.init(col0, lt);
+    auto stash = [&](int buf) {
+      al.finish(pa);
+      bl.finish(pb);
 #pragma unroll
-    for (int j = 0; j < AROWS; ++j) *reinterpret_cast<float4*>(&sm.a[buf][(srow + RPP * j) * LDS_LD + scol]) = pa.v[j];
+      for (int j = 0; j < AR; ++j) *reinterpret_cast<float4*>(&sm.a[buf][(srow + RPP * j) * LDS_LD + scol]) = pa.v[j];
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + RPP * j) * LDS_LD + scol]) = pb.v[j];
-  };
-  auto compute = [&](int cur) {
-    const float* As = sm.a[cur] + (wm * 64 + li) * LDS_LD + 4 * lh;
-    const float* Bs = sm.b[cur] + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      float4 af[2], bf[NTN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
-#pragma unroll
-      for (int j = 0; j < NTN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NTN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-  };
-
-#if ACVAE_NT_WS
-  // Warp-specialised schedule: wavefronts 0-3 (one per SIMD) only read LDS and issue MFMAs; wavefronts 4-7 (their
-  // SIMD partners) only load, activate and store the next tile.  Two identical waves sharing a SIMD finish their MFMA
-  // phase together and then both stall the matrix pipe while they stage (measured: 124 vs 148 TFLOP/s without
-  // staging); with split roles the matrix pipe always has a wave ready and the staging VALU/VMEM work co-issues.
-  if (wave >= 4) {
-    // loader wavefronts: two register sets, tiles requested TWO K-steps before they are written to the 2-deep LDS ring
-    Pending pa0, pb0, pa1, pb1;
-    al.init(row0);
-    bl.init(col0);
-    const int lt = ltid();
-    const int srow_l = lt / KT, scol_l = (lt % KT) * 4;
-    auto stash_l = [&](int buf, Pending& pa, Pending& pb) {
-      al.finish(AROWS, pa);
-      bl.finish(BROWS, pb);
-#pragma unroll
-      for (int j = 0; j < AROWS; ++j)
-        *reinterpret_cast<float4*>(&sm.a[buf][(srow_l + RPP * j) * LDS_LD + scol_l]) = pa.v[j];
-#pragma unroll
-      for (int j = 0; j < BROWS; ++j)
-        *reinterpret_cast<float4*>(&sm.b[buf][(srow_l + RPP * j) * LDS_LD + scol_l]) = pb.v[j];
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + RPP * j) * LDS_LD + scol]) = pb.v[j];
     };
-    al.issue(row0, 0, AROWS, pa0);
-    bl.issue(col0, 0, BROWS, pb0);
-    if (nk > 1) {
-      al.issue(row0, 1, AROWS, pa1);
-      bl.issue(col0, 1, BROWS, pb1);
-    }
-    stash_l(0, pa0, pb0);
+    al.issue(row0, 0, lt, pa);
+    bl.issue(col0, 0, lt, pb);
+    stash(0);
     __syncthreads();
-    for (int ks = 0; ks < nk; ks += 2) {
-      if (ks + 2 < nk) {
-        al.issue(row0, ks + 2, AROWS, pa0);
-        bl.issue(col0, ks + 2, BROWS, pb0);
+    for (int ks = 0; ks < nk; ++ks) {
+      if (ks + 1 < nk) {
+        al.issue(row0, ks + 1, lt, pa);
+        bl.issue(col0, ks + 1, lt, pb);
+        stash((ks + 1) & 1);
       }
-      if (ks + 1 < nk) stash_l(1, pa1, pb1);
-      __syncthreads();
-      if (ks + 1 >= nk) break;
-      if (ks + 3 < nk) {
-        al.issue(row0, ks + 3, AROWS, pa1);
-        bl.issue(col0, ks + 3, BROWS, pb1);
-      }
-      if (ks + 2 < nk) stash_l(0, pa0, pb0);
       __syncthreads();
     }
   } else {
-#ifdef ACVAE_WS_PRIO
-    __builtin_amdgcn_s_setprio(ACVAE_WS_PRIO);   // matrix waves win issue arbitration against their loader partners
-#endif
+    // ------------------------------------------------------------------ matrix wavefronts
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
-      compute(ks & 1);
+      const int cur = ks & 1;
+      const float* As = sm.a[cur] + (wm * 64 + li) * LDS_LD + 4 * lh;
+      const float* Bs = sm.b[cur] + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        float4 af[2], bf[NTN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NTN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
       __syncthreads();
     }
-#ifdef ACVAE_WS_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   }
-#else
-  // Global loads run TWO K-steps ahead of the MFMAs (two register sets, statically named so nothing is
-  // dynamically indexed), the LDS ring is two deep: tile ks+2 is requested before the MFMAs of tile ks, tile ks+1
-  // (requested one iteration earlier) is activated + written to LDS after them.  One barrier per K-step.
-  Pending pa0, pb0, pa1, pb1;
-  al.issue(row0, 0, AROWS, pa0);
-  bl.issue(col0, 0, BROWS, pb0);
-  if (nk > 1) {
-    al.issue(row0, 1, AROWS, pa1);
-    bl.issue(col0, 1, BROWS, pb1);
-  }
-  stash(0, pa0, pb0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ks += 2) {
-    // even step: compute tile ks from LDS[0]; slot 0 registers are free -> request tile ks+2 into them
-    if (ks + 2 < nk) {
-      al.issue(row0, ks + 2, AROWS, pa0);
-      bl.issue(col0, ks + 2, BROWS, pb0);
-    }
-    compute(0);
-    if (ks + 1 < nk) stash(1, pa1, pb1);
-    __syncthreads();
-    if (ks + 1 >= nk) break;
-    // odd step: compute tile ks+1 from LDS[1]; request tile ks+3 into slot 1
-    if (ks + 3 < nk) {
-      al.issue(row0, ks + 3, AROWS, pa1);
-      bl.issue(col0, ks + 3, BROWS, pb1);
-    }
-    compute(1);
-    if (ks + 2 < nk) stash(0, pa0, pb0);
-    __syncthreads();
-  }
-
-#endif
-
-  // all waves are past the last LDS read (barrier above): LDS is free for the epilogue
-#if ACVAE_NT_WS
-  ep.template run<BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], wave < 4);
-#else
-  ep.template run<BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], true);
-#endif
+  // every wave is past the last LDS access (barrier above): LDS is free for the epilogue
+  ep.template run<BMT, BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], matrix_wave);
 }
-
 
 // =================================================================================================
 // TN block kernel:  C[M,N] = sum_k A[k][m] * B[k][n]   (both operands k-major: weight gradients,
@@ -337,7 +249,7 @@ struct PlainKMajorLoader {
   template <int W>
   __device__ __forceinline__ void init(int) {}
   template <int W>
-  __device__ __forceinline__ void issue(int col0, int k0, Pending& p) const {
+  __device__ __forceinline__ void issue(int col0, int k0, Pending<4>& p) const {
     constexpr int TPR = W / 4;           // threads per k-row
     constexpr int ROWS_PER_IT = 256 / TPR;
     constexpr int ITS = BKT / ROWS_PER_IT;
@@ -362,7 +274,7 @@ struct PlainKMajorLoader {
     }
   }
   template <int W>
-  __device__ __forceinline__ void finish(Pending& p) const {
+  __device__ __forceinline__ void finish(Pending<4>& p) const {
     constexpr int ITS = BKT / (256 / (W / 4));
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
@@ -400,7 +312,7 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   static_assert(AITS <= 4 && BITS <= 4, "Pending holds 4 float4");
-  Pending pa, pb;
+  Pending<4> pa, pb;
   al.template init<TM>(row0);
   bl.template init<TN_>(col0);
   auto stash = [&](int buf) {
