@@ -46,13 +46,18 @@ constexpr int nt_threads() { return (BMT / 32 + 4) * 64; }
 // not contractual: only speed depends on it), so give each XCD a CONTIGUOUS run of the tile sequence; neighbouring
 // M-tiles share im2col halo rows / operand panels and then meet in the same 4 MiB L2.  Bijective for any count.
 __device__ __forceinline__ void xcd_tile(int nm, int nn, int& bm, int& bn) {
+#ifdef ACVAE_NO_XCD_REMAP
+  bm = blockIdx.x; bn = blockIdx.y; return;
+#endif
   const int total = nm * nn;
   const int b = blockIdx.x + blockIdx.y * nm;
   const int q = total >> 3, r = total & 7;
   const int xcd = b & 7, idx = b >> 3;
   const int t = xcd * q + (xcd < r ? xcd : r) + idx;   // XCD x owns q (+1 if x < r) consecutive tiles
-  bm = t % nm;
-  bn = t / nm;
+  // N fastest inside the run: the N-tiles of one M-tile (same A rows, different weight panel) execute back to back
+  // on one XCD, so the A operand is fetched from HBM once, not once per N-tile; consecutive M-tiles share halo rows
+  bn = t % nn;
+  bm = t / nn;
 }
 
 // Operand loaders work in two phases so that the global loads of K-step k+1 are in flight while the matrix waves
