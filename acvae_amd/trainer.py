@@ -155,8 +155,12 @@ class TrainStep:
     def forward_loss(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):
         """Runner._forward(mode='train') + the loss line (:315-318).  Returns (loss, parts, output)."""
         out = self.model(feats, feat_lens, caps, cap_lens, ss_ratio=ss_ratio, dis_ratio=dis_ratio)
-        lens1 = np.asarray(cap_lens) - 1
-        targets = caps[:, 1:1 + out["logits"].shape[1]].to(torch.long)
+        staged = getattr(self.model, "staged", None) or {}
+        lens1 = staged.get("lens1_d")
+        if lens1 is None:
+            lens1 = np.asarray(cap_lens) - 1
+        caps_src = staged.get("caps_d")
+        targets = (caps if caps_src is None else caps_src)[:, 1:1 + out["logits"].shape[1]].to(torch.long)
         ce = self.criterion.masked(out["logits"], targets, lens1)     # == criterion(packed_logits, packed targets)
         kl = self.kl_loss(out["q_means"], out["q_logs"], out["p_means"], out["p_logs"])
         loss = ce + kl_weight * kl

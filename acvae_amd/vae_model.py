@@ -105,6 +105,7 @@ class Hybrid_VAEModel(CaptionModel):
         self.decoder._owner = weakref.ref(self)
         self._encproj_cache = {}
         self.use_side_stream = os.environ.get("ACVAE_SIDE_STREAM", "1") != "0"
+        self.staged = None         # device copies of caps / cap_lens-1 made by the last training forward
         self.noise = None          # optional replay: dict(eps_q=[N,Tc,E], eps_p=[Tc,N,E]) consumed by the next forward
         self._grad_views = None    # {param: flat-gradient view}, set by the train-step harness
         self._grad_ready_cb = None # called with "text" once every text-side gradient has been written
@@ -242,16 +243,21 @@ class Hybrid_VAEModel(CaptionModel):
             if eps_q is None:                                      # same generator order as the reference: the
                 lens1 = np.asarray(cap_lens) - 1                   # posterior's randn precedes the per-step draws
                 eps_q = torch.randn(feats.shape[0], int(lens1.max()), self.decoder.embed_size)
+            # Host-side draws and the small H2D copies of the decode loop go in front of the encoder launch: a
+            # pageable-memory copy waits for the stream to drain, which behind the encoder would stall the host.
+            prep = self._host_prepare(feats.shape[0], feats.device, caps, cap_lens, kwargs)
             if side is not main:
                 side.wait_stream(main)
+                prep["caps_d"].record_stream(side)
             with torch.cuda.stream(side):
-                qnetout = self.qnet(caps, cap_lens, eps=eps_q)
+                qnetout = self.qnet(prep["caps_d"], cap_lens, eps=eps_q)
             encoded = self.encoder(feats, feat_lens)
             if side is not main:
                 main.wait_stream(side)
                 for v in qnetout.values():
                     if isinstance(v, torch.Tensor):
                         v.record_stream(main)
+            encoded["_prep"] = prep
             encoded.update(qnetout)
             return self.train_forward(encoded, caps, cap_lens, **kwargs)
         if len(input) == 2:
@@ -260,22 +266,18 @@ class Hybrid_VAEModel(CaptionModel):
             return self.inference_forward(encoded, **kwargs)
         raise Exception("Number of input should be either 4 (feats, feat_lens, caps, cap_lens) or 2 (feats, feat_lens)")
 
-    def stepwise_forward(self, encoded, caps, cap_lens, **kwargs):
-        """models/vae_model.py:700-730 with decode_step (:792-816), prepare_decoder_input (:818-848) and
-        stepwise_process_step (:850-869) fused into one device-side loop."""
-        mem = encoded["audio_embeds"]
-        dev = mem.device
-        N = mem.shape[0]
+    def _host_prepare(self, N, dev, caps, cap_lens, kwargs):
+        """The decode loop's host-side random decisions, in the reference's per-step order (scheduled-sampling coin
+        :826, prior noise text_encoder.py:259 on the CPU generator (F9), disentangle coin :802-806), and the device
+        copies of the caption ids / lengths / noise."""
         E = self.decoder.embed_size
         train = caps is not None
-        mem_lens_d = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long).to(dev)
         if train:
             lens1 = np.asarray(cap_lens) - 1
             Tc = int(max(cap_lens)) - 1
             ss_ratio, dis_ratio = kwargs["ss_ratio"], kwargs["dis_ratio"]
         else:
             Tc = kwargs.get("max_length", self.max_length)
-        # host-side random decisions, in the reference's per-step order
         replay = self.noise
         self.noise = None
         ss_flags, dis_flags, eps_list = [], [], []
@@ -286,17 +288,31 @@ class Hybrid_VAEModel(CaptionModel):
                 eps_list.append(torch.randn(N, E))                               # text_encoder.py:259 (CPU, F9)
             if train:
                 dis_flags.append(bool(dis_ratio != 0 and torch.rand(1) <= dis_ratio))   # :802-806
-        if eps_list:
-            eps_p = torch.stack(eps_list, 0)
-        else:
-            eps_p = replay["eps_p"][:Tc]
+        eps_p = torch.stack(eps_list, 0) if eps_list else replay["eps_p"][:Tc]
         eps_p = eps_p.to(dev, non_blocking=True).contiguous().float()
+        caps_d = lens1_d = None
         if train:
             caps_d = caps.to(torch.long).to(dev).contiguous()
             lens1_d = torch.as_tensor(lens1, dtype=torch.long).to(dev)
-            q_z = encoded["q_z"]
-        else:
-            caps_d = lens1_d = q_z = None
+        return {"Tc": Tc, "ss_flags": ss_flags, "dis_flags": dis_flags, "eps_p": eps_p, "caps_d": caps_d,
+                "lens1_d": lens1_d}
+
+    def stepwise_forward(self, encoded, caps, cap_lens, **kwargs):
+        """models/vae_model.py:700-730 with decode_step (:792-816), prepare_decoder_input (:818-848) and
+        stepwise_process_step (:850-869) fused into one device-side loop."""
+        mem = encoded["audio_embeds"]
+        dev = mem.device
+        N = mem.shape[0]
+        E = self.decoder.embed_size
+        train = caps is not None
+        mem_lens_d = encoded.get("audio_embeds_lens_dev")
+        if mem_lens_d is None:
+            mem_lens_d = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long).to(dev)
+        prep = encoded.pop("_prep", None) or self._host_prepare(N, dev, caps, cap_lens, kwargs)
+        Tc, ss_flags, dis_flags, eps_p = prep["Tc"], prep["ss_flags"], prep["dis_flags"], prep["eps_p"]
+        caps_d, lens1_d = prep["caps_d"], prep["lens1_d"]
+        q_z = encoded["q_z"] if train else None
+        self.staged = {"caps_d": caps_d, "lens1_d": lens1_d}           # device copies the loss can reuse
         outs = _DecodeFn.apply(self, mem, mem_lens_d, caps_d, lens1_d, q_z, eps_p, ss_flags, dis_flags, Tc,
                                *self._decode_weights())
         logits, outputs, seqs, slp, attw, pm, pl, pz, putt, hfin, hp, cp = outs
