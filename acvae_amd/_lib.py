@@ -96,3 +96,16 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError("acvae_amd: the HIP path needs tensors on an MI355X device (no CPU fallback)")
+
+
+def h2d(t, dev, dtype=None):
+    """Host array/tensor -> device without draining the stream: a copy out of pageable memory blocks the host until
+    everything queued before it has run, so stage through torch's caching pinned-host allocator and copy
+    asynchronously (the allocator keeps the block alive until the copy's event has passed)."""
+    t = torch.as_tensor(t)
+    if t.device.type != "cpu":
+        return t.to(device=dev, dtype=dtype)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.contiguous().pin_memory().to(dev, non_blocking=True)
+

@@ -166,7 +166,7 @@ class Cnn10(nn.Module):
         """input: [batch, time, 64] log-mel; lens: frame counts (numpy array / list / tensor)."""
         lens = torch.as_tensor(lens)
         lens //= 16                       # in place on the caller's array, as the reference does (:677-678)
-        lens_dev = lens.to(torch.long).to(input.device)      # staged before the kernels: a pageable copy drains the stream
+        lens_dev = _lib.h2d(lens, input.device, torch.long)   # staged before the kernels are queued
         ae, pooled = _Cnn10Fn.apply(self, input, *self._weights())
         return {"audio_embeds": ae, "audio_embeds_pooled": pooled, "state": None, "audio_embeds_lens": lens,
                 "audio_embeds_lens_dev": lens_dev}

@@ -139,11 +139,11 @@ class PosteriorRNN_hybrid(PosteriorBaseEncoder):
         lengths = np.asarray(lengths) - 1
         Tc = int(lengths.max())
         N = x.shape[0]
-        caps_d = x.to(torch.long).to(dev).contiguous()
-        lens1_d = torch.as_tensor(lengths, dtype=torch.long).to(dev)
+        caps_d = _lib.h2d(x, dev, torch.long).contiguous()
+        lens1_d = _lib.h2d(lengths, dev, torch.long)
         if eps is None:
             eps = torch.randn(N, Tc, self.embed_size)
-        eps = eps.to(dev, non_blocking=True).contiguous()
+        eps = _lib.h2d(eps, dev).contiguous()
         qm, ql, qz, utt = _PosteriorFn.apply(self, caps_d, lens1_d, eps, Tc, *self._weights())
         return {"q_means": qm, "q_logs": ql, "q_z": qz, "q_means_utt": utt, "q_logs_utt": None, "q_z_utt": None}
 

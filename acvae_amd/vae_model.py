@@ -289,11 +289,11 @@ class Hybrid_VAEModel(CaptionModel):
             if train:
                 dis_flags.append(bool(dis_ratio != 0 and torch.rand(1) <= dis_ratio))   # :802-806
         eps_p = torch.stack(eps_list, 0) if eps_list else replay["eps_p"][:Tc]
-        eps_p = eps_p.to(dev, non_blocking=True).contiguous().float()
+        eps_p = _lib.h2d(eps_p, dev, torch.float32).contiguous()
         caps_d = lens1_d = None
         if train:
-            caps_d = caps.to(torch.long).to(dev).contiguous()
-            lens1_d = torch.as_tensor(lens1, dtype=torch.long).to(dev)
+            caps_d = _lib.h2d(caps, dev, torch.long).contiguous()
+            lens1_d = _lib.h2d(lens1, dev, torch.long)
         return {"Tc": Tc, "ss_flags": ss_flags, "dis_flags": dis_flags, "eps_p": eps_p, "caps_d": caps_d,
                 "lens1_d": lens1_d}
 
@@ -307,7 +307,7 @@ class Hybrid_VAEModel(CaptionModel):
         train = caps is not None
         mem_lens_d = encoded.get("audio_embeds_lens_dev")
         if mem_lens_d is None:
-            mem_lens_d = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long).to(dev)
+            mem_lens_d = _lib.h2d(encoded["audio_embeds_lens"], dev, torch.long)
         prep = encoded.pop("_prep", None) or self._host_prepare(N, dev, caps, cap_lens, kwargs)
         Tc, ss_flags, dis_flags, eps_p = prep["Tc"], prep["ss_flags"], prep["dis_flags"], prep["eps_p"]
         caps_d, lens1_d = prep["caps_d"], prep["lens1_d"]

@@ -48,3 +48,17 @@ for label, lo, hi in (("host prep + bn0", 0, i_c1), ("encoder forward", i_c1, i_
     print("%-28s span %7.3f ms  busy %7.3f  idle %6.3f  n=%d" % (label, (prev - start) / 1e6, busy / 1e6, gap / 1e6, len(part)))
     for k, v in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:top]:
         print("     %-66s n=%4d busy=%8.1f us avg=%7.1f idle_before=%7.1f us" % (k, v[0], v[1] / 1e3, v[1] / v[0] / 1e3, v[2] / 1e3))
+
+# idle gaps > 20 us on the main stream: what ran on the other stream meanwhile, and which kernel ended the gap
+side = [r for r in seg if r["Stream_Id"] != seg[-1]["Stream_Id"]]
+prev = None
+print("gaps > 20 us on the main stream:")
+for r in main:
+    st = int(r["Start_Timestamp"])
+    if prev is not None and st - int(prev["End_Timestamp"]) > 20e3:
+        lo, hi = int(prev["End_Timestamp"]), st
+        busy = [s for s in side if int(s["Start_Timestamp"]) < hi and int(s["End_Timestamp"]) > lo]
+        print("  t=%8.3f ms gap %6.1f us  after %-28s before %-28s side-stream kernels in gap: %d (%s)" % (
+            (lo - t0) / 1e6, (hi - lo) / 1e3, nm(prev)[:28], nm(r)[:28], len(busy), nm(busy[-1])[:24] if busy else "-"))
+    if prev is None or int(r["End_Timestamp"]) > int(prev["End_Timestamp"]):
+        prev = r
