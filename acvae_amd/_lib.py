@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -98,14 +99,54 @@ def require_cuda(*tensors):
             raise RuntimeError("acvae_amd: the HIP path needs tensors on an MI355X device (no CPU fallback)")
 
 
+class _PinnedRing:
+    """One page-locked staging buffer per device, handed out as a ring.  A freshly hipHostMalloc'ed block makes the
+    first copy out of it wait for the GPU to drain, and torch's caching host allocator needs a fresh block whenever
+    the host runs ahead of the previous copies, so the per-step host->device copies stage through memory that is
+    pinned once.  A slot is reused only after the copy that last read it has passed (event), which blocks only when
+    the host is a whole ring ahead of the GPU."""
+
+    def __init__(self, nbytes=32 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.head = 0
+        self.live = []           # (start, end, event) in allocation order
+
+    def stage(self, t, dev):
+        n = t.numel() * t.element_size()
+        if n == 0 or n > self.buf.numel() // 4:
+            return t.pin_memory().to(dev, non_blocking=True)
+        span = (n + 255) & ~255
+        if self.head + span > self.buf.numel():
+            self.head = 0
+        s, e = self.head, self.head + span
+        self.head = e
+        while self.live and self.live[0][0] < e and self.live[0][1] > s:
+            self.live.pop(0)[2].synchronize()
+        slot = self.buf[s:s + n].view(t.dtype).view(t.shape)
+        np.copyto(slot.numpy(), t.numpy())       # plain memcpy: torch's copy_ fans a 1 MB copy out over the intra-op pool
+        out = slot.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.live.append((s, e, ev))
+        return out
+
+
+_RINGS = {}
+
+
 def h2d(t, dev, dtype=None):
-    """Host array/tensor -> device without draining the stream: a copy out of pageable memory blocks the host until
-    everything queued before it has run, so stage through torch's caching pinned-host allocator and copy
-    asynchronously (the allocator keeps the block alive until the copy's event has passed)."""
+    """Host array/tensor -> device without stalling the host: a copy out of pageable memory waits until everything
+    queued before it has run, so stage through the page-locked ring and copy asynchronously."""
     t = torch.as_tensor(t)
     if t.device.type != "cpu":
         return t.to(device=dev, dtype=dtype)
     if dtype is not None:
         t = t.to(dtype)
-    return t.contiguous().pin_memory().to(dev, non_blocking=True)
-
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise RuntimeError("acvae_amd: the HIP path needs a GPU device (no CPU fallback)")
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ring = _RINGS.get(key)
+    if ring is None:
+        ring = _RINGS[key] = _PinnedRing()
+    return ring.stage(t.contiguous(), dev)

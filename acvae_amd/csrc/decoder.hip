@@ -53,6 +53,22 @@ inline int transp(const float* in, long ld_in, float* out, long ld_out, int rows
 inline int zero(float* p, long n, hipStream_t st) {
   return hipMemsetAsync(p, 0, (size_t)n * sizeof(float), st) == hipSuccess ? ACVAE_OK : (int)hipGetLastError();
 }
+// fork/join of a call's work over two streams: begin() makes aux wait for everything queued on main so far, join() makes
+// main wait for everything queued on aux; with aux == main both are no-ops.  Events are released when they complete.
+struct Fork {
+  hipStream_t main_s, aux;
+  bool on() const { return aux != main_s; }
+  static int edge(hipStream_t from, hipStream_t to) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    hipError_t r = hipEventRecord(e, from);
+    if (r == hipSuccess) r = hipStreamWaitEvent(to, e, 0);
+    (void)hipEventDestroy(e);
+    return r == hipSuccess ? ACVAE_OK : (int)r;
+  }
+  int begin() const { return on() ? edge(main_s, aux) : ACVAE_OK; }
+  int join() const { return on() ? edge(aux, main_s) : ACVAE_OK; }
+};
 inline long tn_ws_floats(int M, int N, int K) { return acvae_gemm_tn_workspace_bytes(M, N, K) / 4 + 64; }
 
 // text-parameter table (state-dict order after the encoder; see include/acvae_hip.h)
@@ -111,13 +127,15 @@ struct DecLayout {
   long words, mem, encproj_d, encproj_p, qd, qp, attw_p, rnn_d, rnn_p, gru_save, hprev_d, lstm_save, c_all, hp_all,
       hpprev, lse, pool_arg, pool_hid, unfinished, saved_total;
   // fwd scratch
-  long skws, gi_d, gh_d, gates_p, ml, h0, scratch_fwd;
+  long skws, skws_p, gi_d, gh_d, gates_p, ml, h0, scratch_fwd;
   // bwd scratch
   long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a,
       dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, scratch_bwd;
+  // bwd scratch private to the prior chain (it may run on the second stream)
+  long dencproj_p, dvpart_p, dmem_p, drnn_p, tn_p, dpart_p, attws_p;
   long attws_bytes;
-  long tn_floats;
+  long tn_floats, tn_p_floats;
 };
 int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLayout& L) {
   if (N <= 0 || Tc <= 0 || S <= 0 || E <= 0 || H <= 0 || A <= 0 || V <= 1 || Eenc <= 0) return ACVAE_EINVAL;
@@ -135,12 +153,14 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   L.unfinished = s.take(N);
   L.saved_total = s.off;
   Bump f;
-  L.skws = f.take(acvae_skinny_ws_floats());   // same offset (0) in the forward and backward scratch maps
+  L.skws = f.take(acvae_skinny_ws_floats());   // same offsets in the forward and backward scratch maps
+  L.skws_p = f.take(acvae_skinny_ws_floats());
   L.gi_d = f.take(R * 3 * H); L.gh_d = f.take((long)N * 3 * H); L.gates_p = f.take(R * 4 * Hp);
   L.ml = f.take((long)N * 2 * E); L.h0 = f.take((long)N * (H > Hp ? H : Hp));
   L.scratch_fwd = f.off;
   Bump b;
-  b.take(acvae_skinny_ws_floats());            // skinny split-K workspace at offset 0 (L.skws)
+  b.take(acvae_skinny_ws_floats());            // skinny split-K workspaces first (L.skws, L.skws_p)
+  b.take(acvae_skinny_ws_floats());
   L.wt_cls = b.take((long)H * V + 64); L.wt_dih = b.take((long)3 * E * 3 * H); L.wt_dhh = b.take((long)H * 3 * H);
   L.wt_datt = b.take((long)(E + H) * A); L.wt_pih = b.take((long)3 * E * 4 * Hp); L.wt_phh = b.take((long)Hp * 4 * Hp);
   L.wt_pml = b.take((long)Hp * 2 * E); L.wt_patt = b.take((long)2 * E * E); L.wt_mlo = b.take((long)H * 2 * E);
@@ -166,6 +186,17 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   }
   L.attws_bytes = acvae_attn_bwd_workspace_bytes(N, Tc, S, A > E ? A : E);
   L.attws = b.take(L.attws_bytes / 4 + 64);
+  L.attws_p = b.take(L.attws_bytes / 4 + 64);
+  L.dencproj_p = b.take((long)N * S * E); L.dvpart_p = b.take((long)N * E); L.dmem_p = b.take((long)N * S * E);
+  L.drnn_p = b.take(R * 3 * E);
+  tn = 0;
+  mx(4 * Hp, 3 * E, (int)R); mx(4 * Hp, Hp, (int)R); mx(2 * E, Hp, (int)R); mx(E, E, (int)R); mx(E, E, N * S);
+  L.tn_p_floats = tn;
+  L.tn_p = b.take(tn);
+  {
+    int w = 4 * Hp; if (2 * E > w) w = 2 * E;
+    L.dpart_p = b.take(2 * acvae::colsum_scratch_doubles(w));
+  }
   L.scratch_bwd = b.off;
   return ACVAE_OK;
 }
@@ -312,7 +343,7 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
                                 float* p_logs, float* p_z, float* p_means_utt, float* h_final, float* hp_final,
                                 float* cp_final, void* saved_v, int64_t saved_bytes, void* scratch_v,
                                 int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc,
-                                int start_idx, int end_idx, void* stream) {
+                                int start_idx, int end_idx, void* stream, void* aux_stream) {
   DecLayout L;
   ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
   if (!params || !mem_in || !mem_lens || !eps_p || !logits || !outputs || !seqs || !sampled_logprobs || !attn_w ||
@@ -324,14 +355,21 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
   if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_fwd * 4) return ACVAE_EWORKSPACE;
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
-  Ctx st{(hipStream_t)stream, sc + L.skws};
-  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   const int R = N * Tc, Hp = E;
   const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
-  bool teacher = train;
+  bool teacher = train, prior_feeds_decoder = !train;
   if (train)
-    for (int t = 0; t < Tc; ++t) teacher = teacher && ss_flags_host[t] != 0;
+    for (int t = 0; t < Tc; ++t) {
+      teacher = teacher && ss_flags_host[t] != 0;
+      prior_feeds_decoder = prior_feeds_decoder || dis_flags_host[t] != 0;
+    }
+  // st: the decoder chain and everything batched; sp: the prior chain (second stream only when the chains are independent)
+  Ctx st{(hipStream_t)stream, sc + L.skws};
+  const Fork fork{st.s, (aux_stream && teacher) ? (hipStream_t)aux_stream : st.s};
+  Ctx sp{fork.aux, sc + L.skws_p};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  ACVAE_TRY(acvae_skinny_ws_reset(sp.skws, st.s));
 
   int64_t* words = (int64_t*)(sv + L.words);
   float* mem = sv + L.mem;
@@ -367,16 +405,16 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
     const int M = rows_of(cnt);
     // embedding -> rnn_p[:, t, 0:E]
     ACVAE_TRY(acvae::embed_gather(words + t0, cnt == Tc ? 1 : Tc, P(TP_P_EMB), V, rnn_p + (long)t0 * 3 * E,
-                                  ldof(cnt, 3 * E), M, E, st));
+                                  ldof(cnt, 3 * E), M, E, sp));
     // query projection and attention over the audio memory (text_encoder.py:251)
     ACVAE_TRY(gemm(rnn_p + (long)t0 * 3 * E, ldof(cnt, 3 * E), P(TP_P_ATT_W), 2 * E, nullptr, qp + (long)t0 * E,
-                   ldof(cnt, E), M, E, E, 0, st));
+                   ldof(cnt, E), M, E, E, 0, sp));
     ACVAE_TRY(acvae_attn_fwd(qp + (long)t0 * E, (long)Tc * E, E, encproj_p, mem, mem_lens, P(TP_P_ATT_V),
                              rnn_p + (long)t0 * 3 * E + E, ld3E, 3 * E, attw_p + (long)t0 * S, (long)Tc * S, S, N, cnt, S,
-                             E, E, st));
+                             E, E, sp));
     // LSTM input projection of [emb; ctx] (+ both biases); the last_z / h parts are added per step
     ACVAE_TRY(gemm(rnn_p + (long)t0 * 3 * E, ldof(cnt, 3 * E), P(TP_P_WIH), 3 * E, P(TP_P_BIH),
-                   gates_p + (long)t0 * 4 * Hp, ldof(cnt, 4 * Hp), M, 4 * Hp, 2 * E, 0, st));
+                   gates_p + (long)t0 * 4 * Hp, ldof(cnt, 4 * Hp), M, 4 * Hp, 2 * E, 0, sp));
     return ACVAE_OK;
   };
   float* hp_all = sv + L.hp_all;
@@ -387,18 +425,18 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
     const float* hprev = t ? hp_all + (long)(t - 1) * Hp : zeros;
     const long ldh = t ? (long)Tc * Hp : Hp;
     const float* cprev = t ? c_all + (long)(t - 1) * Hp : nullptr;
-    ACVAE_TRY(acvae::copy_rows(hpprev + (long)t * Hp, (long)Tc * Hp, hprev, ldh, N, Hp, st));
-    if (t == 0) ACVAE_TRY(acvae::copy_rows(rnn_p + 2 * E, ld3E, nullptr, 0, N, E, st));  // last_z = 0
+    ACVAE_TRY(acvae::copy_rows(hpprev + (long)t * Hp, (long)Tc * Hp, hprev, ldh, N, Hp, sp));
+    if (t == 0) ACVAE_TRY(acvae::copy_rows(rnn_p + 2 * E, ld3E, nullptr, 0, N, E, sp));  // last_z = 0
     // gates += last_z . W_ih[:, 2E:3E]^T + h . W_hh^T + b_hh
     ACVAE_TRY(gemm2(rnn_p + (long)t * 3 * E + 2 * E, ld3E, P(TP_P_WIH) + 2 * E, 3 * E, E, hprev, ldh, P(TP_P_WHH), Hp,
-                    Hp, P(TP_P_BHH), gates_p + (long)t * 4 * Hp, (long)Tc * 4 * Hp, N, 4 * Hp, 1, st));
+                    Hp, P(TP_P_BHH), gates_p + (long)t * 4 * Hp, (long)Tc * 4 * Hp, N, 4 * Hp, 1, sp));
     ACVAE_TRY(acvae::lstm_fwd(gates_p + (long)t * 4 * Hp, (long)Tc * 4 * Hp, cprev, (long)Tc * Hp,
                               hp_all + (long)t * Hp, (long)Tc * Hp, c_all + (long)t * Hp, (long)Tc * Hp,
-                              lstm_save + (long)t * 5 * Hp, (long)Tc * 5 * Hp, N, Hp, st));
-    ACVAE_TRY(gemm(hp_all + (long)t * Hp, (long)Tc * Hp, P(TP_P_ML_W), Hp, P(TP_P_ML_B), ml, 2 * E, N, 2 * E, Hp, 0, st));
+                              lstm_save + (long)t * 5 * Hp, (long)Tc * 5 * Hp, N, Hp, sp));
+    ACVAE_TRY(gemm(hp_all + (long)t * Hp, (long)Tc * Hp, P(TP_P_ML_W), Hp, P(TP_P_ML_B), ml, 2 * E, N, 2 * E, Hp, 0, sp));
     float* z2 = (t + 1 < Tc) ? rnn_p + (long)(t + 1) * 3 * E + 2 * E : nullptr;
     ACVAE_TRY(acvae_reparam_fwd(ml, 2 * E, eps_p + (long)t * N * E, E, p_means + (long)t * E, p_logs + (long)t * E,
-                                p_z + (long)t * E, (long)Tc * E, z2, ld3E, N, E, st));
+                                p_z + (long)t * E, (long)Tc * E, z2, ld3E, N, E, sp));
     return ACVAE_OK;
   };
   auto dec_pre = [&](int t0, int cnt) -> int {
@@ -443,11 +481,14 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
 
   if (teacher) {
     ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));
+    ACVAE_TRY(fork.begin());
     ACVAE_TRY(prior_pre(0, Tc));
     for (int t = 0; t < Tc; ++t) ACVAE_TRY(prior_step(t));
+    if (prior_feeds_decoder) ACVAE_TRY(fork.join());   // dec_pre reads p_z
     ACVAE_TRY(dec_pre(0, Tc));
     for (int t = 0; t < Tc; ++t) ACVAE_TRY(dec_step(t));
     ACVAE_TRY(classify(0, Tc));
+    if (!prior_feeds_decoder) ACVAE_TRY(fork.join());
   } else {
     for (int t = 0; t < Tc; ++t) {
       ACVAE_TRY(acvae::select_word(caps, ld_caps, seqs, Tc, words, Tc, t, train && ss_flags_host[t], start_idx, N, st));
@@ -477,7 +518,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
                                 const float* d_p_means, const float* d_p_logs, const float* d_p_z,
                                 const float* d_p_means_utt, float* d_mem_in, float* d_q_z, void* saved_v,
                                 int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S, int E,
-                                int H, int A, int V, int Eenc, void* stream) {
+                                int H, int A, int V, int Eenc, void* stream, void* aux_stream) {
   DecLayout L;
   ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
   if (!params || !grads || !mem_in || !mem_lens || !lens1 || !eps_p || !dis_flags_host || !outputs || !attn_w ||
@@ -486,14 +527,23 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   if (saved_bytes < L.saved_total * 4 || scratch_bytes < L.scratch_bwd * 4) return ACVAE_EWORKSPACE;
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
+  bool prior_feeds_decoder = false;
+  for (int t = 0; t < Tc; ++t) prior_feeds_decoder = prior_feeds_decoder || dis_flags_host[t] != 0;
+  // st: decoder chain; sp: prior chain, on the second stream when given (it has its own accumulators; the two meet in
+  // dmem at the end).  A step that fed the prior's z to the decoder makes the prior BPTT wait for the decoder's dz.
   Ctx st{(hipStream_t)stream, sc + L.skws};
+  const Fork fork{st.s, aux_stream ? (hipStream_t)aux_stream : st.s};
+  Ctx sp{fork.aux, sc + L.skws_p};
   ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  ACVAE_TRY(acvae_skinny_ws_reset(sp.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc, Hp = E;
   const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
+  TnWs tn_p{sc + L.tn_p, L.tn_p_floats * 4};
   double* dpart = (double*)(sc + L.dpart);
+  double* dpart_p = (double*)(sc + L.dpart_p);
   const int64_t* words = (const int64_t*)(sv + L.words);
   float* mem = sv + L.mem;
   float* rnn_d = sv + L.rnn_d;
@@ -514,6 +564,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   ACVAE_TRY(transp(P(TP_P_ML_W), Hp, wt_pml, 2 * E, 2 * E, Hp, st));     // [Hp][2E]
   ACVAE_TRY(transp(P(TP_P_ATT_W), 2 * E, wt_patt, E, E, 2 * E, st));     // [2E][E]
   ACVAE_TRY(transp(P(TP_MLO_W), H, wt_mlo, 2 * E, 2 * E, H, st));        // [H][2E]
+  int64_t* words_c = (int64_t*)(sc + L.words_c);
+  ACVAE_TRY(acvae::gather_words(words, Tc, 1, words_c, N, Tc, st));
+  ACVAE_TRY(fork.begin());
 
   // ---- d_outputs = external + utterance head + classifier
   float* d_out = sc + L.d_out;
@@ -587,20 +640,12 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   float* dz_dec = sc + L.dz_dec;
   ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, st));                    // d emb
   ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, st));  // d z
-  int64_t* words_c = (int64_t*)(sc + L.words_c);
-  ACVAE_TRY(acvae::gather_words(words, Tc, 1, words_c, N, Tc, st));
   ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, st));
   ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, st));
-  // route dz to the posterior sample or to the prior sample, per step
-  float* dpz = sc + L.dqp;  // reuse as d p_z total [N,Tc,E] until the prior attention needs dqp
-  for (int t = 0; t < Tc; ++t) {
-    const bool prior_z = dis_flags_host[t] != 0;
-    ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, prior_z ? nullptr : dz_dec + (long)t * E,
+  // route dz to the posterior sample (here) or to the prior sample (prior chain, below), per step
+  for (int t = 0; t < Tc; ++t)
+    ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
                                (long)Tc * E, N, E, st));
-    const float* src = d_p_z ? d_p_z + (long)t * E : nullptr;
-    ACVAE_TRY(acvae::copy_rows(dpz + (long)t * E, (long)Tc * E, src, (long)Tc * E, N, E, st));
-    if (prior_z) ACVAE_TRY(acvae::add_rows(dpz + (long)t * E, (long)Tc * E, dz_dec + (long)t * E, (long)Tc * E, N, E, st));
-  }
 
   // ---- prior BPTT
   float* dgates = sc + L.dgates;
@@ -615,53 +660,68 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   const float* c_all = sv + L.c_all;
   const float* hp_all = sv + L.hp_all;
   const float* hpprev = sv + L.hpprev;
-  ACVAE_TRY(zero(dhp, (long)N * Hp, st));
-  ACVAE_TRY(zero(dc, (long)N * Hp, st));
-  ACVAE_TRY(zero(dlz, (long)N * E, st));
+  float* dpz = sc + L.dqp;  // d p_z total [N,Tc,E]; the buffer becomes dqp once the prior attention needs it
+  float* drnn_p = sc + L.drnn_p;
+  float* dencproj_p = sc + L.dencproj_p;
+  float* dvpart_p = sc + L.dvpart_p;
+  float* dmem_p = sc + L.dmem_p;
+  if (prior_feeds_decoder && fork.on()) ACVAE_TRY(Fork::edge(st.s, sp.s));   // dz_dec comes from the decoder chain
+  for (int t = 0; t < Tc; ++t) {
+    ACVAE_TRY(acvae::copy_rows(dpz + (long)t * E, (long)Tc * E, d_p_z ? d_p_z + (long)t * E : nullptr, (long)Tc * E, N, E,
+                               sp));
+    if (dis_flags_host[t])
+      ACVAE_TRY(acvae::add_rows(dpz + (long)t * E, (long)Tc * E, dz_dec + (long)t * E, (long)Tc * E, N, E, sp));
+  }
+  ACVAE_TRY(zero(dmem_p, (long)N * S * E, sp));
+  ACVAE_TRY(zero(dhp, (long)N * Hp, sp));
+  ACVAE_TRY(zero(dc, (long)N * Hp, sp));
+  ACVAE_TRY(zero(dlz, (long)N * E, sp));
   for (int t = Tc - 1; t >= 0; --t) {
     // dz_t = d p_z[:,t] (+ decoder share) + d last_z from step t+1
-    ACVAE_TRY(acvae::add_rows(dlz, E, dpz + (long)t * E, (long)Tc * E, N, E, st));
+    ACVAE_TRY(acvae::add_rows(dlz, E, dpz + (long)t * E, (long)Tc * E, N, E, sp));
     ACVAE_TRY(acvae_reparam_bwd(dlz, E, d_p_means ? d_p_means + (long)t * E : nullptr,
                                 d_p_logs ? d_p_logs + (long)t * E : nullptr, (long)Tc * E, p_logs + (long)t * E,
                                 (long)Tc * E, eps_p + (long)t * N * E, E, dml_all + (long)t * 2 * E, (long)Tc * 2 * E, N,
-                                E, st));
+                                E, sp));
     // dh = dh_next + dml . W_ml
-    ACVAE_TRY(gemm(dml_all + (long)t * 2 * E, (long)Tc * 2 * E, wt_pml, 2 * E, nullptr, dhp, Hp, N, Hp, 2 * E, 1, st));
+    ACVAE_TRY(gemm(dml_all + (long)t * 2 * E, (long)Tc * 2 * E, wt_pml, 2 * E, nullptr, dhp, Hp, N, Hp, 2 * E, 1, sp));
     ACVAE_TRY(acvae::lstm_bwd(dhp, Hp, dc, Hp, lstm_save + (long)t * 5 * Hp, (long)Tc * 5 * Hp,
                               t ? c_all + (long)(t - 1) * Hp : nullptr, (long)Tc * Hp, dgates + (long)t * 4 * Hp,
-                              (long)Tc * 4 * Hp, dc2, Hp, N, Hp, st));
-    ACVAE_TRY(gemm(dgates + (long)t * 4 * Hp, (long)Tc * 4 * Hp, wt_phh, 4 * Hp, nullptr, dhp2, Hp, N, Hp, 4 * Hp, 0, st));
+                              (long)Tc * 4 * Hp, dc2, Hp, N, Hp, sp));
+    ACVAE_TRY(gemm(dgates + (long)t * 4 * Hp, (long)Tc * 4 * Hp, wt_phh, 4 * Hp, nullptr, dhp2, Hp, N, Hp, 4 * Hp, 0, sp));
     ACVAE_TRY(gemm(dgates + (long)t * 4 * Hp, (long)Tc * 4 * Hp, wt_pih + (long)2 * E * 4 * Hp, 4 * Hp, nullptr, dlz2, E,
-                   N, E, 4 * Hp, 0, st));
+                   N, E, 4 * Hp, 0, sp));
     float* tmp = dhp; dhp = dhp2; dhp2 = tmp;
     tmp = dc; dc = dc2; dc2 = tmp;
     tmp = dlz; dlz = dlz2; dlz2 = tmp;
   }
   // batched parameter gradients of the prior
-  ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn, st));
-  ACVAE_TRY(acvae::colsum2(dml_all, R, 2 * E, dpart, G(TP_P_ML_B), nullptr, 0, st));
-  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, rnn_p, 3 * E, G(TP_P_WIH), 3 * E, 4 * Hp, 3 * E, R, tn, st));
-  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart, G(TP_P_BIH), nullptr, 0, st));
-  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart, G(TP_P_BHH), nullptr, 0, st));
-  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, hpprev, Hp, G(TP_P_WHH), Hp, 4 * Hp, Hp, R, tn, st));
+  ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn_p, sp));
+  ACVAE_TRY(acvae::colsum2(dml_all, R, 2 * E, dpart_p, G(TP_P_ML_B), nullptr, 0, sp));
+  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, rnn_p, 3 * E, G(TP_P_WIH), 3 * E, 4 * Hp, 3 * E, R, tn_p, sp));
+  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BIH), nullptr, 0, sp));
+  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BHH), nullptr, 0, sp));
+  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, hpprev, Hp, G(TP_P_WHH), Hp, 4 * Hp, Hp, R, tn_p, sp));
   // d[emb; ctx] of the prior
-  ACVAE_TRY(gemm(dgates, 4 * Hp, wt_pih, 4 * Hp, nullptr, drnn, 3 * E, R, 2 * E, 4 * Hp, 0, st));   // cols 0:2E of drnn[R,3E]
+  ACVAE_TRY(gemm(dgates, 4 * Hp, wt_pih, 4 * Hp, nullptr, drnn_p, 3 * E, R, 2 * E, 4 * Hp, 0, sp));   // cols 0:2E of drnn_p[R,3E]
   // prior attention backward (all Tc queries of a clip inside one workgroup: deterministic accumulation)
   float* dqp = sc + L.dqp;  // dpz is dead from here on
-  ACVAE_TRY(zero(dencproj, (long)N * S * E, st));
-  ACVAE_TRY(zero(dvpart, (long)N * E, st));
-  ACVAE_TRY(acvae_attn_bwd(drnn + E, (long)Tc * 3 * E, 3 * E, sv + L.qp, (long)Tc * E, E, sv + L.encproj_p, mem,
-                           mem_lens, P(TP_P_ATT_V), sv + L.attw_p, (long)Tc * S, S, dqp, (long)Tc * E, E, dencproj, dmem,
-                           dvpart, sc + L.attws, L.attws_bytes, N, Tc, S, E, E, st));
+  ACVAE_TRY(zero(dencproj_p, (long)N * S * E, sp));
+  ACVAE_TRY(zero(dvpart_p, (long)N * E, sp));
+  ACVAE_TRY(acvae_attn_bwd(drnn_p + E, (long)Tc * 3 * E, 3 * E, sv + L.qp, (long)Tc * E, E, sv + L.encproj_p, mem,
+                           mem_lens, P(TP_P_ATT_V), sv + L.attw_p, (long)Tc * S, S, dqp, (long)Tc * E, E, dencproj_p,
+                           dmem_p, dvpart_p, sc + L.attws_p, L.attws_bytes, N, Tc, S, E, E, sp));
   // d emb_p = drnn[:, 0:E] + dqp . W_att[:, :E]
-  ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn, 3 * E, R, E, E, 1, st));
-  ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn, st));
-  ACVAE_TRY(gemm_tn(dencproj, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn, st));
-  ACVAE_TRY(acvae::colsum2(dencproj, N * S, E, dpart, G(TP_P_ATT_B), nullptr, 0, st));
-  ACVAE_TRY(acvae::colsum2(dvpart, N, E, dpart, G(TP_P_ATT_V), nullptr, 0, st));
-  ACVAE_TRY(gemm(dencproj, E, wt_patt + (long)E * E, E, nullptr, dmem, E, N * S, E, E, 1, st));
-  ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, st));
-  ACVAE_TRY(acvae::embed_scatter(words_c, drnn, 3 * E, G(TP_P_EMB), V, R, E, st));
+  ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn_p, 3 * E, R, E, E, 1, sp));
+  ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn_p, sp));
+  ACVAE_TRY(gemm_tn(dencproj_p, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn_p, sp));
+  ACVAE_TRY(acvae::colsum2(dencproj_p, N * S, E, dpart_p, G(TP_P_ATT_B), nullptr, 0, sp));
+  ACVAE_TRY(acvae::colsum2(dvpart_p, N, E, dpart_p, G(TP_P_ATT_V), nullptr, 0, sp));
+  ACVAE_TRY(gemm(dencproj_p, E, wt_patt + (long)E * E, E, nullptr, dmem_p, E, N * S, E, E, 1, sp));
+  ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, sp));
+  ACVAE_TRY(acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp));
+  ACVAE_TRY(fork.join());
+  ACVAE_TRY(acvae::add_rows(dmem, E, dmem_p, E, N * S, E, st));
   // ---- memory gradient back through the optional ln projection
   if (has_ln) {
     ACVAE_TRY(transp(P(TP_LN_W), Eenc, wt_ln, E, E, Eenc, st));                          // [Eenc][E]

@@ -53,7 +53,8 @@ class _DecodeFn(torch.autograd.Function):
         mem = mem.contiguous()
         _lib.call("acvae_decode_fwd", ptr_table(params), mem, mem_lens_d, caps_d, caps_d.stride(0) if train else 0,
                   lens1_d, q_z, eps_p, ss_arr, dis_arr, logits, outputs, seqs, slp, attw, pm, pl, pz, putt, hfin, hp, cp,
-                  saved, saved_b, scratch, scratch_b, *dims, model.start_idx, model.end_idx, _lib.current_stream())
+                  saved, saved_b, scratch, scratch_b, *dims, model.start_idx, model.end_idx, _lib.current_stream(),
+                  model._aux_stream())
         ctx.model, ctx.saved, ctx.dims, ctx.dis_arr = model, saved, dims, dis_arr
         ctx.keep = (mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl)
         ctx.mark_non_differentiable(seqs, slp, attw, hfin, hp, cp)
@@ -81,7 +82,8 @@ class _DecodeFn(torch.autograd.Function):
         scratch = scratch_buffer(scratch_b, dev)
         _lib.call("acvae_decode_bwd", ptr_table(params), ptr_table(grads), mem, mem_lens_d, lens1_d, eps_p, ctx.dis_arr,
                   outputs, attw, pl, c(d_logits), c(d_outputs), c(d_pm), c(d_pl), c(d_pz), c(d_putt), d_mem, d_qz,
-                  ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, _lib.current_stream())
+                  ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, _lib.current_stream(),
+                  model._aux_stream())
         ctx.saved = None
         outs = [next((g for p, g in zip(params, grads) if p is w), None) for w in model._decode_weights()]
         return (None, d_mem, None, None, None, d_qz, None, None, None, None, *outs)
@@ -215,6 +217,12 @@ class Hybrid_VAEModel(CaptionModel):
         if getattr(self, "_side", None) is None or self._side.device != main.device:
             self._side = torch.cuda.Stream(device=main.device)
         return self._side
+
+    def _aux_stream(self):
+        """Second HIP stream handle for the decode calls (prior chain beside the decoder chain), or None."""
+        if not self.use_side_stream:
+            return None
+        return self._side_stream(torch.cuda.current_stream()).cuda_stream
 
     # ---- reference API
     def train_forward(self, encoded, caps, cap_lens, **kwargs):

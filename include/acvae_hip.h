@@ -175,7 +175,11 @@ int acvae_posterior_bwd(const void* const* params, void* const* grads, const int
  *   dis_flags_host[t] != 0: step t feeds the PRIOR's z to the decoder (torch.rand(1) <= dis_ratio, :805).
  * Outputs: logits [N,Tc,V], outputs [N,Tc,H], seqs i64 [N,Tc], sampled_logprobs [N,Tc],
  *   attn_w [N,Tc,S] (the reference's attn_weights transposed), p_means/p_logs/p_z [N,Tc,E],
- *   p_means_utt [N,2E] (training only), final states h [N,H], (hp, cp) [N,E]. */
+ *   p_means_utt [N,2E] (training only), final states h [N,H], (hp, cp) [N,E].
+ * aux_stream (may be NULL): a second HIP stream of the same device.  With teacher forcing the prior's recurrence
+ *   (embedding -> attention -> LSTM -> z_t) and the decoder's (attention -> GRU) are two independent chains of ~10 us
+ *   kernels unless a step feeds the prior's z to the decoder; given a second stream the call forks after the hoisted
+ *   GEMMs, runs the prior chain there and joins before it returns, so on return all work is ordered on `stream`. */
 int64_t acvae_decode_saved_bytes(int N, int Tc, int S, int E, int H, int A, int V, int Eenc);
 int64_t acvae_decode_scratch_bytes(int N, int Tc, int S, int E, int H, int A, int V, int Eenc);
 int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64_t* mem_lens, const int64_t* caps,
@@ -184,7 +188,7 @@ int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64
                      float* sampled_logprobs, float* attn_w, float* p_means, float* p_logs, float* p_z,
                      float* p_means_utt, float* h_final, float* hp_final, float* cp_final, void* saved,
                      int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int Tc, int S, int E, int H,
-                     int A, int V, int Eenc, int start_idx, int end_idx, void* stream);
+                     int A, int V, int Eenc, int start_idx, int end_idx, void* stream, void* aux_stream);
 /* Backward for upstream gradients of logits / outputs / p_means / p_logs / p_z / p_means_utt (each may be
  * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E]. */
 int acvae_decode_bwd(const void* const* params, void* const* grads, const float* mem_in, const int64_t* mem_lens,
@@ -192,7 +196,8 @@ int acvae_decode_bwd(const void* const* params, void* const* grads, const float*
                      const float* attn_w, const float* p_logs, const float* d_logits, const float* d_outputs_ext,
                      const float* d_p_means, const float* d_p_logs, const float* d_p_z, const float* d_p_means_utt,
                      float* d_mem_in, float* d_q_z, void* saved, int64_t saved_bytes, void* scratch,
-                     int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc, void* stream);
+                     int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc, void* stream,
+                     void* aux_stream);
 /* float caption ids (collate pads with torch.zeros -> float32, caption_dataset.py:293) -> int64 */
 int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, void* stream);
 
