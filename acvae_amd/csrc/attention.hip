@@ -12,26 +12,29 @@
 
 namespace {
 
-constexpr int ATT_THREADS = 256;
+constexpr int ATT_THREADS = 256;      // many query rows per launch (batched teacher-forced prior attention)
+constexpr int ATT_THREADS_BIG = 1024;  // few query rows (one decode step): 16 wavefronts per row hide the L2 latency
 
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(
+// VEC: A % 4 == 0, E % 4 == 0, E / 4 <= blockDim.x and every row 16-B aligned (checked by the launcher).
+template <bool VEC>
+__global__ __launch_bounds__(ATT_THREADS_BIG) void attn_fwd_kernel(
     const float* __restrict__ qproj, long q_sn, long q_sj, const float* __restrict__ encproj,
     const float* __restrict__ enc, const int64_t* __restrict__ lens, const float* __restrict__ v,
     float* __restrict__ ctx, long c_sn, long c_sj, float* __restrict__ weights, long w_sn, long w_sj, int Tq, int S,
     int A, int E) {
-  extern __shared__ float smem[];  // [S] scores/weights, then [16] reduction scratch
+  extern __shared__ float smem[];  // [S] scores/weights, [16] reduction scratch, VEC: [groups][E] context partials
   float* sc = smem;
   float* red = smem + S;
   const int n = blockIdx.x / Tq, j = blockIdx.x % Tq;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ATT_THREADS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const float* q = qproj + n * q_sn + j * q_sj;
   const float* P = encproj + (long)n * S * A;
   const int len = (int)lens[n];
-  // ---- scores: wave per frame, lanes over A (float4 when A % 4 == 0)
+  // ---- scores: wave per frame, lanes over A
   for (int s = wave; s < S; s += nw) {
     const float* p = P + (long)s * A;
     float acc = 0.f;
-    if ((A & 3) == 0) {
+    if (VEC) {
       for (int a = lane * 4; a < A; a += 256) {
         const float4 pv = *reinterpret_cast<const float4*>(p + a);
         const float4 qv = *reinterpret_cast<const float4*>(q + a);
@@ -48,10 +51,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(
   __syncthreads();
   // ---- softmax over S
   float m = -INFINITY;
-  for (int s = threadIdx.x; s < S; s += ATT_THREADS) m = fmaxf(m, sc[s]);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) m = fmaxf(m, sc[s]);
   m = block_max(m, red);
   float sum = 0.f;
-  for (int s = threadIdx.x; s < S; s += ATT_THREADS) {
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
     const float e = expf(sc[s] - m);
     sc[s] = e;
     sum += e;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(
   const float inv = 1.f / sum;
   float* wout = weights + n * w_sn + j * w_sj;
   __syncthreads();
-  for (int s = threadIdx.x; s < S; s += ATT_THREADS) {
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
     const float w = sc[s] * inv;
     sc[s] = w;
     wout[s] = w;
@@ -69,10 +72,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(
   // ---- context
   const float* Hn = enc + (long)n * S * E;
   float* c = ctx + n * c_sn + j * c_sj;
-  for (int e = threadIdx.x; e < E; e += ATT_THREADS) {
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += sc[s] * Hn[(long)s * E + e];
-    c[e] = acc;
+  if (VEC) {
+    // E/4 threads cover one enc row as float4; the thread groups take frames g, g+G, ... and meet in LDS (fixed order)
+    float* part = smem + ((S + 16 + 3) & ~3);
+    const int ev = E >> 2, G = blockDim.x / ev;
+    const int g = threadIdx.x / ev, e4 = (threadIdx.x - g * ev) * 4;
+    if (g < G) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = g; s0 < S; s0 += G) {
+        const float4 h = *reinterpret_cast<const float4*>(Hn + (long)s0 * E + e4);
+        const float w = sc[s0];
+        acc.x += w * h.x; acc.y += w * h.y; acc.z += w * h.z; acc.w += w * h.w;
+      }
+      *reinterpret_cast<float4*>(part + (long)g * E + e4) = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+      float acc = 0.f;
+      for (int k = 0; k < G; ++k) acc += part[(long)k * E + e];
+      c[e] = acc;
+    }
+  } else {
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += sc[s] * Hn[(long)s * E + e];
+      c[e] = acc;
+    }
   }
 }
 
@@ -87,7 +112,8 @@ constexpr int ATB_THREADS = 512;
 constexpr int ATB_CH = 8;     // frames per chunk
 constexpr int ATB_SLOTS = 4;  // A, E <= ATB_SLOTS * ATB_THREADS
 
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_score_kernel(
+template <bool VEC>
+__global__ __launch_bounds__(ATT_THREADS_BIG) void attn_bwd_score_kernel(
     const float* __restrict__ dctx, long dc_sn, long dc_sj, const float* __restrict__ enc,
     const int64_t* __restrict__ lens, const float* __restrict__ weights, long w_sn, long w_sj,
     float* __restrict__ dscore, int Tq, int S, int E) {
@@ -95,24 +121,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_score_kernel(
   float* dw = smem;
   float* red = smem + S;
   const int n = blockIdx.x / Tq, j = blockIdx.x % Tq;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ATT_THREADS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const float* dc = dctx + n * dc_sn + j * dc_sj;
   const float* w = weights + n * w_sn + j * w_sj;
   const float* Hn = enc + (long)n * S * E;
   const int len = (int)lens[n];
   for (int s = wave; s < S; s += nw) {
     float acc = 0.f;
-    for (int e = lane; e < E; e += 64) acc += dc[e] * Hn[(long)s * E + e];
+    if (VEC) {
+      for (int e = lane * 4; e < E; e += 256) {
+        const float4 d = *reinterpret_cast<const float4*>(dc + e);
+        const float4 h = *reinterpret_cast<const float4*>(Hn + (long)s * E + e);
+        acc += d.x * h.x + d.y * h.y + d.z * h.z + d.w * h.w;
+      }
+    } else {
+      for (int e = lane; e < E; e += 64) acc += dc[e] * Hn[(long)s * E + e];
+    }
     acc = wave_sum(acc);
     if (lane == 0) dw[s] = acc;
   }
   __syncthreads();
   float dot = 0.f;
-  for (int s = threadIdx.x; s < S; s += ATT_THREADS) dot += w[s] * dw[s];
+  for (int s = threadIdx.x; s < S; s += blockDim.x) dot += w[s] * dw[s];
   dot = block_sum(dot, red);
   float* out = dscore + (long)blockIdx.x * S;
   // masked_fill blocks the gradient at s >= len (matters only when len == 0)
-  for (int s = threadIdx.x; s < S; s += ATT_THREADS) out[s] = (s < len) ? w[s] * (dw[s] - dot) : 0.f;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) out[s] = (s < len) ? w[s] * (dw[s] - dot) : 0.f;
 }
 
 __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_accum_kernel(
@@ -221,9 +255,17 @@ extern "C" int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, co
   if (S > 8192) return ACVAE_EUNSUPPORTED;
   if ((A & 3) == 0 && (!aligned16(qproj) || !aligned16(encproj) || !aligned16(v) || (q_sn & 3) || (q_sj & 3)))
     return ACVAE_EALIGN;
-  const size_t shm = (size_t)(S + 16) * sizeof(float);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(N * Tq), dim3(ATT_THREADS), shm, (hipStream_t)stream, qproj, q_sn, q_sj,
-                     encproj, enc, lens, v, ctx, c_sn, c_sj, weights, w_sn, w_sj, Tq, S, A, E);
+  const int threads = (long)N * Tq < 256 ? ATT_THREADS_BIG : ATT_THREADS;
+  const bool vec = (A & 3) == 0 && (E & 3) == 0 && E / 4 <= threads && aligned16(enc);
+  const int groups = vec ? threads / (E / 4) : 0;
+  const size_t shm = (size_t)(((S + 16 + 3) & ~3) + (long)groups * E) * sizeof(float);
+  if (shm > 64 * 1024) return ACVAE_EUNSUPPORTED;
+  if (vec)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(N * Tq), dim3(threads), shm, (hipStream_t)stream, qproj, q_sn, q_sj,
+                       encproj, enc, lens, v, ctx, c_sn, c_sj, weights, w_sn, w_sj, Tq, S, A, E);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(N * Tq), dim3(threads), shm, (hipStream_t)stream, qproj, q_sn,
+                       q_sj, encproj, enc, lens, v, ctx, c_sn, c_sj, weights, w_sn, w_sj, Tq, S, A, E);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
@@ -250,8 +292,14 @@ extern "C" int acvae_attn_bwd(const float* dctx, int64_t dc_sn, int64_t dc_sj, c
   float* dscore = ws;
   float* dq_part = dscore + (long)N * Tq * S;
   float* dv_chunk = dq_part + (long)N * Tq * nchunk * A;
-  hipLaunchKernelGGL(attn_bwd_score_kernel, dim3(N * Tq), dim3(ATT_THREADS), (size_t)(S + 16) * sizeof(float), st,
-                     dctx, dc_sn, dc_sj, enc, lens, weights, w_sn, w_sj, dscore, Tq, S, E);
+  const int threads = (long)N * Tq < 256 ? ATT_THREADS_BIG : ATT_THREADS;
+  const bool vec = (E & 3) == 0 && aligned16(dctx) && aligned16(enc) && !(dc_sn & 3) && !(dc_sj & 3);
+  if (vec)
+    hipLaunchKernelGGL(attn_bwd_score_kernel<true>, dim3(N * Tq), dim3(threads), (size_t)(S + 16) * sizeof(float), st,
+                       dctx, dc_sn, dc_sj, enc, lens, weights, w_sn, w_sj, dscore, Tq, S, E);
+  else
+    hipLaunchKernelGGL(attn_bwd_score_kernel<false>, dim3(N * Tq), dim3(threads), (size_t)(S + 16) * sizeof(float), st,
+                       dctx, dc_sn, dc_sj, enc, lens, weights, w_sn, w_sj, dscore, Tq, S, E);
   hipLaunchKernelGGL(attn_bwd_accum_kernel, dim3(N, nchunk), dim3(ATB_THREADS), 0, st, dctx, dc_sn, dc_sj, qproj, q_sn,
                      q_sj, encproj, v, weights, w_sn, w_sj, dscore, dq_part, dv_chunk, dencproj, denc, Tq, S, A, E,
                      nchunk);

@@ -220,7 +220,7 @@ class Hybrid_VAEModel(CaptionModel):
 
     def _aux_stream(self):
         """Second HIP stream handle for the decode calls (prior chain beside the decoder chain), or None."""
-        if not self.use_side_stream:
+        if not self.use_side_stream or os.environ.get("ACVAE_DECODE_AUX", "1") == "0":
             return None
         return self._side_stream(torch.cuda.current_stream()).cuda_stream
 
