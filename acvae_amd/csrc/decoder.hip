@@ -58,12 +58,17 @@ inline int zero(float* p, long n, hipStream_t st) {
 struct Fork {
   hipStream_t main_s, aux;
   bool on() const { return aux != main_s; }
+  // Events come from a small ring that is never destroyed: hipEventDestroy on an event that has not completed yet may
+  // hold the host until it has, which would serialise the host with the GPU at every fork.
   static int edge(hipStream_t from, hipStream_t to) {
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    constexpr int RING = 64;
+    static hipEvent_t ring[RING];
+    static int next = 0;
+    hipEvent_t& e = ring[next];
+    next = (next + 1) % RING;
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
     hipError_t r = hipEventRecord(e, from);
     if (r == hipSuccess) r = hipStreamWaitEvent(to, e, 0);
-    (void)hipEventDestroy(e);
     return r == hipSuccess ? ACVAE_OK : (int)r;
   }
   int begin() const { return on() ? edge(main_s, aux) : ACVAE_OK; }
@@ -483,10 +488,18 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
     ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));
     ACVAE_TRY(fork.begin());
     ACVAE_TRY(prior_pre(0, Tc));
-    for (int t = 0; t < Tc; ++t) ACVAE_TRY(prior_step(t));
-    if (prior_feeds_decoder) ACVAE_TRY(fork.join());   // dec_pre reads p_z
-    ACVAE_TRY(dec_pre(0, Tc));
-    for (int t = 0; t < Tc; ++t) ACVAE_TRY(dec_step(t));
+    if (prior_feeds_decoder) {            // dec_pre reads p_z: the chains run back to back
+      for (int t = 0; t < Tc; ++t) ACVAE_TRY(prior_step(t));
+      ACVAE_TRY(fork.join());
+      ACVAE_TRY(dec_pre(0, Tc));
+      for (int t = 0; t < Tc; ++t) ACVAE_TRY(dec_step(t));
+    } else {                              // independent chains: feed both queues step by step
+      ACVAE_TRY(dec_pre(0, Tc));
+      for (int t = 0; t < Tc; ++t) {
+        ACVAE_TRY(prior_step(t));
+        ACVAE_TRY(dec_step(t));
+      }
+    }
     ACVAE_TRY(classify(0, Tc));
     if (!prior_feeds_decoder) ACVAE_TRY(fork.join());
   } else {
@@ -609,7 +622,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   ACVAE_TRY(zero(dvpart, (long)N * A, st));
   ACVAE_TRY(zero(dmem, (long)N * S * E, st));
   ACVAE_TRY(zero(dh, (long)N * H, st));
-  for (int t = Tc - 1; t >= 0; --t) {
+  float* drnn = sc + L.drnn;
+  float* dz_dec = sc + L.dz_dec;
+  auto dec_bptt = [&](int t) -> int {
     ACVAE_TRY(acvae::gru_bwd(dh, H, d_out + (long)t * H, (long)Tc * H, gru_save + (long)t * 4 * H, (long)Tc * 4 * H,
                              hprev_d + (long)t * H, (long)Tc * H, dgi + (long)t * 3 * H, (long)Tc * 3 * H,
                              dgh + (long)t * 3 * H, (long)Tc * 3 * H, dh2, H, nullptr, t, N, H, st));
@@ -623,7 +638,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(gemm2(dgh + (long)t * 3 * H, (long)Tc * 3 * H, wt_dhh, 3 * H, 3 * H, dqd + (long)t * A, (long)Tc * A,
                     wt_datt, A, A, nullptr, dh2, H, N, H, 1, st));
     float* tmp = dh; dh = dh2; dh2 = tmp;
-  }
+    return ACVAE_OK;
+  };
+  auto dec_batched = [&]() -> int {
   // batched parameter gradients of the decoder
   ACVAE_TRY(gemm_tn(dgi, 3 * H, rnn_d, 3 * E, G(TP_DEC_WIH), 3 * E, 3 * H, 3 * E, R, tn, st));
   ACVAE_TRY(acvae::colsum2(dgi, R, 3 * H, dpart, G(TP_DEC_BIH), nullptr, 0, st));
@@ -636,8 +653,6 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   ACVAE_TRY(acvae::colsum2(dvpart, N, A, dpart, G(TP_DEC_ATT_V), nullptr, 0, st));
   ACVAE_TRY(gemm(dencproj, A, wt_datt + (long)H * A, A, nullptr, dmem, E, N * S, E, A, 1, st));
   // d(rnn_input) for the embedding and z columns
-  float* drnn = sc + L.drnn;
-  float* dz_dec = sc + L.dz_dec;
   ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, st));                    // d emb
   ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, st));  // d z
   ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, st));
@@ -646,6 +661,8 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   for (int t = 0; t < Tc; ++t)
     ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
                                (long)Tc * E, N, E, st));
+    return ACVAE_OK;
+  };
 
   // ---- prior BPTT
   float* dgates = sc + L.dgates;
@@ -665,7 +682,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   float* dencproj_p = sc + L.dencproj_p;
   float* dvpart_p = sc + L.dvpart_p;
   float* dmem_p = sc + L.dmem_p;
-  if (prior_feeds_decoder && fork.on()) ACVAE_TRY(Fork::edge(st.s, sp.s));   // dz_dec comes from the decoder chain
+  auto prior_begin = [&]() -> int {
   for (int t = 0; t < Tc; ++t) {
     ACVAE_TRY(acvae::copy_rows(dpz + (long)t * E, (long)Tc * E, d_p_z ? d_p_z + (long)t * E : nullptr, (long)Tc * E, N, E,
                                sp));
@@ -676,7 +693,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   ACVAE_TRY(zero(dhp, (long)N * Hp, sp));
   ACVAE_TRY(zero(dc, (long)N * Hp, sp));
   ACVAE_TRY(zero(dlz, (long)N * E, sp));
-  for (int t = Tc - 1; t >= 0; --t) {
+    return ACVAE_OK;
+  };
+  auto prior_bptt = [&](int t) -> int {
     // dz_t = d p_z[:,t] (+ decoder share) + d last_z from step t+1
     ACVAE_TRY(acvae::add_rows(dlz, E, dpz + (long)t * E, (long)Tc * E, N, E, sp));
     ACVAE_TRY(acvae_reparam_bwd(dlz, E, d_p_means ? d_p_means + (long)t * E : nullptr,
@@ -694,7 +713,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     float* tmp = dhp; dhp = dhp2; dhp2 = tmp;
     tmp = dc; dc = dc2; dc2 = tmp;
     tmp = dlz; dlz = dlz2; dlz2 = tmp;
-  }
+    return ACVAE_OK;
+  };
+  auto prior_batched = [&]() -> int {
   // batched parameter gradients of the prior
   ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn_p, sp));
   ACVAE_TRY(acvae::colsum2(dml_all, R, 2 * E, dpart_p, G(TP_P_ML_B), nullptr, 0, sp));
@@ -720,6 +741,24 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   ACVAE_TRY(gemm(dencproj_p, E, wt_patt + (long)E * E, E, nullptr, dmem_p, E, N * S, E, E, 1, sp));
   ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, sp));
   ACVAE_TRY(acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp));
+    return ACVAE_OK;
+  };
+  if (prior_feeds_decoder) {   // the prior BPTT needs the decoder's dz: back to back
+    for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(dec_bptt(t));
+    ACVAE_TRY(dec_batched());
+    if (fork.on()) ACVAE_TRY(Fork::edge(st.s, sp.s));
+    ACVAE_TRY(prior_begin());
+    for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(prior_bptt(t));
+    ACVAE_TRY(prior_batched());
+  } else {                     // independent chains: feed both queues step by step
+    ACVAE_TRY(prior_begin());
+    for (int t = Tc - 1; t >= 0; --t) {
+      ACVAE_TRY(dec_bptt(t));
+      ACVAE_TRY(prior_bptt(t));
+    }
+    ACVAE_TRY(dec_batched());
+    ACVAE_TRY(prior_batched());
+  }
   ACVAE_TRY(fork.join());
   ACVAE_TRY(acvae::add_rows(dmem, E, dmem_p, E, N * S, E, st));
   // ---- memory gradient back through the optional ln projection

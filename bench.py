@@ -20,6 +20,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the HIP runtime's kernel-argument ring (see acvae_amd/__init__.py); must be in the environment before HIP initialises
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(32 << 20))
 
 B, T, F, V, L, E = 32, 1000, 64, 5000, 22, 512
 HOP_S = 0.010  # assumed log-mel hop (PANNs/Cnn10 convention; the reference never states it: SURVEY §8(d))

@@ -2,6 +2,7 @@
 import os, sys, cProfile, pstats
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(32 << 20))
 import torch
 import bench
 from acvae_amd.trainer import TrainStep

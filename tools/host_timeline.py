@@ -3,6 +3,7 @@ tracks the GPU time is where the host blocks (pageable copies, allocator, queue 
 import os, sys, time, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(32 << 20))
 import torch
 import bench
 from acvae_amd import _lib
