@@ -100,12 +100,14 @@ struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
   }
   template <int WT>
   __device__ __forceinline__ void issue(int, int k0, Pending<4>& p) const {
-    constexpr int TPR = WT / 4, RPI = 256 / TPR, ITS = BKT / RPI;
+    constexpr int TPR = WT / 4, RPI = 256 / TPR, ITS = tn_its<WT>();
+    constexpr bool EXACT = (RPI * TPR == 256) && (BKT % RPI == 0);
     p.mask = 0;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-      const int px = k0 + threadIdx.x / TPR + it * RPI;
-      bool ok = colok && px < M;
+      const int kr = threadIdx.x / TPR + it * RPI;
+      const int px = k0 + kr;
+      bool ok = colok && px < M && (EXACT || (threadIdx.x < RPI * TPR && kr < BKT));
       const int w = px % W, h = (px / W) % H;
       const int hh = h + dy, ww = w + dx;
       ok = ok && hh >= 0 && hh < H && ww >= 0 && ww < W;
@@ -115,7 +117,7 @@ struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
   }
   template <int WT>
   __device__ __forceinline__ void finish(Pending<4>& p) const {
-    constexpr int ITS = BKT / (256 / (WT / 4));
+    constexpr int ITS = tn_its<WT>();
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       float4 v = p.v[it];
@@ -206,6 +208,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   const int kb = z * k_per;
   const int ke = min(M, kb + k_per);
   tn_block<WM, WN>(al, bl, Cout, NC, kb, ke, bx, by, slab + (long)z * Cout * NC, NC, 0, sm);
+}
+
+// NC = 576 (Cin = 64): 192-column tiles (3 exactly) instead of 2.25 of the 256-wide / 4.5 of the 128-wide ones
+template <int EM>
+__global__ __launch_bounds__(256, 2) void conv_wgrad192_kernel(const float* __restrict__ dY, ConvKMajorLoader bl,
+                                                               float* __restrict__ slab, int M, int Cout, int NC,
+                                                               int k_per) {
+  __shared__ TnSmemG<2 * EM * 32, 192> sm;
+  PlainKMajorLoader<true> al{dY, Cout, Cout, M};
+  const int tiles = gridDim.x * gridDim.y;
+  const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int xcd = b & 7, idx = b >> 3;
+  const int z = (idx / tiles) * 8 + xcd, tile = idx % tiles;
+  const int bx = tile % gridDim.x, by = tile / gridDim.x;
+  const int kb = z * k_per;
+  const int ke = min(M, kb + k_per);
+  tn_block_g<2, 2, EM, 3>(al, bl, Cout, NC, kb, ke, bx, by, slab + (long)z * Cout * NC, NC, 0, sm);
 }
 
 // dW_oihw[co][ci][tap] = sum_z slab[z][co][tap*Cin + ci]
@@ -740,9 +759,11 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
 }
 int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, CONV_BMT); }
 
+static bool wgrad_use192(int NC) { return NC % 192 == 0 && NC % 128 != 0; }
 static int wgrad_splits(int M, int Cout, int NC) {
   const bool narrow = Cout <= 64;
-  const long tiles = (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
+  const long tiles = wgrad_use192(NC) ? (long)cdiv(Cout, narrow ? 64 : 128) * (NC / 192)
+                                      : (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
   // 2 workgroups fit per CU -> 512 slots; aim just under 4 full rounds (a few blocks over a round boundary cost a
   // whole extra round: 1040 blocks ran 18 % slower than 2030), and keep the count a multiple of 8: one group of
   // pixel slices per XCD (conv_wgrad_kernel)
@@ -764,7 +785,15 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
   const int k_per = cdiv(cdiv(M, s), BKT) * BKT;
   ConvKMajorLoader bl{X, scale, shift, H, W, Cin, M, NC};
   prof_begin(ACVAE_PROF_CONV_WGRAD, st);
-  if (Cout <= 64) {
+  if (wgrad_use192(NC)) {
+    if (Cout <= 64) {
+      dim3 grid(cdiv(Cout, 64), NC / 192, s);
+      hipLaunchKernelGGL((conv_wgrad192_kernel<1>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
+    } else {
+      dim3 grid(cdiv(Cout, 128), NC / 192, s);
+      hipLaunchKernelGGL((conv_wgrad192_kernel<2>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
+    }
+  } else if (Cout <= 64) {
     dim3 grid(cdiv(Cout, 64), cdiv(NC, 256), s);
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
   } else {

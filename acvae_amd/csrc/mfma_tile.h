@@ -14,6 +14,7 @@
 //   of k-group g, lanes 0-31 supply k = 8g+e and lanes 32-63 supply k = 8g+4+e for BOTH operands,
 //   which is a legal permutation of the summation index.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace mfma {
@@ -245,6 +246,10 @@ struct alignas(16) TnSmem {
   alignas(16) float b[2][BKT * 64 * WN];
 };
 
+// float4 slots a thread holds for a [BKT][W] tile (W/4 threads per k-row, 256 threads)
+template <int W>
+constexpr int tn_its() { return (BKT + 256 / (W / 4) - 1) / (256 / (W / 4)); }
+
 // plain k-major loader: tile [BKT][W] floats, W = 64*WX; thread loads float4 at k = (tid / (W/4)) + it*(256/(W/4)), col = (tid % (W/4))*4
 template <bool VEC4>
 struct PlainKMajorLoader {
@@ -257,19 +262,22 @@ struct PlainKMajorLoader {
   __device__ __forceinline__ void issue(int col0, int k0, Pending<4>& p) const {
     constexpr int TPR = W / 4;           // threads per k-row
     constexpr int ROWS_PER_IT = 256 / TPR;
-    constexpr int ITS = BKT / ROWS_PER_IT;
+    constexpr int ITS = tn_its<W>();
+    constexpr bool EXACT = (ROWS_PER_IT * TPR == 256) && (BKT % ROWS_PER_IT == 0);   // W = 192: 240 threads, 4th pass partial
     const int c = col0 + (threadIdx.x % TPR) * 4;
     p.mask = 0;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-      const int k = k0 + threadIdx.x / TPR + it * ROWS_PER_IT;
+      const int kr = threadIdx.x / TPR + it * ROWS_PER_IT;
+      const int k = k0 + kr;
+      const bool slot = EXACT || (threadIdx.x < ROWS_PER_IT * TPR && kr < BKT);
       if (VEC4) {
-        const bool ok = (k < K) && (c + 4 <= cols);
+        const bool ok = slot && (k < K) && (c + 4 <= cols);
         const float* q = ok ? base + (long)k * ld + c : base;
         p.v[it] = *reinterpret_cast<const float4*>(q);
         p.mask |= (ok ? 1u : 0u) << it;
       } else {
-        const bool kok = k < K;
+        const bool kok = slot && k < K;
         const float* q = base + (kok ? (long)k * ld : 0);
         const bool o0 = kok && c + 0 < cols, o1 = kok && c + 1 < cols, o2 = kok && c + 2 < cols, o3 = kok && c + 3 < cols;
         p.v[it].x = q[o0 ? c + 0 : 0]; p.v[it].y = q[o1 ? c + 1 : 0];
@@ -280,7 +288,7 @@ struct PlainKMajorLoader {
   }
   template <int W>
   __device__ __forceinline__ void finish(Pending<4>& p) const {
-    constexpr int ITS = BKT / (256 / (W / 4));
+    constexpr int ITS = tn_its<W>();
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       if (VEC4) {
@@ -374,6 +382,103 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
         if (n < N) {
           float* p = C + (long)m * ldc + n;
           float v = acc[em][en][r];
+          if (accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+}
+
+// Same pipeline with a free wave tile: 4 wavefronts as WM x WN, each EM x EN MFMA tiles (32 x 32), for operand widths
+// that the 64 x 64 wave tile covers badly (9*64 = 576 columns = 3 x 192).  Plain tile-to-lane map (one ds_read_b32 per
+// MFMA tile and K-step): tile (i, j) of the wave at (wm, wn) holds m = wm*EM*32 + i*32 + rho, n = wn*EN*32 + j*32 + li.
+template <int TM, int TN_>
+struct alignas(16) TnSmemG {
+  alignas(16) float a[2][BKT * TM];
+  alignas(16) float b[2][BKT * TN_];
+};
+
+template <int WM, int WN, int EM, int EN, class ALoader, class BLoader>
+__device__ __forceinline__ void tn_block_g(ALoader al, BLoader bl, int M, int N, int k_begin, int k_end, int block_m,
+                                           int block_n, float* C, long ldc, int accumulate,
+                                           TnSmemG<WM * EM * 32, WN * EN * 32>& sm) {
+  static_assert(WM * WN == 4, "four wavefronts");
+  constexpr int TM = WM * EM * 32, TN_ = WN * EN * 32;
+  constexpr int AITS = tn_its<TM>(), BITS = tn_its<TN_>();
+  static_assert(AITS <= 4 && BITS <= 4, "Pending holds 4 float4");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int row0 = block_m * TM, col0 = block_n * TN_;
+  const int nk = (k_end - k_begin + BKT - 1) / BKT;
+
+  f32x16 acc[EM][EN];
+#pragma unroll
+  for (int i = 0; i < EM; ++i)
+#pragma unroll
+    for (int j = 0; j < EN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Pending<4> pa, pb;
+  al.template init<TM>(row0);
+  bl.template init<TN_>(col0);
+  auto put = [&](float* dst, const Pending<4>& p, auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    constexpr int TPR = W / 4, RPI = 256 / TPR, ITS = tn_its<W>();
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const int k = tid / TPR + it * RPI;
+      if (tid < RPI * TPR && k < BKT) *reinterpret_cast<float4*>(&dst[k * W + (tid % TPR) * 4]) = p.v[it];
+    }
+  };
+  auto stash = [&](int buf) {
+    al.template finish<TM>(pa);
+    bl.template finish<TN_>(pb);
+    put(sm.a[buf], pa, std::integral_constant<int, TM>{});
+    put(sm.b[buf], pb, std::integral_constant<int, TN_>{});
+  };
+  if (nk > 0) {
+    al.template issue<TM>(row0, k_begin, pa);
+    bl.template issue<TN_>(col0, k_begin, pb);
+    stash(0);
+  }
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) {
+      al.template issue<TM>(row0, k_begin + (ks + 1) * BKT, pa);
+      bl.template issue<TN_>(col0, k_begin + (ks + 1) * BKT, pb);
+    }
+    const float* As = sm.a[cur] + lh * TM + wm * EM * 32 + li;
+    const float* Bs = sm.b[cur] + lh * TN_ + wn * EN * 32 + li;
+#pragma unroll
+    for (int kk = 0; kk < BKT / 2; ++kk) {
+      float af[EM], bf[EN];
+#pragma unroll
+      for (int i = 0; i < EM; ++i) af[i] = As[kk * 2 * TM + i * 32];
+#pragma unroll
+      for (int j = 0; j < EN; ++j) bf[j] = Bs[kk * 2 * TN_ + j * 32];
+#pragma unroll
+      for (int i = 0; i < EM; ++i)
+#pragma unroll
+        for (int j = 0; j < EN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (ks + 1 < nk) stash(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < EM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = row0 + wm * EM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < EN; ++j) {
+        const int n = col0 + wn * EN * 32 + j * 32 + li;
+        if (n < N) {
+          float* p = C + (long)m * ldc + n;
+          float v = acc[i][j][r];
           if (accumulate) v += *p;
           *p = v;
         }
