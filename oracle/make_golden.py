@@ -264,9 +264,48 @@ def g9_beam(ref):
     save("g9_beam", dims=np.array([3, 96, V, E, beam]), feats=feats, feat_lens=feat_lens, eps=eps, seqs=ro["seqs"])
 
 
+def g10_host():
+    """Batch / evaluation contract, produced by the reference's own host code: collate_fn (caption_dataset.py:278-318)
+    on a seeded ragged training batch and an evaluation batch, Vocabulary (build_vocab.py:9-28) pickled, and
+    BaseRunner._convert_idx2sentence (base_runner.py:146-157) on id rows with/without <start>/<end>."""
+    import pickle
+    host = ref_shim.load_host_side()
+    g = torch.Generator().manual_seed(110)
+    words = ["<pad>", "<start>", "<end>", "<unk>"] + [f"w{i}" for i in range(16)]
+    vocab = host.build_vocab.Vocabulary()
+    for w in words:
+        vocab.add_word(w)
+    T = [9, 5, 12, 7]
+    L = [5, 8, 3, 8]
+    items = []
+    for i in range(4):
+        feat = torch.randn(T[i], 6, generator=g)
+        cap = torch.cat([torch.tensor([1]), torch.randint(4, 20, (L[i] - 2,), generator=g), torch.tensor([2])])
+        items.append((feat, cap, f"clip{i}"))
+    feats = np.zeros((4, max(T), 6), np.float32); caps = np.zeros((4, max(L)), np.int64)
+    for i, (f, c, _) in enumerate(items):
+        feats[i, :T[i]] = f.numpy(); caps[i, :L[i]] = c.numpy()
+    out = host.caption_dataset.collate_fn([0, 1], 1)(list(items))
+    ev = host.caption_dataset.collate_fn([1, ])([(k, f) for f, _, k in items[:3]])
+    rows = np.array([[1, 5, 6, 7, 2, 2, 2, 2], [1, 9, 9, 4, 10, 11, 12, 13], [2, 5, 6, 7, 8, 9, 10, 11],
+                     [5, 1, 6, 2, 7, 8, 2, 9]])
+    sents = [host.base_runner.BaseRunner._convert_idx2sentence(r, vocab) for r in rows]
+    sents_zh = [" ".join(host.base_runner.BaseRunner._convert_idx2sentence(r, vocab, zh=True)) for r in rows]
+    save("g10_host", in_feats=feats, in_caps=caps, in_T=np.array(T), in_L=np.array(L),
+         tr_feats=out[0], tr_caps=out[1], tr_keys=np.array(out[2]), tr_feat_lens=out[3], tr_cap_lens=out[4],
+         tr_caps_is_float=np.array(out[1].dtype == torch.float32),
+         ev_keys=np.array(ev[0]), ev_feats=ev[1], ev_feat_lens=ev[2],
+         words=np.array(words), vocab_pickle=np.frombuffer(pickle.dumps(vocab), dtype=np.uint8),
+         rows=rows, sentences=np.array(sents), sentences_zh=np.array(sents_zh))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "host":          # only the host-side fixture
+        g10_host()
+        return
     ref = ref_shim.load()
+    g10_host()
     g1_attention(ref); g2_reparam_kl(ref); g3_ce(ref); g4_encoder(ref); g5_rnn(ref)
     train_fixture(ref, "g6_train_step", 4, 64, 50, 64, 8, True, 0, seed=6)
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)

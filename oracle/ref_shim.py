@@ -47,6 +47,26 @@ def load():
                                  vae_model=vae, word_model=wm, train_util=tu)
 
 
+def load_host_side():
+    """The host-side modules of the batch / evaluation contract: ``datasets.caption_dataset`` (collate_fn),
+    ``utils.build_vocab`` (Vocabulary) and ``runners.base_runner`` (BaseRunner._convert_idx2sentence).  They import
+    packages that are absent here and that the functions under test never touch (h5py, fire, ignite): empty stand-in
+    modules are registered for those names only."""
+    load()
+    for name in ("h5py", "fire"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if "ignite" not in sys.modules:
+        for name in ("ignite", "ignite.engine", "ignite.engine.engine", "ignite.contrib", "ignite.contrib.handlers"):
+            sys.modules[name] = types.ModuleType(name)
+        sys.modules["ignite.engine.engine"].Engine = type("Engine", (), {})
+        sys.modules["ignite.contrib.handlers"].ProgressBar = type("ProgressBar", (), {})
+    import datasets.caption_dataset as cd
+    import utils.build_vocab as bv
+    import runners.base_runner as br
+    return types.SimpleNamespace(caption_dataset=cd, build_vocab=bv, base_runner=br)
+
+
 def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None):
     """Hybrid_VAEModel(Cnn10, VAERNNBahdanauAttnDecoder, PosteriorRNN_hybrid, PriorRNN): the
     self-consistent combination of SURVEY F6, built the way runners/pytorch_runner_vae.py:33-73 does."""
