@@ -258,6 +258,38 @@ __global__ void logprob_add_kernel(const float* __restrict__ logits, long ld, co
     out[i] = logits[n * ld + c] - lse[n] + (prev ? prev[n] : 0.f);
   }
 }
+// Diverse beam search scores (N3, word_model.py:344-348): per row
+//   out[n,c] = log_softmax(log_softmax(logits[n]) / T)[c] - lambda * counts[c] + prev[n]
+// counts (nullable) = how often the earlier groups chose word c at this step.  One workgroup per row.
+__global__ __launch_bounds__(256) void dbs_scores_kernel(const float* __restrict__ logits, long ld, float temperature,
+                                                         const float* __restrict__ counts, float lambda,
+                                                         const float* __restrict__ prev, float* __restrict__ out,
+                                                         int V) {
+  __shared__ float red[16];
+  const int n = blockIdx.x;
+  const float* x = logits + (long)n * ld;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) m = fmaxf(m, x[c]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) s += expf(x[c] - m);
+  s = block_sum(s, red);
+  const float lse1 = m + logf(s);
+  float m2 = -INFINITY;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) m2 = fmaxf(m2, (x[c] - lse1) / temperature);
+  m2 = block_max(m2, red);
+  float s2 = 0.f;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) s2 += expf((x[c] - lse1) / temperature - m2);
+  s2 = block_sum(s2, red);
+  const float lse2 = m2 + logf(s2);
+  const float pv = prev ? prev[n] : 0.f;
+  float* o = out + (long)n * V;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) {
+    float v = (x[c] - lse1) / temperature - lse2;
+    if (counts) v -= counts[c] * lambda;
+    o[c] = pv + v;
+  }
+}
 // flat top-k (k <= 16) of x[0..n), sorted descending, ties -> lower index first (torch.topk(sorted=True) order for
 // distinct values); one workgroup, k selection passes.  Also emits idx / V and idx % V.
 __global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict__ x, long n, int k, int V,
@@ -415,6 +447,15 @@ extern "C" int acvae_logprob_add(const float* logits, int64_t ld, const float* l
   if (!logits || !lse || !out || N <= 0 || V <= 0) return ACVAE_EINVAL;
   hipLaunchKernelGGL(logprob_add_kernel, dim3(grid_for((long)N * V, EW_THREADS)), dim3(EW_THREADS), 0,
                      (hipStream_t)stream, logits, ld, lse, prev, out, N, V);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_dbs_scores(const float* logits, int64_t ld, float temperature, const float* counts,
+                                float diversity_lambda, const float* prev, float* out, int N, int V, void* stream) {
+  if (!logits || !out || N <= 0 || V <= 0 || !(temperature > 0.f)) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(dbs_scores_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, ld, temperature, counts,
+                     diversity_lambda, prev, out, V);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

@@ -213,6 +213,87 @@ class Hybrid_VAEModel(CaptionModel):
             attn_out[i] = attw[0]
         return {"seqs": seqs_out, "attn_weights": attn_out}
 
+    @torch.no_grad()
+    def diverse_beam_search(self, encoded, max_length, beam_size, group_size, diversity_lambda, temperature, group_nbest):
+        """CaptionModel.diverse_beam_search (models/word_model.py:297-394) with this model's hooks (vae_model.py:
+        997-1040): per clip, ``group_size`` groups of ``bdash = beam_size // group_size`` beams; group g runs one
+        step behind group g-1 and its log-probabilities at a local step are lowered by ``diversity_lambda`` x the
+        number of times the earlier groups chose each word at that step; finished beams score logprob / length.
+        Returns {"seqs": i64 [N, beam_size or group_size, max_length]}.  Host bookkeeping (sequence tables, finished
+        beams) as in the reference, which also reads the chosen words back every step; prior / decoder step, the score
+        transform and the flat top-k are library calls."""
+        mem_all = encoded["audio_embeds"].contiguous()
+        dev = mem_all.device
+        if hasattr(self, "ln"):
+            Nn, Ss, Ee = mem_all.shape
+            proj = torch.empty(Nn, Ss, self.decoder.embed_size, device=dev)
+            _lib.call("acvae_gemm_nt", mem_all, Ee, self.ln.weight, Ee, self.ln.bias, proj, self.decoder.embed_size,
+                      Nn * Ss, self.decoder.embed_size, Ee, 0, _lib.current_stream())
+            mem_all = proj
+        lens_all = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long)
+        N, S, E = mem_all.shape
+        V = self.vocab_size
+        bdash = beam_size // group_size
+        if bdash < 1 or bdash > 16:
+            raise ValueError("diverse_beam_search: beam_size // group_size must be in 1..16")
+        st = _lib.current_stream
+        out = torch.full((N, beam_size if group_nbest else group_size, max_length), self.end_idx, dtype=torch.long)
+        scores = torch.empty(bdash, V, device=dev)
+        vals = torch.empty(bdash, device=dev)
+        idx, prev_d, nxt_d = (torch.empty(bdash, dtype=torch.long, device=dev) for _ in range(3))
+        for i in range(N):
+            mem = mem_all[i].unsqueeze(0).repeat(bdash, 1, 1).contiguous()
+            lens = lens_all[i].repeat(bdash)
+            seq = [np.zeros((bdash, 0), np.int64) for _ in range(group_size)]
+            score = [np.zeros(bdash, np.float32) for _ in range(group_size)]
+            done = [[] for _ in range(group_size)]
+            carry = [None] * group_size
+            for t in range(max_length + group_size - 1):
+                for g in range(group_size):
+                    lt = t - g
+                    if lt < 0 or lt > max_length - 1:
+                        continue
+                    if lt == 0:
+                        w = torch.full((bdash,), self.start_idx, dtype=torch.long, device=dev)
+                        state = self.decoder.init_hidden(bdash).to(dev)
+                        hid = self.pnet.init_hidden(bdash, dev)
+                        last_z = torch.zeros(bdash, E, device=dev)
+                    else:
+                        state0, hid0, z0, w, parent = carry[g]
+                        state = state0[:, parent].contiguous()
+                        hid = (hid0[0][:, parent].contiguous(), hid0[1][:, parent].contiguous())
+                        last_z = z0[parent].contiguous()
+                    pn = self.pnet(w.unsqueeze(1), mem, hid, last_z, lens)
+                    dn = self.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
+                    logits = dn["logits"].squeeze(1)
+                    counts = None
+                    if g > 0:                                        # add_diversity (:298-312)
+                        c = np.zeros(V, np.float32)
+                        for earlier in range(g):
+                            np.add.at(c, seq[earlier][:, lt], 1.0)
+                        counts = _lib.h2d(c, dev)
+                    _lib.call("acvae_dbs_scores", logits, V, float(temperature), counts, float(diversity_lambda),
+                              _lib.h2d(score[g], dev), scores, bdash, V, st())
+                    _lib.call("acvae_topk_flat", scores, V if lt == 0 else bdash * V, bdash, V, vals, idx, prev_d, nxt_d,
+                              st())
+                    top = vals.cpu().numpy().copy()                  # the reference syncs here too (topk_words.cpu())
+                    parent_h, nxt_h = prev_d.cpu().numpy().copy(), nxt_d.cpu().numpy().copy()
+                    seq[g] = np.concatenate([seq[g][parent_h] if lt > 0 else seq[g], nxt_h[:, None]], axis=1)
+                    ended = seq[g][:, lt] == self.end_idx
+                    if t == max_length + g - 1:
+                        ended[:] = True
+                    for b in range(bdash):
+                        if ended[b]:
+                            done[g].append({"seq": seq[g][b].copy(), "score": float(top[b]) / (lt + 1)})
+                    top[ended] -= np.float32(1000)
+                    score[g] = top
+                    carry[g] = (dn["state"], pn["hiddens_state"], pn["z"], nxt_d.clone(), prev_d.clone())
+            done = [sorted(d, key=lambda x: -x["score"])[:bdash] for d in done]
+            chosen = sum(done, []) if group_nbest else [d[0] for d in done]
+            for r, beam in enumerate(chosen):
+                out[i, r, :len(beam["seq"])] = torch.from_numpy(beam["seq"])
+        return {"seqs": out.to(dev)}
+
     def _side_stream(self, main):
         if getattr(self, "_side", None) is None or self._side.device != main.device:
             self._side = torch.cuda.Stream(device=main.device)
@@ -233,9 +314,14 @@ class Hybrid_VAEModel(CaptionModel):
         max_length = kwargs.get("max_length", self.max_length)
         if method == "beam":                                              # vae_model.py:884-886
             return self.beam_search(encoded, max_length, kwargs.get("beam_size", 3))
+        if method == "dbs":                                               # vae_model.py:887-893
+            return self.diverse_beam_search(encoded, max_length, kwargs.get("beam_size", 5), kwargs.get("group_size", 5),
+                                            kwargs.get("diversity_lambda", 0.5), kwargs.get("temperature", 1.0),
+                                            kwargs.get("group_nbest", True))
         if method != "greedy":
             raise NotImplementedError(f"inference method {method!r}: the HIP path implements greedy decoding with "
-                                      "z ~ prior and beam search (dbs / gumbel / multinomial are SURVEY §8(f) next rows)")
+                                      "z ~ prior, beam search and diverse beam search (gumbel / multinomial sampling "
+                                      "are not on SURVEY §8's path)")
         return self.stepwise_forward(encoded, None, None, **kwargs)
 
     def forward(self, *input, **kwargs):

@@ -247,6 +247,12 @@ int acvae_logprob_add(const float* logits, int64_t ld, const float* lse, const f
                       void* stream);
 int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx, int64_t* row, int64_t* col,
                     void* stream);
+/* Diverse beam search, models/word_model.py:344-348 with add_diversity :298-312: per beam row
+ *   out[n,c] = log_softmax(log_softmax(logits[n]) / temperature)[c] - diversity_lambda * counts[c] + prev[n]
+ * counts [V] (may be NULL: first group) = how often the earlier groups chose word c at this local step; prev [N]
+ * (may be NULL) the running beam log-probabilities. */
+int acvae_dbs_scores(const float* logits, int64_t ld, float temperature, const float* counts, float diversity_lambda,
+                     const float* prev, float* out, int N, int V, void* stream);
 
 #ifdef __cplusplus
 }

@@ -446,6 +446,79 @@ def beam_search(state, feats, feat_lens, beam_size=3, max_length=MAX_LENGTH, eps
 
 
 # ----------------------------------------------------------------------------
+# N3  CaptionModel.diverse_beam_search   models/word_model.py:297-394 with the Hybrid_VAEModel hooks
+#     (prepare_dbs_decoder_input / dbs_step / dbs_process_step, models/vae_model.py:997-1040)
+# ----------------------------------------------------------------------------
+def diverse_beam_search(state, feats, feat_lens, beam_size=5, group_size=5, diversity_lambda=0.5, temperature=1.0,
+                        group_nbest=True, max_length=MAX_LENGTH):
+    """Group g of a clip runs one step behind group g-1 (global step t = local step + g); at a local step its
+    log-probabilities are lowered by lambda x (how often the earlier groups chose each word at that local step).
+    Per group `bdash = beam_size // group_size` beams; finished beams are scored by logprob / length.  Returns seqs
+    i64 [N, beam_size (group_nbest) or group_size, max_length], <end>-filled.  The randn draws of the prior come
+    from torch's CPU generator in call order (clip, t, group)."""
+    enc = cnn10_forward(state, feats, feat_lens, training=False)
+    if "ln.weight" in state:
+        enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
+    mem_all, lens_all = enc["audio_embeds"], enc["audio_embeds_lens"]
+    N = mem_all.shape[0]
+    E = state["decoder.word_embeddings.weight"].shape[1]
+    H = state["decoder.model.weight_hh_l0"].shape[1]
+    V = state["decoder.classifier.weight"].shape[0]
+    bdash = beam_size // group_size
+    out = torch.full((N, beam_size if group_nbest else group_size, max_length), END_IDX, dtype=torch.long)
+    for i in range(N):
+        mem = mem_all[i].unsqueeze(0).repeat(bdash, 1, 1)
+        lens = lens_all[i].repeat(bdash)
+        seq = [torch.zeros(bdash, 0, dtype=torch.long) for _ in range(group_size)]
+        score = [mem.new_zeros(bdash) for _ in range(group_size)]
+        done = [[] for _ in range(group_size)]
+        carry = [None] * group_size          # (h, (hp, cp), last_z, next_word, parent beam) of each group
+        for t in range(max_length + group_size - 1):
+            for g in range(group_size):
+                lt = t - g
+                if lt < 0 or lt > max_length - 1:
+                    continue
+                if lt == 0:
+                    w = torch.full((bdash,), START_IDX, dtype=torch.long)
+                    h = mem.new_zeros(bdash, H)
+                    hc = (mem.new_zeros(bdash, E), mem.new_zeros(bdash, E))
+                    last_z = mem.new_zeros(bdash, E)
+                else:
+                    h0, hc0, z0, w, parent = carry[g]
+                    h, hc, last_z = h0[parent], (hc0[0][parent], hc0[1][parent]), z0[parent]
+                pr = prior_step(state, w.unsqueeze(1), mem, hc, last_z, lens)
+                d = decoder_step(state, w.unsqueeze(1), h, mem, lens, pr["z"])
+                lp = torch.log_softmax(d["logits"], dim=1)
+                lp = torch.log_softmax(lp / temperature, dim=1)
+                if g > 0:                                            # add_diversity, word_model.py:298-312
+                    counts = torch.zeros(V)
+                    for earlier in range(g):
+                        for b in range(bdash):
+                            counts[seq[earlier][b, lt]] += 1
+                    lp = lp - counts.unsqueeze(0) * diversity_lambda
+                lp = score[g].unsqueeze(1) + lp
+                flat = lp[0] if lt == 0 else lp.reshape(-1)
+                top, words = flat.topk(bdash, 0, True, True)
+                score[g] = top
+                parent = torch.div(words, V, rounding_mode="floor")
+                nxt = words % V
+                seq[g] = torch.cat([seq[g][parent] if lt > 0 else seq[g], nxt.unsqueeze(1)], dim=1)
+                ended = seq[g][:, lt] == END_IDX
+                if t == max_length + g - 1:
+                    ended[:] = True
+                for b in range(bdash):
+                    if ended[b]:
+                        done[g].append({"seq": seq[g][b].clone(), "score": score[g][b].item() / (lt + 1)})
+                score[g][ended] -= 1000
+                carry[g] = (d["state"], pr["hiddens_state"], pr["z"], nxt, parent)
+        done = [sorted(d_, key=lambda x: -x["score"])[:bdash] for d_ in done]
+        chosen = sum(done, []) if group_nbest else [d_[0] for d_ in done]
+        for r, beam in enumerate(chosen):
+            out[i, r, :len(beam["seq"])] = beam["seq"]
+    return out
+
+
+# ----------------------------------------------------------------------------
 # A8/A9/A13 losses ; A10 loss assembly + optimiser
 # ----------------------------------------------------------------------------
 def label_smoothing_loss(logit, target, classes, smoothing):

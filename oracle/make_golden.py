@@ -264,6 +264,42 @@ def g9_beam(ref):
     save("g9_beam", dims=np.array([3, 96, V, E, beam]), feats=feats, feat_lens=feat_lens, eps=eps, seqs=ro["seqs"])
 
 
+DBS_CASES = [dict(beam_size=4, group_size=2), dict(beam_size=6, group_size=3, diversity_lambda=0.8, temperature=1.5,
+             group_nbest=False), dict(), dict(beam_size=6, group_size=2, diversity_lambda=2.0)]
+
+
+def g11_dbs(ref):
+    """N3: the reference's diverse beam search (word_model.py:297-394 + vae_model.py:997-1040) on two clips, four
+    argument sets; a second weight set raises the <end> logit so that beams finish early.  The prior's randn draws
+    come from the CPU generator seeded per case; the oracle must reproduce the token ids exactly."""
+    V, E, ML = 40, 64, 7
+    g = torch.Generator().manual_seed(111)
+    feats = torch.randn(2, 96, 64, generator=g)
+    feat_lens = np.array([96, 80])
+    out = {}
+    for tag, bump in (("a", 0.0), ("b", 0.3)):
+        state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+        state["decoder.classifier.bias"] = state["decoder.classifier.bias"].clone()
+        state["decoder.classifier.bias"][O.END_IDX] += bump
+        model = ref_shim.build_reference_model(ref, V, E, E)
+        load_state_into(model, state)
+        model.eval()
+        for ci, kw in enumerate(DBS_CASES):
+            torch.manual_seed(40 + ci)
+            with torch.no_grad():
+                rs = model(feats, feat_lens.copy(), method="dbs", max_length=ML, **kw)["seqs"]
+            torch.manual_seed(40 + ci)
+            with torch.no_grad():
+                os_ = O.diverse_beam_search({k: v.clone() for k, v in state.items()}, feats, feat_lens.copy(),
+                                            max_length=ML, **kw)
+            assert torch.equal(rs, os_), (tag, kw)
+            out[f"seqs_{tag}{ci}"] = rs
+    ends = sum(int((v[..., :-1] == O.END_IDX).any()) for k, v in out.items() if k.startswith("seqs_b"))
+    assert ends > 0, "the <end>-biased weights should finish some beams early"
+    save("g11_dbs", dims=np.array([2, 96, V, E, ML]), feats=feats, feat_lens=feat_lens, end_bump=np.array([0.0, 0.3]),
+         **out)
+
+
 def g10_host():
     """Batch / evaluation contract, produced by the reference's own host code: collate_fn (caption_dataset.py:278-318)
     on a seeded ragged training batch and an evaluation batch, Vocabulary (build_vocab.py:9-28) pickled, and
@@ -305,7 +341,11 @@ def main():
         g10_host()
         return
     ref = ref_shim.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "dbs":
+        g11_dbs(ref)
+        return
     g10_host()
+    g11_dbs(ref)
     g1_attention(ref); g2_reparam_kl(ref); g3_ce(ref); g4_encoder(ref); g5_rnn(ref)
     train_fixture(ref, "g6_train_step", 4, 64, 50, 64, 8, True, 0, seed=6)
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)

@@ -118,3 +118,21 @@ def test_forward_batch_train_mode_packs_like_the_runner():
     assert torch.equal(out["targets"].cpu(), HO.packed(batch[1][:, 1:], lens1))
     out["packed_logits"].sum().backward()                       # the gather is autograd-connected to the decode
     assert model.decoder.classifier.weight.grad is not None
+
+
+def test_evaluate_dbs_matches_oracle():
+    """method="dbs": no replication (:101), the search returns [clips, beams, len] and every beam becomes a caption."""
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    model = build_model(V, E, state)
+    items, voc = clips(2), vocab()
+    torch.manual_seed(13)
+    got = EV.evaluate(model, items, voc, method="dbs", beam_size=4, group_size=2, diversity_lambda=0.7, max_length=6)
+    torch.manual_seed(13)
+    keys_pb, seqs_pb = [], []
+    for key, feat in items:
+        with torch.no_grad():
+            seqs = O.diverse_beam_search({k: v.clone() for k, v in state.items()}, feat[None], np.array([feat.shape[0]]),
+                                         beam_size=4, group_size=2, diversity_lambda=0.7, max_length=6)
+        keys_pb.append([key]); seqs_pb.append(seqs.numpy())
+    want = HO.predictions(keys_pb, seqs_pb, voc.idx2word)
+    assert got == want and len(got["predictions"][1]["captions"]) == 4

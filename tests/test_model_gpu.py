@@ -188,6 +188,44 @@ def test_g9_beam_search_token_exact():
     assert np.array_equal(o["seqs"].cpu().numpy(), g["seqs"])
 
 
+DBS_CASES = [dict(beam_size=4, group_size=2), dict(beam_size=6, group_size=3, diversity_lambda=0.8, temperature=1.5,
+             group_nbest=False), dict(), dict(beam_size=6, group_size=2, diversity_lambda=2.0)]
+
+
+def test_g11_diverse_beam_search_token_exact():
+    """N3: diverse beam search against the reference's own output (golden g11), incl. beams that finish early."""
+    g = load_golden("g11_dbs")
+    _, _, V, E, ML = (int(x) for x in g["dims"])
+    for tag, bump in zip("ab", g["end_bump"]):
+        state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+        state["decoder.classifier.bias"] = state["decoder.classifier.bias"].clone()
+        state["decoder.classifier.bias"][O.END_IDX] += float(bump)
+        model = build_model(V, E, state).eval()
+        for ci, kw in enumerate(DBS_CASES):
+            torch.manual_seed(40 + ci)          # the prior's randn draws come from the CPU generator in call order (F9)
+            with torch.no_grad():
+                o = model(T(g["feats"]).cuda(), g["feat_lens"].copy(), method="dbs", max_length=ML, **kw)
+            assert np.array_equal(o["seqs"].cpu().numpy(), g[f"seqs_{tag}{ci}"]), (tag, kw)
+
+
+def test_dbs_scores_kernel_vs_torch():
+    from acvae_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    N, V = 5, 5000
+    logits = (torch.randn(N, V, generator=g) * 3).cuda()
+    counts = torch.randint(0, 3, (V,), generator=g).float().cuda()
+    prev = torch.randn(N, generator=g).cuda()
+    out = torch.empty(N, V, device="cuda")
+    for temp, lam, cnt, pv in ((1.0, 0.5, counts, prev), (1.7, 2.0, counts, None), (0.6, 0.0, None, prev)):
+        _lib.call("acvae_dbs_scores", logits, V, temp, cnt, lam, pv, out, N, V, _lib.current_stream())
+        want = torch.log_softmax(torch.log_softmax(logits.cpu(), 1) / temp, 1)
+        if cnt is not None:
+            want = want - cnt.cpu() * lam
+        if pv is not None:
+            want = want + pv.cpu()[:, None]
+        close(out, want, 1e-5, 1e-5, what=f"dbs scores T={temp}")
+
+
 def test_single_step_modules_vs_oracle():
     """A4/A5 per-call API: pnet.forward / decoder.forward one step at a time."""
     V, E, N, S = 40, 64, 5, 9

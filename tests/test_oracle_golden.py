@@ -140,3 +140,27 @@ def test_g9_beam_search_token_exact():
     with torch.no_grad():
         seqs = O.beam_search(state, T(g["feats"]), g["feat_lens"].copy(), beam, O.MAX_LENGTH, T(g["eps"]))
     assert np.array_equal(seqs.numpy(), g["seqs"])
+
+
+DBS_CASES = [dict(beam_size=4, group_size=2), dict(beam_size=6, group_size=3, diversity_lambda=0.8, temperature=1.5,
+             group_nbest=False), dict(), dict(beam_size=6, group_size=2, diversity_lambda=2.0)]
+
+
+def dbs_state(V, E, bump):
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    state["decoder.classifier.bias"] = state["decoder.classifier.bias"].clone()
+    state["decoder.classifier.bias"][O.END_IDX] += float(bump)
+    return state
+
+
+def test_g11_diverse_beam_search_token_exact():
+    """N3: reference = word_model.py:297-394 + vae_model.py:997-1040 (golden made by running it)."""
+    g = load_golden("g11_dbs")
+    _, _, V, E, ML = (int(x) for x in g["dims"])
+    for tag, bump in zip("ab", g["end_bump"]):
+        state = dbs_state(V, E, bump)
+        for ci, kw in enumerate(DBS_CASES):
+            torch.manual_seed(40 + ci)
+            with torch.no_grad():
+                seqs = O.diverse_beam_search(state, T(g["feats"]), g["feat_lens"].copy(), max_length=ML, **kw)
+            assert np.array_equal(seqs.numpy(), g[f"seqs_{tag}{ci}"]), (tag, kw)
