@@ -10,6 +10,10 @@ struct DropoutSpec {
   uint32_t site;        // dropout call-site id (0..5 in Cnn10.forward order)
 };
 
+// upstream of a BN+ReLU output in the backward: UP_PLAIN = dO as is; UP_POOL = through dropout + 2x2 average pool;
+// UP_DROP = through dropout only (pool_size (1,1))
+enum { UP_PLAIN = 0, UP_POOL = 1, UP_DROP = 2 };
+
 namespace acvae {
 int conv3x3_igemm(const float* X, const float* scale, const float* shift, const float* Wp, float* Y, float* partials,
                   int N, int H, int W, int Cin, int Cout, hipStream_t st);
@@ -32,10 +36,11 @@ int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, co
 int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
                     const float* W1, const float* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
                     float* dbeta0, double* dpart, int N, int T, int F, hipStream_t st);
+// pool: 2x2 average pool after BN+ReLU (ConvBlock pool_size (2,2)); !pool: pool_size (1,1) (Cnn14's last block)
 int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* P, int N, int H, int W, int C,
-                 DropoutSpec drop, hipStream_t st);
+                 DropoutSpec drop, hipStream_t st, bool pool = true);
 int bn_bwd_blocks(int N, int H, int W);
-int bn_bwd(const float* Y, const float* dO, bool pool, const float* scale, const float* shift, const float* mean,
+int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
            int W, int C, DropoutSpec drop, hipStream_t st);
 int freq_mean(const float* P, float* out, long rows, int Fp, int C, hipStream_t st);

@@ -568,12 +568,39 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ Y, const float* __
   }
 }
 
+// pool_size (1,1): BN + ReLU + dropout at full resolution
+__global__ void bn_relu_drop_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float* __restrict__ P, int N, int H, int W, int C,
+                                    DropoutSpec drop) {
+  const int C4 = C / 4;
+  const long total = (long)N * H * W * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+    const float4 a = bnrelu4(reinterpret_cast<const float4*>(Y)[i], sc, sh);
+    const float4 m = drop4(drop, i, n, h, w, c4 * 4, H, W, C);
+    reinterpret_cast<float4*>(P)[i] = make_float4(a.x * m.x, a.y * m.y, a.z * m.z, a.w * m.w);
+  }
+}
+
 // ------------------------------------------------------------------ BN backward
-// g = relu'(bn(Y)) * upstream;  POOL: upstream = dP[n,h/2,w/2,c] * dropmask * 0.25 (0 for a trailing odd row/col)
-template <bool POOL>
+// g = relu'(bn(Y)) * upstream;  UP_POOL: upstream = dP[n,h/2,w/2,c] * dropmask * 0.25 (0 for a trailing odd row/col)
+template <int UP>
 __device__ __forceinline__ float4 upstream4(const float* __restrict__ dO, const DropoutSpec& drop, int n, int h, int w,
                                             int c, int H, int W, int C) {
-  if (!POOL) return *reinterpret_cast<const float4*>(dO + ((((long)n * H + h) * W + w) * C + c));
+  if (UP == UP_PLAIN) return *reinterpret_cast<const float4*>(dO + ((((long)n * H + h) * W + w) * C + c));
+  if (UP == UP_DROP) {
+    const long i4 = ((((long)n * H + h) * W + w) * C + c) >> 2;
+    float4 v = reinterpret_cast<const float4*>(dO)[i4];
+    const float4 m = drop4(drop, i4, n, h, w, c, H, W, C);
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    return v;
+  }
   const int Ho = H / 2, Wo = W / 2;
   const int ho = h >> 1, wo = w >> 1;
   if (ho >= Ho || wo >= Wo) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -584,8 +611,9 @@ __device__ __forceinline__ float4 upstream4(const float* __restrict__ dO, const 
   return v;
 }
 
-// partials [blocks][2][C]: sum g | sum g*yhat.  Block = 256 threads = (C/4) channel-quads x (1024/C) pixels.
-template <bool POOL>
+// partials [blocks][2][C]: sum g | sum g*yhat.  Block = 256 threads = (Cc/4) channel-quads x (1024/Cc) pixels of the
+// channel chunk blockIdx.y (Cc = min(C, 1024) channels per chunk).
+template <int UP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ Y, const float* __restrict__ dO,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
@@ -594,11 +622,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             float* __restrict__ partials, int N, int H, int W, int C,
                                                             int pix_per_block, DropoutSpec drop) {
   extern __shared__ float red[];  // [256][8]
-  const int C4 = C / 4;
+  const int Cc = C < 1024 ? C : 1024;
+  const int C4 = Cc / 4;
   const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
   const long M = (long)N * H * W;
   const long p0 = (long)blockIdx.x * pix_per_block;
-  const int c = cq * 4;
+  const int c = blockIdx.y * Cc + cq * 4;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (pl < npl) {
     const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
@@ -608,7 +637,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       const long t = p / W;
       const int h = (int)(t % H), n = (int)(t / H);
       const float4 y = *reinterpret_cast<const float4*>(Y + p * C + c);
-      float4 g = upstream4<POOL>(dO, drop, n, h, w, c, H, W, C);
+      float4 g = upstream4<UP>(dO, drop, n, h, w, c, H, W, C);
       if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
       if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
       if (y.z * sc.z + sh.z <= 0.f) g.z = 0.f;
@@ -633,7 +662,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // dY = scale * (g - sum_g/n - yhat * sum_gy/n)      (scale = gamma * invstd)
-template <bool POOL>
+template <int UP>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ Y, const float* __restrict__ dO,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -652,7 +681,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ Y, const float* __
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
     const float4 sg = *reinterpret_cast<const float4*>(sum_g + c), sgy = *reinterpret_cast<const float4*>(sum_gy + c);
     const float4 y = reinterpret_cast<const float4*>(Y)[i];
-    float4 g = upstream4<POOL>(dO, drop, n, h, w, c, H, W, C);
+    float4 g = upstream4<UP>(dO, drop, n, h, w, c, H, W, C);
     if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
     if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
     if (y.z * sc.z + sh.z <= 0.f) g.z = 0.f;
@@ -873,37 +902,38 @@ int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, co
 }
 
 int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* P, int N, int H, int W, int C,
-                 DropoutSpec drop, hipStream_t st) {
-  const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-  if (total <= 0) return ACVAE_EINVAL;
-  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
+                 DropoutSpec drop, hipStream_t st, bool pool) {
+  const long total = pool ? (long)N * (H / 2) * (W / 2) * (C / 4) : (long)N * H * W * (C / 4);
+  if (total <= 0 || C % 4 != 0) return ACVAE_EINVAL;
+  if (pool)
+    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
+  else
+    hipLaunchKernelGGL(bn_relu_drop_kernel, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
 
 constexpr int BNB_PIX = 512;
 int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, BNB_PIX); }
-int bn_bwd(const float* Y, const float* dO, bool pool, const float* scale, const float* shift, const float* mean,
+int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
            int W, int C, DropoutSpec drop, hipStream_t st) {
-  if (C % 4 != 0 || C > 1024 || 1024 % C != 0) return ACVAE_EUNSUPPORTED;
-  const int nb = bn_bwd_blocks(N, H, W);
+  const int Cc = C < 1024 ? C : 1024;
+  if (C % 4 != 0 || 1024 % Cc != 0 || C % Cc != 0) return ACVAE_EUNSUPPORTED;
+  const dim3 rgrid(bn_bwd_blocks(N, H, W), C / Cc);
+  const int nb = rgrid.x;
   const size_t shm = 256 * 8 * sizeof(float);
-  if (pool)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), shm, st, Y, dO, scale, shift, mean, invstd,
-                       partials, N, H, W, C, BNB_PIX, drop);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), shm, st, Y, dO, scale, shift, mean, invstd,
-                       partials, N, H, W, C, BNB_PIX, drop);
-  // sum_g (= dbeta) | sum_gy (= dgamma)
-  ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st));
   const long total = (long)N * H * W * (C / 4);
-  if (pool)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,
-                       invstd, sum_g, sum_gy, dY, N, H, W, C, drop);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,
-                       invstd, sum_g, sum_gy, dY, N, H, W, C, drop);
+#define BN_BWD_LAUNCH(UP_)                                                                                             \
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<UP_>, rgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials, \
+                     N, H, W, C, BNB_PIX, drop);                                                                       \
+  ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st)); /* sum_g (= dbeta) | sum_gy (= dgamma) */        \
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<UP_>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,       \
+                     invstd, sum_g, sum_gy, dY, N, H, W, C, drop)
+  if (upstream == UP_POOL) { BN_BWD_LAUNCH(UP_POOL); }
+  else if (upstream == UP_DROP) { BN_BWD_LAUNCH(UP_DROP); }
+  else { BN_BWD_LAUNCH(UP_PLAIN); }
+#undef BN_BWD_LAUNCH
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

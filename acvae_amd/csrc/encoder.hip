@@ -8,14 +8,25 @@
 
 namespace {
 
-constexpr int kChan[5] = {1, 64, 128, 256, 512};
+// arch 0: Cnn10 (models/encoder.py:651-707): 4 blocks, every block 2x2-pooled, 512-wide output, time / 16.
+// arch 1: Cnn14_16k (models/encoder.py:871-964): 6 blocks up to 2048 channels, block 6 pooled (1,1), time / 32.
+constexpr int kMaxBlocks = 6;
+constexpr int kChan[kMaxBlocks + 1] = {1, 64, 128, 256, 512, 1024, 2048};
+struct Arch { int blocks; bool pool_last; };
+inline bool arch_of(int arch, Arch& a) {
+  if (arch == ACVAE_ARCH_CNN10) { a = {4, true}; return true; }
+  if (arch == ACVAE_ARCH_CNN14_16K) { a = {6, false}; return true; }
+  return false;
+}
 
 struct EncLayout {
   int N, T, F;
-  int H[5], W[5];              // conv spatial dims of block b (1..4); [0] unused
-  long y1[5], y2[5], p[5];     // float offsets into `saved`
-  long wf1[5], wf2[5];
-  long bn[9];                  // each: 4*C floats (scale, shift, mean, invstd); 0 = bn0, 1+2*(b-1)+{0,1} = block b bn1/bn2
+  int nb, Cemb;                // blocks; channels of the last block (= width of audio_embeds)
+  bool pool[kMaxBlocks + 1];   // block b ends in a 2x2 average pool
+  int H[kMaxBlocks + 1], W[kMaxBlocks + 1];    // conv spatial dims of block b (1..nb); [0] = dims after the last block
+  long y1[kMaxBlocks + 1], y2[kMaxBlocks + 1], p[kMaxBlocks + 1];     // float offsets into `saved`
+  long wf1[kMaxBlocks + 1], wf2[kMaxBlocks + 1];
+  long bn[2 * kMaxBlocks + 1];  // each: 4*C floats (scale, shift, mean, invstd); 0 = bn0, 1+2*(b-1)+{0,1} = block b bn1/bn2
   long pooled_in;
   long total;
   // scratch
@@ -24,16 +35,20 @@ struct EncLayout {
 
 long align4(long x) { return (x + 63) & ~63L; }
 
-int make_layout(int N, int T, int F, EncLayout& L) {
-  if (N <= 0 || F != 64 || T < 16) return ACVAE_EINVAL;
-  L.N = N; L.T = T; L.F = F;
+int make_layout(int arch, int N, int T, int F, EncLayout& L) {
+  Arch A;
+  if (!arch_of(arch, A)) return ACVAE_EINVAL;
+  const int div = 1 << (A.pool_last ? A.blocks : A.blocks - 1);
+  if (N <= 0 || F != 64 || T < div) return ACVAE_EINVAL;
+  L.N = N; L.T = T; L.F = F; L.nb = A.blocks; L.Cemb = kChan[A.blocks];
   long off = 0;
   int h = T, w = F;
   long max_act = 0, max_pool = 0, max_part = 0, max_slab = 0, max_bnpart = 0;
-  for (int b = 1; b <= 4; ++b) {
+  for (int b = 1; b <= L.nb; ++b) {
     L.H[b] = h; L.W[b] = w;
+    L.pool[b] = b < L.nb || A.pool_last;
     const long act = (long)N * h * w * kChan[b];
-    const long pool = (long)N * (h / 2) * (w / 2) * kChan[b];
+    const long pool = L.pool[b] ? (long)N * (h / 2) * (w / 2) * kChan[b] : act;
     L.y1[b] = off; off = align4(off + act);
     L.y2[b] = off; off = align4(off + act);
     L.p[b] = off; off = align4(off + pool);
@@ -51,14 +66,14 @@ int make_layout(int N, int T, int F, EncLayout& L) {
     }
     const long bp = (long)acvae::bn_bwd_blocks(N, h, w) * 2 * kChan[b];
     if (bp > max_bnpart) max_bnpart = bp;
-    h /= 2; w /= 2;
+    if (L.pool[b]) { h /= 2; w /= 2; }
   }
-  L.H[0] = h; L.W[0] = w;  // S and F' after the last pool
-  for (int i = 0; i < 9; ++i) {
+  L.H[0] = h; L.W[0] = w;  // S and F' after the last block
+  for (int i = 0; i < 2 * L.nb + 1; ++i) {
     const int C = i == 0 ? 64 : kChan[(i - 1) / 2 + 1];
     L.bn[i] = off; off = align4(off + 4L * C);
   }
-  L.pooled_in = off; off = align4(off + (long)N * 512);
+  L.pooled_in = off; off = align4(off + (long)N * L.Cemb);
   L.total = off;
   // scratch
   const long c1 = (long)acvae::conv1_first_blocks(N, T) * 128;
@@ -66,10 +81,10 @@ int make_layout(int N, int T, int F, EncLayout& L) {
   if (c1 > max_part) max_part = c1;
   if (b0 > max_part) max_part = b0;
   long s = 0;
-  L.s_dpart = s; s = align4(s + 2 * acvae::colsum_scratch_doubles(1024));
+  L.s_dpart = s; s = align4(s + 2 * acvae::colsum_scratch_doubles(2 * L.Cemb > 1024 ? 2 * L.Cemb : 1024));
   L.s_partials = s; s = align4(s + max_part);
   L.s_bnpart = s; s = align4(s + max_bnpart);
-  L.s_wd = s; s = align4(s + 512L * 9 * 512);
+  L.s_wd = s; s = align4(s + (long)L.Cemb * 9 * L.Cemb);
   L.s_slab = s; s = align4(s + max_slab);
   L.s_c1w = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 576);
   L.s_c1b = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 128);
@@ -85,7 +100,8 @@ int make_layout(int N, int T, int F, EncLayout& L) {
 inline int p_bn0(int k) { return k; }                                  // w, b, rm, rv, nbt
 inline int p_conv(int b, int which) { return 5 + (b - 1) * 12 + (which - 1); }
 inline int p_bn(int b, int which, int k) { return 5 + (b - 1) * 12 + 2 + (which - 1) * 5 + k; }
-constexpr int P_EMBED_W = 53, P_EMBED_B = 54;
+inline int p_fc_w(int nb) { return 5 + nb * 12; }       // embed_pooled (Cnn10) / fc1 (Cnn14_16k)
+inline int p_fc_b(int nb) { return 6 + nb * 12; }
 
 struct BnPtrs { float *scale, *shift, *mean, *invstd; };
 inline BnPtrs bn_at(float* saved, const EncLayout& L, int i) {
@@ -104,23 +120,34 @@ inline DropoutSpec dspec(float p, const uint8_t* const* masks, uint64_t seed, in
 
 }  // namespace
 
-extern "C" int64_t acvae_encoder_saved_bytes(int N, int T, int F) {
+extern "C" int acvae_encoder_nparams(int arch) {
+  Arch A;
+  return arch_of(arch, A) ? 7 + A.blocks * 12 : -1;
+}
+extern "C" int acvae_encoder_out_dims(int arch, int T, int* S, int* C) {
+  Arch A;
+  if (!arch_of(arch, A) || !S || !C) return ACVAE_EINVAL;
+  *S = T >> (A.pool_last ? A.blocks : A.blocks - 1);
+  *C = kChan[A.blocks];
+  return ACVAE_OK;
+}
+extern "C" int64_t acvae_encoder_saved_bytes(int arch, int N, int T, int F) {
   EncLayout L;
-  if (make_layout(N, T, F, L) != ACVAE_OK) return -1;
+  if (make_layout(arch, N, T, F, L) != ACVAE_OK) return -1;
   return L.total * (int64_t)sizeof(float);
 }
-extern "C" int64_t acvae_encoder_scratch_bytes(int N, int T, int F) {
+extern "C" int64_t acvae_encoder_scratch_bytes(int arch, int N, int T, int F) {
   EncLayout L;
-  if (make_layout(N, T, F, L) != ACVAE_OK) return -1;
+  if (make_layout(arch, N, T, F, L) != ACVAE_OK) return -1;
   return L.s_total * (int64_t)sizeof(float);
 }
 
 extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, float* audio_embeds, float* pooled,
-                                 void* saved_v, int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N,
-                                 int T, int F, int training, float p_block, float p_fc, uint64_t seed,
+                                 void* saved_v, int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int arch,
+                                 int N, int T, int F, int training, float p_block, float p_fc, uint64_t seed,
                                  const uint8_t* const* masks, void* stream) {
   EncLayout L;
-  ACVAE_TRY(make_layout(N, T, F, L));
+  ACVAE_TRY(make_layout(arch, N, T, F, L));
   if (!params || !feats || !audio_embeds || !pooled || !saved_v || !scratch_v) return ACVAE_EINVAL;
   if (saved_bytes < L.total * (int64_t)sizeof(float) || scratch_bytes < L.s_total * (int64_t)sizeof(float))
     return ACVAE_EWORKSPACE;
@@ -139,7 +166,7 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
   ACVAE_TRY(acvae::bn_finalize(partials, nparts, 64, (double)N * T, P(p_bn0(0)), P(p_bn0(1)), P(p_bn0(2)), P(p_bn0(3)),
                                (int64_t*)params[p_bn0(4)], training, b0.scale, b0.shift, b0.mean, b0.invstd, dpart, st));
   const float* x_in = nullptr;
-  for (int b = 1; b <= 4; ++b) {
+  for (int b = 1; b <= L.nb; ++b) {
     const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
     const double cnt = (double)N * H * W;
     float* Y1 = saved + L.y1[b];
@@ -166,26 +193,26 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
                                  P(p_bn(b, 2, 1)), P(p_bn(b, 2, 2)), P(p_bn(b, 2, 3)), (int64_t*)params[p_bn(b, 2, 4)],
                                  training, n2.scale, n2.shift, n2.mean, n2.invstd, dpart, st));
     ACVAE_TRY(acvae::bn_relu_pool(Y2, n2.scale, n2.shift, saved + L.p[b], N, H, W, C,
-                                  dspec(p_block, masks, seed, b - 1, training), st));
+                                  dspec(p_block, masks, seed, b - 1, training), st, L.pool[b]));
     x_in = saved + L.p[b];
   }
-  const int S = L.H[0], Fp = L.W[0];
-  ACVAE_TRY(acvae::freq_mean(saved + L.p[4], audio_embeds, (long)N * S, Fp, 512, st));
-  // pooled branch (encoder.py:693-698)
+  const int S = L.H[0], Fp = L.W[0], Ce = L.Cemb;
+  ACVAE_TRY(acvae::freq_mean(saved + L.p[L.nb], audio_embeds, (long)N * S, Fp, Ce, st));
+  // pooled branch (encoder.py:693-698 / :944-950): dropout sites nb, nb+1 after the nb block sites
   float* pin = saved + L.pooled_in;
-  ACVAE_TRY(acvae::time_pool(audio_embeds, pin, N, S, 512, dspec(p_fc, masks, seed, 4, training), st));
-  ACVAE_TRY(acvae_gemm_nt_dual(pin, 512, P(P_EMBED_W), 512, 512, nullptr, 0, nullptr, 0, 0, P(P_EMBED_B), pooled, 512,
-                               N, 512, 0, st));
-  ACVAE_TRY(acvae::relu_dropout(pooled, N * 512, dspec(p_fc, masks, seed, 5, training), st));
+  ACVAE_TRY(acvae::time_pool(audio_embeds, pin, N, S, Ce, dspec(p_fc, masks, seed, L.nb, training), st));
+  ACVAE_TRY(acvae_gemm_nt_dual(pin, Ce, P(p_fc_w(L.nb)), Ce, Ce, nullptr, 0, nullptr, 0, 0, P(p_fc_b(L.nb)), pooled, Ce,
+                               N, Ce, 0, st));
+  ACVAE_TRY(acvae::relu_dropout(pooled, N * Ce, dspec(p_fc, masks, seed, L.nb + 1, training), st));
   return ACVAE_OK;
 }
 
 extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
                                  const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
-                                 int64_t scratch_bytes, int N, int T, int F, float p_block, uint64_t seed,
+                                 int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
                                  const uint8_t* const* masks, void* stream) {
   EncLayout L;
-  ACVAE_TRY(make_layout(N, T, F, L));
+  ACVAE_TRY(make_layout(arch, N, T, F, L));
   if (!params || !grads || !feats || !d_audio_embeds || !saved_v || !scratch_v) return ACVAE_EINVAL;
   if (saved_bytes < L.total * (int64_t)sizeof(float) || scratch_bytes < L.s_total * (int64_t)sizeof(float))
     return ACVAE_EWORKSPACE;
@@ -203,21 +230,21 @@ extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, 
   float* bnpart = scratch + L.s_bnpart;
   double* dpart = (double*)(scratch + L.s_dpart);
   const int S = L.H[0], Fp = L.W[0];
-  ACVAE_TRY(acvae::freq_mean_bwd(d_audio_embeds, dp_cur, (long)N * S, Fp, 512, st));
-  for (int b = 4; b >= 1; --b) {
+  ACVAE_TRY(acvae::freq_mean_bwd(d_audio_embeds, dp_cur, (long)N * S, Fp, L.Cemb, st));
+  for (int b = L.nb; b >= 1; --b) {
     const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
     float* Y1 = saved + L.y1[b];
     float* Y2 = saved + L.y2[b];
     BnPtrs n1 = bn_at(saved, L, 1 + 2 * (b - 1)), n2 = bn_at(saved, L, 2 + 2 * (b - 1));
     // conv2 / bn2 / pool / dropout
-    ACVAE_TRY(acvae::bn_bwd(Y2, dp_cur, true, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
+    ACVAE_TRY(acvae::bn_bwd(Y2, dp_cur, L.pool[b] ? UP_POOL : UP_DROP, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
                             G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, 1), st));
     ACVAE_TRY(acvae::conv3x3_wgrad(dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
     ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), nullptr, wd, C, C, st));
     ACVAE_TRY(acvae::conv3x3_igemm(dya, nullptr, nullptr, wd, dyb, nullptr, N, H, W, C, C, st));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
-    ACVAE_TRY(acvae::bn_bwd(Y1, dyb, false, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
+    ACVAE_TRY(acvae::bn_bwd(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
                             G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st));
     if (b > 1) {
       ACVAE_TRY(acvae::conv3x3_wgrad(dya, saved + L.p[b - 1], nullptr, nullptr, G(p_conv(b, 1)), slab, N, H, W, Cin, C,

@@ -54,7 +54,7 @@ class ConvBlock(nn.Module):
         init_layer(self.conv1); init_layer(self.conv2); init_bn(self.bn1); init_bn(self.bn2)
 
     def forward(self, *a, **k):
-        raise RuntimeError("ConvBlock is a parameter container on the HIP path; call Cnn10.forward")
+        raise RuntimeError("ConvBlock is a parameter container on the HIP path; call the encoder's forward")
 
 
 def _bn_tensors(bn):
@@ -71,25 +71,27 @@ class _Cnn10Fn(torch.autograd.Function):
         N, T, F = feats.shape
         tensors = mod._param_table()
         dev = feats.device
-        saved_b = _lib.call("acvae_encoder_saved_bytes", N, T, F)
-        scratch_b = _lib.call("acvae_encoder_scratch_bytes", N, T, F)
+        arch = mod.ARCH
+        saved_b = _lib.call("acvae_encoder_saved_bytes", arch, N, T, F)
+        scratch_b = _lib.call("acvae_encoder_scratch_bytes", arch, N, T, F)
         if saved_b < 0:
-            raise RuntimeError(f"Cnn10: unsupported input shape {tuple(feats.shape)} (need F=64, T>=16)")
+            raise RuntimeError(f"{type(mod).__name__}: unsupported input shape {tuple(feats.shape)} "
+                               f"(need F=64, T>={mod.TIME_DIV})")
         saved = torch.empty(saved_b, dtype=torch.uint8, device=dev)
         scratch = scratch_buffer(scratch_b, dev)
-        S = T // 16
-        ae = torch.empty(N, S, 512, device=dev)
-        pooled = torch.empty(N, 512, device=dev)
+        S, C = T // mod.TIME_DIV, mod.OUT_CHANNELS
+        ae = torch.empty(N, S, C, device=dev)
+        pooled = torch.empty(N, C, device=dev)
         training = bool(mod.training)
         masks = None
         if training and mod.dropout_masks is not None:
             masks = [m.to(device=dev, dtype=torch.uint8).contiguous() for m in mod.dropout_masks]
-            if len(masks) != 6:
-                raise ValueError("dropout_masks must hold the 6 masks of Cnn10.forward in call order")
+            if len(masks) != mod.N_BLOCKS + 2:
+                raise ValueError(f"dropout_masks must hold the {mod.N_BLOCKS + 2} masks of the forward in call order")
         seed = mod._next_seed() if training else 0
         mt = ptr_table(masks) if masks is not None else None
-        _lib.call("acvae_encoder_fwd", ptr_table(tensors), feats, ae, pooled, saved, saved_b, scratch, scratch_b, N, T,
-                  F, int(training), float(mod.p_block), float(mod.p_fc), seed, mt, _lib.current_stream())
+        _lib.call("acvae_encoder_fwd", ptr_table(tensors), feats, ae, pooled, saved, saved_b, scratch, scratch_b, arch,
+                  N, T, F, int(training), float(mod.p_block), float(mod.p_fc), seed, mt, _lib.current_stream())
         ctx.mod, ctx.feats, ctx.saved, ctx.masks, ctx.seed = mod, feats, saved, masks, seed
         ctx.mark_non_differentiable(pooled)
         return ae, pooled
@@ -102,14 +104,14 @@ class _Cnn10Fn(torch.autograd.Function):
         grads = [None] * len(tensors)
         outs = []
         for i, t in enumerate(tensors):
-            if t.dtype.is_floating_point and t.requires_grad and i < 53:
+            if t.dtype.is_floating_point and t.requires_grad and i < len(tensors) - 2:
                 grads[i] = mod._grad_buffer(t)
         d_ae = d_ae.contiguous().float()
-        scratch_b = _lib.call("acvae_encoder_scratch_bytes", N, T, F)
+        scratch_b = _lib.call("acvae_encoder_scratch_bytes", mod.ARCH, N, T, F)
         scratch = scratch_buffer(scratch_b, feats.device)
         mt = ptr_table(ctx.masks) if ctx.masks is not None else None
         _lib.call("acvae_encoder_bwd", ptr_table(tensors), ptr_table(grads), feats, d_ae, ctx.saved,
-                  ctx.saved.numel(), scratch, scratch_b, N, T, F, float(mod.p_block), ctx.seed, mt,
+                  ctx.saved.numel(), scratch, scratch_b, mod.ARCH, N, T, F, float(mod.p_block), ctx.seed, mt,
                   _lib.current_stream())
         ctx.saved = None
         if mod._grad_ready_cb is not None:
@@ -119,37 +121,43 @@ class _Cnn10Fn(torch.autograd.Function):
         return (None, None, *outs)
 
 
-class Cnn10(nn.Module):
-    """PANNs CNN10 audio encoder (reference ``models/encoder.py:651-707``)."""
+class _PannsCnn(nn.Module):
+    """Shared plumbing of the PANNs CNN encoders: bn0 over the mel axis, N_BLOCKS ConvBlocks, a pooled head."""
+    ARCH, N_BLOCKS, TIME_DIV, OUT_CHANNELS, HEAD = 0, 4, 16, 512, "embed_pooled"
 
     def __init__(self, inputdim, embed_size, **kwargs):
         super().__init__()
         self.inputdim = inputdim          # BaseEncoder attributes
         self.embed_size = embed_size
         self.bn0 = nn.BatchNorm2d(64)
-        self.conv_block1 = ConvBlock(1, 64)
-        self.conv_block2 = ConvBlock(64, 128)
-        self.conv_block3 = ConvBlock(128, 256)
-        self.conv_block4 = ConvBlock(256, 512)
-        self.embed_pooled = nn.Linear(512, 512, bias=True)
+        chans = [1, 64, 128, 256, 512, 1024, 2048]
+        for b in range(1, self.N_BLOCKS + 1):
+            setattr(self, f"conv_block{b}", ConvBlock(chans[b - 1], chans[b]))
+        setattr(self, self.HEAD, nn.Linear(self.OUT_CHANNELS, self.OUT_CHANNELS, bias=True))
         init_bn(self.bn0)
-        init_layer(self.embed_pooled)
-        self.p_block, self.p_fc = 0.2, 0.5      # F.dropout probabilities, encoder.py:684-698
+        init_layer(getattr(self, self.HEAD))
+        self.p_block, self.p_fc = 0.2, 0.5      # F.dropout probabilities, encoder.py:684-698 / :929-950
         self.dropout_masks = None               # optional explicit keep-masks (parity tests)
         self._seed_base, self._calls = None, 0
         self._grad_views = None                 # {param: flat-gradient view}, set by the train-step harness
         self._grad_ready_cb = None              # called with "encoder" when the backward has written all grads
 
     # ---- plumbing
+    def _blocks(self):
+        return [getattr(self, f"conv_block{b}") for b in range(1, self.N_BLOCKS + 1)]
+
+    def _head(self):
+        return getattr(self, self.HEAD)
+
     def _param_table(self):
         t = _bn_tensors(self.bn0)
-        for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4):
+        for blk in self._blocks():
             t += [blk.conv1.weight, blk.conv2.weight] + _bn_tensors(blk.bn1) + _bn_tensors(blk.bn2)
-        t += [self.embed_pooled.weight, self.embed_pooled.bias]
+        t += [self._head().weight, self._head().bias]
         return t
 
     def _weights(self):
-        return [t for t in self._param_table()[:53] if isinstance(t, nn.Parameter)]
+        return [t for t in self._param_table()[:-2] if isinstance(t, nn.Parameter)]
 
     def _grad_buffer(self, p):
         if self._grad_views is not None and p in self._grad_views:
@@ -165,8 +173,19 @@ class Cnn10(nn.Module):
     def forward(self, input, lens):
         """input: [batch, time, 64] log-mel; lens: frame counts (numpy array / list / tensor)."""
         lens = torch.as_tensor(lens)
-        lens //= 16                       # in place on the caller's array, as the reference does (:677-678)
+        lens //= self.TIME_DIV            # in place on the caller's array, as the reference does (:677-678 / :913-914)
         lens_dev = _lib.h2d(lens, input.device, torch.long)   # staged before the kernels are queued
         ae, pooled = _Cnn10Fn.apply(self, input, *self._weights())
         return {"audio_embeds": ae, "audio_embeds_pooled": pooled, "state": None, "audio_embeds_lens": lens,
                 "audio_embeds_lens_dev": lens_dev}
+
+
+class Cnn10(_PannsCnn):
+    """PANNs CNN10 audio encoder (reference ``models/encoder.py:651-707``)."""
+
+
+class Cnn14_16k(_PannsCnn):
+    """PANNs CNN14 (16 kHz) audio encoder (reference ``models/encoder.py:871-964``): six ConvBlocks
+    up to 2048 channels, the sixth pooled (1,1), time / 32, ``fc1`` (2048 x 2048) as the pooled head.  With a 512-wide
+    decoder ``Hybrid_VAEModel`` adds the ``ln`` projection 2048 -> 512 (``models/vae_model.py:695-697``)."""
+    ARCH, N_BLOCKS, TIME_DIV, OUT_CHANNELS, HEAD = 1, 6, 32, 2048, "fc1"

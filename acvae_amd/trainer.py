@@ -108,7 +108,8 @@ class TrainStep:
     def _flatten(self):
         model = self.model
         enc_params = set(model.encoder.parameters())
-        never = {model.encoder.embed_pooled.weight, model.encoder.embed_pooled.bias}   # no gradient on this path
+        head = model.encoder._head()                                # embed_pooled / fc1: no gradient on this path
+        never = {head.weight, head.bias}
         params = [p for p in model.parameters() if p.requires_grad]
         text = [p for p in params if p not in enc_params]
         enc = [p for p in params if p in enc_params and p not in never]

@@ -121,17 +121,25 @@ int acvae_mse_bwd(const float* a, const float* b, const float* grad_out, float* 
  * fwd to bwd; `scratch` (acvae_encoder_scratch_bytes) is free between calls.  Gradients are WRITTEN
  * (not accumulated) for every conv / bn weight and bias; embed_pooled receives none (its output is
  * not consumed on this path, models/vae_model.py:821).
+ * `arch` selects the PANNs encoder: ACVAE_ARCH_CNN10 (above) or ACVAE_ARCH_CNN14_16K (SURVEY §8(f) N4,
+ * models/encoder.py:871-964): conv_block{1..6} up to 2048 channels, the sixth block pooled (1,1), S = T/32,
+ * audio_embeds [N,S,2048], the pooled head is fc1 (2048x2048); its table has 79 entries (…, conv_block6.*, fc1.{w,b})
+ * and 8 dropout sites.  acvae_encoder_nparams / acvae_encoder_out_dims report the table length and (S, C).
  * ------------------------------------------------------------------------------------------- */
-#define ACVAE_ENC_NPARAMS 55
-int64_t acvae_encoder_saved_bytes(int N, int T, int F);
-int64_t acvae_encoder_scratch_bytes(int N, int T, int F);
+#define ACVAE_ENC_NPARAMS 55          /* Cnn10 */
+#define ACVAE_ARCH_CNN10 0
+#define ACVAE_ARCH_CNN14_16K 1
+int acvae_encoder_nparams(int arch);
+int acvae_encoder_out_dims(int arch, int T, int* S, int* C);
+int64_t acvae_encoder_saved_bytes(int arch, int N, int T, int F);
+int64_t acvae_encoder_scratch_bytes(int arch, int N, int T, int F);
 int acvae_encoder_fwd(const void* const* params, const float* feats, float* audio_embeds, float* pooled,
-                      void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int T, int F,
-                      int training, float p_block, float p_fc, uint64_t seed, const uint8_t* const* masks,
+                      void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int arch, int N, int T,
+                      int F, int training, float p_block, float p_fc, uint64_t seed, const uint8_t* const* masks,
                       void* stream);
 int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
                       const float* d_audio_embeds, void* saved, int64_t saved_bytes, void* scratch,
-                      int64_t scratch_bytes, int N, int T, int F, float p_block, uint64_t seed,
+                      int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
                       const uint8_t* const* masks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -34,8 +34,13 @@ PAD_IDX, START_IDX, END_IDX, MAX_LENGTH = 0, 1, 2, 20  # models/word_model.py:19
 # ----------------------------------------------------------------------------
 # model description + closed-form parameters
 # ----------------------------------------------------------------------------
+ENCODERS = {"Cnn10": dict(channels=(64, 128, 256, 512), head="embed_pooled", div=16, pool_last=True),
+            # models/encoder.py:871-964: six blocks, the last one pooled (1,1), time // 32
+            "Cnn14_16k": dict(channels=(64, 128, 256, 512, 1024, 2048), head="fc1", div=32, pool_last=False)}
+
+
 def state_shapes(vocab_size: int, embed: int = 512, hidden: int = 512, attn: Optional[int] = None,
-                 q_hidden: Optional[int] = None, enc_embed: int = 512) -> Dict[str, tuple]:
+                 q_hidden: Optional[int] = None, enc_embed: int = 512, encoder: str = "Cnn10") -> Dict[str, tuple]:
     """Shapes of every state-dict entry of Hybrid_VAEModel(Cnn10, VAERNNBahdanauAttnDecoder,
     PosteriorRNN_hybrid, PriorRNN) in the reference's registration order.
 
@@ -56,13 +61,14 @@ def state_shapes(vocab_size: int, embed: int = 512, hidden: int = 512, attn: Opt
 
     bn("encoder.bn0", 64)
     cin = 1
-    for b, cout in enumerate((64, 128, 256, 512), start=1):
+    arch = ENCODERS[encoder]
+    for b, cout in enumerate(arch["channels"], start=1):
         p = f"encoder.conv_block{b}"
         s[p + ".conv1.weight"] = (cout, cin, 3, 3)
         s[p + ".conv2.weight"] = (cout, cout, 3, 3)
         bn(p + ".bn1", cout); bn(p + ".bn2", cout)
         cin = cout
-    s["encoder.embed_pooled.weight"] = (512, 512); s["encoder.embed_pooled.bias"] = (512,)
+    s[f"encoder.{arch['head']}.weight"] = (cin, cin); s[f"encoder.{arch['head']}.bias"] = (cin,)
     mem = E  # decoder is built with enc_mem_size = encoder embed_size (runner :44-48)
     s["decoder.word_embeddings.weight"] = (V, E)
     s["decoder.model.weight_ih_l0"] = (3 * H, E + 2 * mem)
@@ -194,29 +200,35 @@ def _bn_track(state, p, training):
 
 def cnn10_forward(state, feats, feat_lens, training=True, masks=None, record=None, prefix="encoder",
                   mutate_lens=True):
-    """models/encoder.py:672-707.  Returns dict(audio_embeds[N,S,512], audio_embeds_pooled[N,512],
-    audio_embeds_lens i64[N], state None)."""
+    """models/encoder.py:672-707 (Cnn10) and :906-964 (Cnn14_16k, recognised by its conv_block6 / fc1 entries).
+    Returns dict(audio_embeds[N,S,C], audio_embeds_pooled[N,C], audio_embeds_lens i64[N], state None)."""
+    arch = ENCODERS["Cnn14_16k" if prefix + ".fc1.weight" in state else "Cnn10"]
+    nblocks = len(arch["channels"])
     x = feats.unsqueeze(1)                                     # :676
     lens = torch.as_tensor(feat_lens)
     if not mutate_lens:
         lens = lens.clone()
-    lens //= 16                                                # :678 (in place: F11)
+    lens //= arch["div"]                                       # :678 / :914 (in place: F11)
     x = x.transpose(1, 3)
     x = _bn(state, prefix + ".bn0", x, training); _bn_track(state, prefix + ".bn0", training)
     x = x.transpose(1, 3)
-    for b in range(1, 5):                                      # :683-690, ConvBlock.forward :633-649
+    for b in range(1, nblocks + 1):                            # :683-690 / :928-939, ConvBlock.forward :633-649
         p = f"{prefix}.conv_block{b}"
         x = F.conv2d(x, state[p + ".conv1.weight"], None, 1, 1)
         x = F.relu(_bn(state, p + ".bn1", x, training)); _bn_track(state, p + ".bn1", training)
         x = F.conv2d(x, state[p + ".conv2.weight"], None, 1, 1)
         x = F.relu(_bn(state, p + ".bn2", x, training)); _bn_track(state, p + ".bn2", training)
-        x = F.avg_pool2d(x, kernel_size=(2, 2))
+        if b < nblocks or arch["pool_last"]:
+            x = F.avg_pool2d(x, kernel_size=(2, 2))
+        else:
+            x = F.avg_pool2d(x, kernel_size=(1, 1))            # Cnn14_16k block 6, :938
         x = _dropout(x, 0.2, training, masks, record)
     x = torch.mean(x, dim=3)                                   # :691  [N,512,S]
     x1 = torch.max(x, dim=2).values                            # :693 (unmasked)
     x2 = torch.mean(x, dim=2)
     out = _dropout(x1 + x2, 0.5, training, masks, record)
-    out = F.relu(F.linear(out, state[prefix + ".embed_pooled.weight"], state[prefix + ".embed_pooled.bias"]))
+    head = f"{prefix}.{arch['head']}"
+    out = F.relu(F.linear(out, state[head + ".weight"], state[head + ".bias"]))
     emb = _dropout(out, 0.5, training, masks, record)
     return {"audio_embeds": x.transpose(1, 2).contiguous(), "audio_embeds_pooled": emb,
             "state": None, "audio_embeds_lens": lens}

@@ -182,10 +182,10 @@ OUT_KEYS = ("logits", "outputs", "seqs", "sampled_logprobs", "attn_weights", "p_
             "q_means", "q_logs", "q_z", "q_means_utt", "p_means_utt")
 
 
-def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True, keep_noise=True):
-    shapes = O.state_shapes(V, E, E, None, E, 512)
+def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True, keep_noise=True, encoder="Cnn10"):
+    shapes = O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder)
     state = O.closed_form_state(shapes)
-    model = ref_shim.build_reference_model(ref, V, E, E)
+    model = ref_shim.build_reference_model(ref, V, E, E, encoder=encoder)
     load_state_into(model, state)
     model.train()
     feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, T, V, L, seed=seed, ragged=ragged)
@@ -300,6 +300,47 @@ def g11_dbs(ref):
          **out)
 
 
+def g12_cnn14(ref):
+    """N4: Cnn14_16k.forward (models/encoder.py:906-964), train mode (batch-stat BN, 8 dropout sites, running-stat
+    update) and eval mode, tiny T; the oracle restatement is checked against it on the way."""
+    out = {}
+    shapes = {k: v for k, v in O.state_shapes(10, enc_embed=2048, encoder="Cnn14_16k").items() if k.startswith("encoder.")}
+    full = O.closed_form_state(shapes)
+    st = {k[len("encoder."):]: full[k].clone() for k in shapes}
+    for ci, (B, T) in enumerate([(2, 64), (3, 96)]):
+        m = ref.encoder.Cnn14_16k(64, 2048)
+        m.load_state_dict(st)
+        g = torch.Generator().manual_seed(124 + ci)
+        feats = torch.randn(B, T, 64, generator=g) * 2 + 0.5
+        lens = np.array([T] + [int(T * 0.7)] * (B - 1))
+        m.train()
+        torch.manual_seed(60 + ci)
+        with torch.no_grad():
+            r = m(feats, lens.copy())
+        ost = {k: full[k].clone() for k in shapes}
+        rec = []
+        torch.manual_seed(60 + ci)
+        with torch.no_grad():
+            o = O.cnn10_forward(ost, feats, lens.copy(), True, None, rec)
+        assert (r["audio_embeds"] - o["audio_embeds"]).abs().max() < 1e-5
+        assert (r["audio_embeds_pooled"] - o["audio_embeds_pooled"]).abs().max() < 1e-5
+        assert len(rec) == 8 and torch.equal(r["audio_embeds_lens"], o["audio_embeds_lens"])
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        out.update({f"c{ci}_feats": feats, f"c{ci}_lens": lens, f"c{ci}_train_audio_embeds": r["audio_embeds"],
+                    f"c{ci}_train_pooled": r["audio_embeds_pooled"], f"c{ci}_train_lens": r["audio_embeds_lens"],
+                    f"c{ci}_b6bn2_running_mean": sd["conv_block6.bn2.running_mean"],
+                    f"c{ci}_b6bn2_running_var": sd["conv_block6.bn2.running_var"],
+                    f"c{ci}_b5bn1_running_var": sd["conv_block5.bn1.running_var"]})
+        out.update({f"c{ci}_{k}": v for k, v in pack_masks(rec).items()})
+        m.load_state_dict(st)
+        m.eval()
+        with torch.no_grad():
+            r = m(feats, lens.copy())
+        out.update({f"c{ci}_eval_audio_embeds": r["audio_embeds"], f"c{ci}_eval_pooled": r["audio_embeds_pooled"]})
+    out["ncases"] = np.array(2)
+    save("g12_cnn14_encoder", **out)
+
+
 def g10_host():
     """Batch / evaluation contract, produced by the reference's own host code: collate_fn (caption_dataset.py:278-318)
     on a seeded ragged training batch and an evaluation batch, Vocabulary (build_vocab.py:9-28) pickled, and
@@ -344,8 +385,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dbs":
         g11_dbs(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "cnn14":
+        g12_cnn14(ref)
+        train_fixture(ref, "g13_train_step_cnn14", 2, 64, 40, 64, 6, True, 0, seed=36, keep_tensors=False,
+                      encoder="Cnn14_16k")
+        return
     g10_host()
     g11_dbs(ref)
+    g12_cnn14(ref)
+    train_fixture(ref, "g13_train_step_cnn14", 2, 64, 40, 64, 6, True, 0, seed=36, keep_tensors=False, encoder="Cnn14_16k")
     g1_attention(ref); g2_reparam_kl(ref); g3_ce(ref); g4_encoder(ref); g5_rnn(ref)
     train_fixture(ref, "g6_train_step", 4, 64, 50, 64, 8, True, 0, seed=6)
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)

@@ -67,10 +67,10 @@ def load_host_side():
     return types.SimpleNamespace(caption_dataset=cd, build_vocab=bv, base_runner=br)
 
 
-def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None):
+def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None, encoder="Cnn10"):
     """Hybrid_VAEModel(Cnn10, VAERNNBahdanauAttnDecoder, PosteriorRNN_hybrid, PriorRNN): the
     self-consistent combination of SURVEY F6, built the way runners/pytorch_runner_vae.py:33-73 does."""
-    encoder = ref.encoder.Cnn10(64, 512)
+    encoder = ref.encoder.Cnn10(64, 512) if encoder == "Cnn10" else ref.encoder.Cnn14_16k(64, 2048)
     decoder = ref.decoder.VAERNNBahdanauAttnDecoder(
         vocab_size=vocab, enc_mem_size=embed, embed_size=embed, hidden_size=hidden, dropout=0.0,
         num_layers=1, rnn_type="GRU", attn_size=hidden)

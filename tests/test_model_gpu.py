@@ -10,7 +10,7 @@ import torch
 
 import acvae_oracle as O
 from acvae_amd.decoder import VAERNNBahdanauAttnDecoder
-from acvae_amd.encoder import Cnn10
+from acvae_amd.encoder import Cnn10, Cnn14_16k
 from acvae_amd.train_util import LabelSmoothingLoss, MSELoss, Normal_kl_loss
 from acvae_amd.vae_model import Hybrid_VAEModel
 from conftest import load_golden, unpack_masks
@@ -28,8 +28,8 @@ def close(a, b, rtol=1e-4, atol=1e-5, what=""):
                            f"{int((~ok).sum())}/{ok.numel()} out of tolerance"
 
 
-def build_model(V, E, state=None):
-    enc = Cnn10(64, 512)
+def build_model(V, E, state=None, encoder="Cnn10"):
+    enc = Cnn10(64, 512) if encoder == "Cnn10" else Cnn14_16k(64, 2048)
     dec = VAERNNBahdanauAttnDecoder(vocab_size=V, enc_mem_size=E, embed_size=E, hidden_size=E, dropout=0.0,
                                     num_layers=1, rnn_type="GRU", attn_size=E)
     m = Hybrid_VAEModel(enc, dec, posterior_model="PosteriorRNN_hybrid", posterior_args={"hidden_size": E, "dropout": 0.0},
@@ -48,11 +48,11 @@ def hip_loss(out, caps, cap_lens, V, smoothing=0.1, kl_weight=0.5, alpha=1.0):
     return ce + kl_weight * kl + alpha * mse, ce, kl, mse
 
 
-def run_case(name, tensors, full_grads):
+def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=2e-4):
     g = load_golden(name)
     B, Tt, V, E, L = (int(x) for x in g["dims"])
     seed = int(g["seed"])
-    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder))
     feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, Tt, V, L, seed=seed, ragged=bool(int(g["ragged"])))
     dis = float(g["dis_ratio"])
     if "noise_eps_q" in g:
@@ -92,7 +92,7 @@ def run_case(name, tensors, full_grads):
                                                            noise=noise, record=rec, apply_update=False))
     if masks is None:
         masks, eps_q, eps_p = rec["dropout"], rec["eps_q"], rec["eps_p"]
-    model = build_model(V, E, state)
+    model = build_model(V, E, state, encoder)
     model.train()
     model.encoder.dropout_masks = masks
     model.noise = dict(eps_q=eps_q, eps_p=eps_p)
@@ -110,7 +110,7 @@ def run_case(name, tensors, full_grads):
     loss.backward()
     named = dict(model.named_parameters())
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None))
-    assert abs(float(gn) - float(g["grad_norm"])) <= 2e-4 * float(g["grad_norm"]), (float(gn), float(g["grad_norm"]))
+    assert abs(float(gn) - float(g["grad_norm"])) <= gn_tol * float(g["grad_norm"]), (float(gn), float(g["grad_norm"]))
     if tensors:
         for k in [k for k in g if k.startswith("grad_") and k != "grad_norm"]:
             ref = T(g[k])
@@ -131,6 +131,12 @@ def test_g6b_train_step_prior_z_golden():
 
 def test_g6c_train_step_e512_golden():
     run_case("g6c_train_step_e512", tensors=False, full_grads=True)
+
+
+def test_g13_train_step_cnn14_with_ln_golden():
+    """N4: Cnn14_16k encoder + the ln 2048 -> E projection through the whole training step (loss triplet and gradient
+    norm pinned by the reference; blocks 5/6 normalise over 16 / 8 values at this size, hence the looser norm bound)."""
+    run_case("g13_train_step_cnn14", tensors=False, full_grads=False, encoder="Cnn14_16k", gn_tol=2e-3)
 
 
 def test_g8_config1_scalars_golden():

@@ -85,10 +85,10 @@ def test_g5_rnn():
         close(q[k], g[k])
 
 
-def _train_case(name, tensors=True):
+def _train_case(name, tensors=True, encoder="Cnn10", gn_tol=1e-4):
     g = load_golden(name)
     B, Tt, V, E, L = (int(x) for x in g["dims"])
-    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder))
     seed = int(g["seed"])
     feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, Tt, V, L, seed=seed, ragged=bool(int(g["ragged"])))
     assert np.array_equal(cap_lens, g["cap_lens"]) and np.array_equal(feat_lens, g["feat_lens"])
@@ -100,7 +100,7 @@ def _train_case(name, tensors=True):
     res = O.OracleTrainer(state, V).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, float(g["dis_ratio"]), noise=noise)
     for k in ("loss", "ce", "kl", "mse"):
         assert abs(float(res[k]) - float(g[k])) <= 1e-4 * max(1.0, abs(float(g[k]))), (k, float(res[k]), float(g[k]))
-    assert abs(float(res["grad_norm"]) - float(g["grad_norm"])) <= 1e-4 * float(g["grad_norm"])
+    assert abs(float(res["grad_norm"]) - float(g["grad_norm"])) <= gn_tol * float(g["grad_norm"])
     if tensors:
         out = res["out"]
         assert np.array_equal(out["seqs"].numpy(), g["out_seqs"])
@@ -119,6 +119,33 @@ def test_g6_train_step():
 
 def test_g6c_train_step_e512():
     _train_case("g6c_train_step_e512", tensors=False)
+
+
+def test_g12_cnn14_encoder():
+    """N4: Cnn14_16k.forward (models/encoder.py:906-964) against the reference's own outputs."""
+    g = load_golden("g12_cnn14_encoder")
+    shapes = {k: v for k, v in O.state_shapes(10, enc_embed=2048, encoder="Cnn14_16k").items() if k.startswith("encoder.")}
+    full = O.closed_form_state(shapes)
+    for ci in range(int(g["ncases"])):
+        st = {k: v.clone() for k, v in full.items()}
+        masks = unpack_masks(g, f"c{ci}_")
+        assert len(masks) == 8
+        lens = g[f"c{ci}_lens"].copy()
+        o = O.cnn10_forward(st, T(g[f"c{ci}_feats"]), lens, True, list(masks), None)
+        close(o["audio_embeds"], g[f"c{ci}_train_audio_embeds"]); close(o["audio_embeds_pooled"], g[f"c{ci}_train_pooled"])
+        assert o["audio_embeds"].shape[1:] == (g[f"c{ci}_feats"].shape[1] // 32, 2048)
+        assert np.array_equal(lens, g[f"c{ci}_train_lens"])          # in-place //= 32 on the caller's array
+        close(st["encoder.conv_block6.bn2.running_mean"], g[f"c{ci}_b6bn2_running_mean"])
+        close(st["encoder.conv_block6.bn2.running_var"], g[f"c{ci}_b6bn2_running_var"])
+        close(st["encoder.conv_block5.bn1.running_var"], g[f"c{ci}_b5bn1_running_var"])
+        st = {k: v.clone() for k, v in full.items()}
+        o = O.cnn10_forward(st, T(g[f"c{ci}_feats"]), g[f"c{ci}_lens"].copy(), False)
+        close(o["audio_embeds"], g[f"c{ci}_eval_audio_embeds"]); close(o["audio_embeds_pooled"], g[f"c{ci}_eval_pooled"])
+
+
+def test_g13_train_step_cnn14_with_ln():
+    # blocks 5/6 normalise over 16 / 8 values at this size: the gradient norm is more sensitive to summation order
+    _train_case("g13_train_step_cnn14", tensors=False, encoder="Cnn14_16k", gn_tol=1e-3)
 
 
 def test_g7_decode_token_exact():
