@@ -152,8 +152,7 @@ struct ConvStatsEpilogue {
             const int m = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float v = acc[i][j][r];
             if (m < M && n < N) Y[(long)m * Cout + n] = v;
-            s += v;          // rows >= M were staged as zeros -> contribute 0
-            q += v * v;
+            if (m < M) { s += v; q += v * v; }   // tile rows past the last pixel may hold a neighbour's shifted data
           }
         if (partials) {
           s += __shfl_xor(s, 32, 64);
@@ -179,6 +178,197 @@ struct ConvStatsEpilogue {
     }
   }
 };
+
+// ------------------------------------------------------------------ conv3x3 NT block with horizontal-tap reuse
+// The A tile of tap (dy, dx) is the A tile of tap (dy, 0) shifted by dx pixels, so one staged strip of
+// CV_ROWS = 128 + 2 pixel rows (pixels row0-1 .. row0+128 of the flattened image, at vertical offset dy) serves the
+// three horizontal taps: the matrix waves read it at row offsets 0 / 1 / 2 and zero the lanes whose pixel would step
+// over the left / right image border.  A-operand global loads drop to a third (they cost 14 % of the kernel's time
+// when measured alone, tools/ablate.sh); the weight panel of each tap still streams through its own two-deep ring.
+// K order: dy (3) x 32-channel chunk (C/32) x dx (3); weights stay in the (tap, ci)-major layout of repack_fwd.
+constexpr int CV_BMT = 128;
+constexpr int CV_ROWS = CV_BMT + 2;
+constexpr int CV_AR = 5;            // float4 slots per loader thread for the strip: 4 full passes + rows 128, 129
+template <int BN>
+struct alignas(16) ConvSmem {
+  alignas(16) float a[2][(CV_ROWS + 2) * LDS_LD];
+  alignas(16) float b[2][BN * LDS_LD];
+};
+
+struct ConvStripLoader {   // strip row j <-> pixel q = row0 - 1 + j, read at vertical tap offset dy
+  const float* X;
+  const float* scale;  // nullable: act = identity
+  const float* shift;
+  int H, W, C, M;
+  int qh[CV_AR];
+  long qbase[CV_AR];
+  int cq;
+  __device__ __forceinline__ void init(int row0, int lt) {
+    cq = (lt % KT) * 4;
+#pragma unroll
+    for (int j = 0; j < CV_AR; ++j) {
+      const int r = (lt / KT) + RPP * j;                 // strip row; slot 4 exists only for rows 128, 129
+      const long q = (long)row0 - 1 + r;
+      const bool live = r < CV_ROWS && q >= 0 && q < M;
+      qh[j] = live ? (int)((q / W) % H) : -100000;
+      qbase[j] = live ? q * C : 0;
+    }
+  }
+  // group = (dy index, 32-channel chunk)
+  __device__ __forceinline__ void issue(int dyi, int chunk, Pending<CV_AR>& p) const {
+    const int ci = chunk * BK + cq;
+    const int dy = dyi - 1;
+    const long off = (long)dy * W * C + ci;
+    if (scale) {
+      p.sc = *reinterpret_cast<const float4*>(scale + ci);
+      p.sh = *reinterpret_cast<const float4*>(shift + ci);
+    }
+    p.mask = 0;
+#pragma unroll
+    for (int j = 0; j < CV_AR; ++j) {
+      const int hh = qh[j] + dy;
+      const bool ok = hh >= 0 && hh < H;
+      p.v[j] = *reinterpret_cast<const float4*>(ok ? X + qbase[j] + off : X);   // always a legal address
+      p.mask |= (ok ? 1u : 0u) << j;
+    }
+  }
+  __device__ __forceinline__ void finish(Pending<CV_AR>& p) const {
+#pragma unroll
+    for (int j = 0; j < CV_AR; ++j) {
+      float4 v = p.v[j];
+      if (scale) {
+        v.x = fmaxf(v.x * p.sc.x + p.sh.x, 0.f); v.y = fmaxf(v.y * p.sc.y + p.sh.y, 0.f);
+        v.z = fmaxf(v.z * p.sc.z + p.sh.z, 0.f); v.w = fmaxf(v.w * p.sc.w + p.sh.w, 0.f);
+      }
+      p.v[j] = ((p.mask >> j) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+};
+
+template <int BN, class Epilogue>
+__device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<true, BN / 32> bl, int M, int N, int C,
+                                              int W, int block_m, int block_n, const Epilogue& ep, ConvSmem<BN>& sm) {
+  constexpr int NTN = BN / 64;     // MFMA tiles per matrix wave along N
+  constexpr int NMW = CV_BMT / 32; // matrix wavefronts (2 x 2)
+  constexpr int BR = BN / RPP;     // B rows per loader thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool matrix_wave = wave < NMW;
+  const int wm = (wave >> 1) % (CV_BMT / 64), wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int row0 = block_m * CV_BMT, col0 = block_n * BN;
+  const int nchunk = C / BK;
+  const int ngrp = 3 * nchunk;      // (dy, chunk) groups, three horizontal taps each
+
+  f32x16 acc[2][NTN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (!matrix_wave) {
+    // ------------------------------------------------------------------ loader wavefronts
+    const int lt = tid - NMW * 64;
+    const int srow = lt / KT, scol = (lt % KT) * 4;
+    Pending<CV_AR> pa;
+    Pending<BR> pb;
+    al.init(row0, lt);
+    bl.init(col0, lt);
+    auto put_a = [&](int buf) {
+      al.finish(pa);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&sm.a[buf][(srow + RPP * j) * LDS_LD + scol]) = pa.v[j];
+      if (srow < CV_ROWS - 4 * RPP) *reinterpret_cast<float4*>(&sm.a[buf][(srow + RPP * 4) * LDS_LD + scol]) = pa.v[4];
+    };
+    auto put_b = [&](int buf) {
+      bl.finish(pb);
+#pragma unroll
+      for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + RPP * j) * LDS_LD + scol]) = pb.v[j];
+    };
+    // weight K-step of sub-stage (grp, dxi): tap = dyi*3 + dxi, channels chunk*32..
+    auto kstep_of = [&](int grp, int dxi) { const int dyi = grp / nchunk; return (dyi * 3 + dxi) * nchunk + (grp - dyi * nchunk); };
+    al.issue(0, 0, pa);
+    bl.issue(col0, kstep_of(0, 0), lt, pb);
+    put_a(0);
+    put_b(0);
+    __syncthreads();
+    for (int grp = 0; grp < ngrp; ++grp) {
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+        const int s = grp * 3 + dxi;
+        const int g1 = grp + 1;
+        if (dxi == 0 && g1 < ngrp) {           // the next strip's loads fly for three sub-stages
+          const int dyi = g1 / nchunk;
+          al.issue(dyi, g1 - dyi * nchunk, pa);
+        }
+        if (dxi < 2) {
+          bl.issue(col0, kstep_of(grp, dxi + 1), lt, pb);
+          put_b((s + 1) & 1);
+        } else if (g1 < ngrp) {
+          bl.issue(col0, kstep_of(g1, 0), lt, pb);
+          put_a(g1 & 1);
+          put_b((s + 1) & 1);
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ matrix wavefronts
+    // border masks of this lane's two tile rows: pixel p = row0 + wm*64 + i*32 + li
+    bool okl[2], okr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int w = (row0 + wm * 64 + i * 32 + li) % W;
+      okl[i] = w > 0; okr[i] = w < W - 1;
+    }
+    __syncthreads();
+    for (int grp = 0; grp < ngrp; ++grp) {
+      const float* Ag = sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh;
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+        const float* As = Ag + dxi * LDS_LD;           // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
+        const float* Bs = sm.b[(grp * 3 + dxi) & 1] + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+          float4 af[2], bf[NTN];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            af[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
+            if (dxi == 0 && !okl[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dxi == 2 && !okr[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < NTN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // every wave is past the last LDS access (barrier above): LDS is free for the epilogue
+  ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], matrix_wave);
+}
+
+template <int BN>
+__global__ __launch_bounds__(nt_threads<CV_BMT>(), 2) void conv_igemm3_kernel(ConvStripLoader al,
+                                                                              const float* __restrict__ Wp,
+                                                                              ConvStatsEpilogue ep, int M, int Cout,
+                                                                              int K) {
+  __shared__ ConvSmem<BN> sm;
+  PlainLoader<true, BN / 32> bl{Wp, K, Cout, K};
+  int bm, bn;
+  xcd_tile(gridDim.x, gridDim.y, bm, bn);
+  conv_nt_block<BN>(al, bl, M, Cout, al.C, al.W, bm, bn, ep, sm);
+}
 
 // BMT x BN tile; the A operand (im2col rows) carries the previous layer's BatchNorm+ReLU when al.scale != nullptr.
 template <int BMT, int BN>
@@ -772,15 +962,27 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
   if (Cin % 32 != 0 || Cout % 4 != 0) return ACVAE_EUNSUPPORTED;
   if (!aligned16(X) || !aligned16(Wp) || !aligned16(Y)) return ACVAE_EALIGN;
   const int M = N * H * W, K = 9 * Cin;
-  ConvRowLoader<CONV_BMT / 32> al{X, scale, shift, H, W, Cin, M};
   ConvStatsEpilogue ep{Y, partials, Cout};
+  static const bool strip = !(getenv("ACVAE_CONV_STRIP") && getenv("ACVAE_CONV_STRIP")[0] == '0');   // A/B switch
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
-  if (Cout <= 64) {
-    dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 64));
-    hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 64>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+  if (strip) {
+    ConvStripLoader al{X, scale, shift, H, W, Cin, M};
+    if (Cout <= 64) {
+      dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, 64));
+      hipLaunchKernelGGL((conv_igemm3_kernel<64>), grid, dim3(nt_threads<CV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+    } else {
+      dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, 128));
+      hipLaunchKernelGGL((conv_igemm3_kernel<128>), grid, dim3(nt_threads<CV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+    }
   } else {
-    dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 128));
-    hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 128>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+    ConvRowLoader<CONV_BMT / 32> al{X, scale, shift, H, W, Cin, M};
+    if (Cout <= 64) {
+      dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 64));
+      hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 64>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+    } else {
+      dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 128));
+      hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 128>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+    }
   }
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();

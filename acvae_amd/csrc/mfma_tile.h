@@ -187,6 +187,7 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
 #pragma unroll
       for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + RPP * j) * LDS_LD + scol]) = pb.v[j];
     };
+#ifndef ACVAE_ABL
     al.issue(row0, 0, lt, pa);
     bl.issue(col0, 0, lt, pb);
     stash(0);
@@ -199,6 +200,32 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
       }
       __syncthreads();
     }
+#else
+    // dev-only ablations of the operand fetch path (tools/ablate.sh); results are wrong by construction
+    //  1: no global loads, LDS stores kept   2: loads issued, LDS stores skipped   3: neither
+    //  4: only the B (weight) loads          5: only the A (activation) loads
+    auto fake = [&](auto& p) {
+#pragma unroll
+      for (int j = 0; j < (int)(sizeof(p.v) / sizeof(p.v[0])); ++j) p.v[j] = make_float4(1.f, 2.f, 3.f, 4.f);
+      p.mask = 0xffffffffu; p.sc = make_float4(1.f, 1.f, 1.f, 1.f); p.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto keep = [&](auto& p) {
+#pragma unroll
+      for (int j = 0; j < (int)(sizeof(p.v) / sizeof(p.v[0])); ++j) asm volatile("" ::"v"(p.v[j].x), "v"(p.v[j].w));
+    };
+    auto step = [&](int ks) {
+      if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 4) fake(pa); else al.issue(row0, ks, lt, pa);
+      if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 5) fake(pb); else bl.issue(col0, ks, lt, pb);
+      if (ACVAE_ABL == 2) { keep(pa); keep(pb); }
+      else if (ACVAE_ABL != 3) stash(ks & 1);
+    };
+    step(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+      if (ks + 1 < nk) step(ks + 1);
+      __syncthreads();
+    }
+#endif
   } else {
     // ------------------------------------------------------------------ matrix wavefronts
     __syncthreads();

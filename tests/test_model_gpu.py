@@ -48,6 +48,26 @@ def hip_loss(out, caps, cap_lens, V, smoothing=0.1, kl_weight=0.5, alpha=1.0):
     return ce + kl_weight * kl + alpha * mse, ce, kl, mse
 
 
+def close_enc_grad(a, b, what=""):
+    """Encoder gradients: tight unless a ReLU-boundary flip sits upstream (tests/test_encoder_gpu.py explains): one mask
+    bit that differs between the MFMA and the CPU summation order moves every encoder gradient below it by up to ~1 %.
+    Median error <= 0.2 % of max and relative L2 <= 2 %."""
+    a = torch.as_tensor(a).detach().cpu().double(); b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    mx = max(float(b.abs().max()), 1e-6)
+    l2 = float(err.pow(2).sum().sqrt() / max(float(b.pow(2).sum().sqrt()), 1e-12))
+    assert float(err.median()) <= 2e-3 * mx and l2 <= 2e-2, \
+        f"{what}: median {float(err.median()):.2e} max {float(err.max()):.2e} (ref max {mx:.2e}) rel-L2 {l2:.2e}"
+
+
+def close_grad_of(name, a, ref, what):
+    if name.startswith("encoder."):
+        close_enc_grad(a, ref, what)
+    else:
+        close(a, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-3), what=what)
+
+
 def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=2e-4):
     g = load_golden(name)
     B, Tt, V, E, L = (int(x) for x in g["dims"])
@@ -113,11 +133,10 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=2e-4):
     assert abs(float(gn) - float(g["grad_norm"])) <= gn_tol * float(g["grad_norm"]), (float(gn), float(g["grad_norm"]))
     if tensors:
         for k in [k for k in g if k.startswith("grad_") and k != "grad_norm"]:
-            ref = T(g[k])
-            close(named[k[5:]].grad, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-3), what=k)
+            close_grad_of(k[5:], named[k[5:]].grad, T(g[k]), k)
     if full_grads:
         for k, ref in ores["grads"].items():
-            close(named[k].grad, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-3), what="oracle grad " + k)
+            close_grad_of(k, named[k].grad, ref, "oracle grad " + k)
         assert set(k for k, p in named.items() if p.grad is not None) == set(ores["grads"])
 
 
