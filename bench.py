@@ -184,7 +184,7 @@ def main():
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}" if n_gpus > 1 else "single",
                        "frames_per_s": frames_per_s, "audio_s_per_s": frames_per_s * HOP_S, "hop_s_assumed": HOP_S,
                        "loss_last_step": loss},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (conv3x3 implicit GEMM fwd+dgrad, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm3_kernel (conv3x3 implicit GEMM fwd+dgrad with horizontal-tap reuse, fp32 MFMA)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,

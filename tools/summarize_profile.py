@@ -34,7 +34,7 @@ def counter(sub, name):
             if r["Counter_Name"] != name:
                 continue
             k = r["Kernel_Name"]
-            short = ("conv_igemm" if "conv_igemm_kernel" in k else "conv_wgrad" if "conv_wgrad_kernel" in k else None)
+            short = ("conv_igemm" if "conv_igemm" in k else "conv_wgrad" if "conv_wgrad" in k else None)
             if short:
                 per[short].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
@@ -52,7 +52,7 @@ for k in ("conv_igemm", "conv_wgrad"):
     res[k] = {"dispatches_averaged": nf, "FETCH_SIZE_KB_avg_raw": f, "WRITE_SIZE_KB_avg": w,
               "fetch_bytes_per_launch": 2 * f * 1024, "write_bytes_per_launch": w * 1024,
               "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
-res["kernel"] = "conv_igemm_kernel<128|64> (conv3x3 implicit GEMM, forward + data gradient)"
+res["kernel"] = "conv_igemm3_kernel<128|64> (conv3x3 implicit GEMM with horizontal-tap reuse, forward + data gradient)"
 res["hbm_bytes_per_launch"] = res["conv_igemm"]["hbm_bytes_per_launch"]
 res["algorithmic_bytes_per_launch"] = ("one read of the conv input + one write of its output + the weights, averaged "
                                        "over the 14 launches of a step: ~0.29 GB")
