@@ -245,7 +245,11 @@ struct ConvStripLoader {   // strip row j <-> pixel q = row0 - 1 + j, read at ve
   }
 };
 
-template <int BN, class Epilogue>
+// BDMA: the weight panel goes global -> LDS by LDS-DMA (no register round trip): the LDS image of a panel is then
+// lane-linear, [BN rows][32 floats] unpadded, and the bank spread comes from an XOR swizzle of the 16-byte chunk index
+// with the row (chunk c of row r sits at position c ^ (r & 7)), applied on the SOURCE address by the loader and on the
+// read address by the matrix waves.  Needs N % BN == 0 (an LDS-DMA cannot zero-fill).
+template <int BN, bool BDMA, class Epilogue>
 __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<true, BN / 32> bl, int M, int N, int C,
                                               int W, int block_m, int block_n, const Epilogue& ep, ConvSmem<BN>& sm) {
   constexpr int NTN = BN / 64;     // MFMA tiles per matrix wave along N
@@ -282,14 +286,27 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
       if (srow < CV_ROWS - 4 * RPP) *reinterpret_cast<float4*>(&sm.a[buf][(srow + RPP * 4) * LDS_LD + scol]) = pa.v[4];
     };
     auto put_b = [&](int buf) {
+      if (BDMA) return;
       bl.finish(pb);
 #pragma unroll
       for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + RPP * j) * LDS_LD + scol]) = pb.v[j];
     };
+    // one LDS-DMA instruction = 8 rows x 128 B: wave lw takes the row groups lw, lw+4, ...
+    auto fetch_b = [&](int buf, int kstep) {
+      if (!BDMA) { bl.issue(col0, kstep, lt, pb); return; }
+      const int lw = lt >> 6, l = lt & 63;
+      const int chunk = (l & 7) ^ (l >> 3);
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        const int rg = lw + 4 * j;
+        const float* src = bl.base + (long)(col0 + rg * 8 + (l >> 3)) * bl.ld + kstep * BK + chunk * 4;
+        __builtin_amdgcn_global_load_lds(src, &sm.b[buf][rg * 8 * BK], 16, 0, 0);
+      }
+    };
     // weight K-step of sub-stage (grp, dxi): tap = dyi*3 + dxi, channels chunk*32..
     auto kstep_of = [&](int grp, int dxi) { const int dyi = grp / nchunk; return (dyi * 3 + dxi) * nchunk + (grp - dyi * nchunk); };
     al.issue(0, 0, pa);
-    bl.issue(col0, kstep_of(0, 0), lt, pb);
+    fetch_b(0, kstep_of(0, 0));
     put_a(0);
     put_b(0);
     __syncthreads();
@@ -303,10 +320,10 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
           al.issue(dyi, g1 - dyi * nchunk, pa);
         }
         if (dxi < 2) {
-          bl.issue(col0, kstep_of(grp, dxi + 1), lt, pb);
+          fetch_b((s + 1) & 1, kstep_of(grp, dxi + 1));
           put_b((s + 1) & 1);
         } else if (g1 < ngrp) {
-          bl.issue(col0, kstep_of(g1, 0), lt, pb);
+          fetch_b((s + 1) & 1, kstep_of(g1, 0));
           put_a(g1 & 1);
           put_b((s + 1) & 1);
         }
@@ -328,7 +345,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
 #pragma unroll
       for (int dxi = 0; dxi < 3; ++dxi) {
         const float* As = Ag + dxi * LDS_LD;           // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
-        const float* Bs = sm.b[(grp * 3 + dxi) & 1] + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+        const float* Bs = sm.b[(grp * 3 + dxi) & 1] + (wn * (BN / 2) + li) * (BDMA ? BK : LDS_LD) + (BDMA ? 0 : 4 * lh);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
           float4 af[2], bf[NTN];
@@ -339,7 +356,9 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
             if (dxi == 2 && !okr[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
-          for (int j = 0; j < NTN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
+          for (int j = 0; j < NTN; ++j)
+            bf[j] = BDMA ? *reinterpret_cast<const float4*>(Bs + j * 32 * BK + (((g * 2 + lh) ^ (li & 7)) << 2))
+                         : *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -358,7 +377,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
   ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], matrix_wave);
 }
 
-template <int BN>
+template <int BN, bool BDMA>
 __global__ __launch_bounds__(nt_threads<CV_BMT>(), 2) void conv_igemm3_kernel(ConvStripLoader al,
                                                                               const float* __restrict__ Wp,
                                                                               ConvStatsEpilogue ep, int M, int Cout,
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(nt_threads<CV_BMT>(), 2) void conv_igemm3_kernel(Co
   PlainLoader<true, BN / 32> bl{Wp, K, Cout, K};
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  conv_nt_block<BN>(al, bl, M, Cout, al.C, al.W, bm, bn, ep, sm);
+  conv_nt_block<BN, BDMA>(al, bl, M, Cout, al.C, al.W, bm, bn, ep, sm);
 }
 
 // BMT x BN tile; the A operand (im2col rows) carries the previous layer's BatchNorm+ReLU when al.scale != nullptr.
@@ -963,16 +982,20 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
   if (!aligned16(X) || !aligned16(Wp) || !aligned16(Y)) return ACVAE_EALIGN;
   const int M = N * H * W, K = 9 * Cin;
   ConvStatsEpilogue ep{Y, partials, Cout};
-  static const bool strip = !(getenv("ACVAE_CONV_STRIP") && getenv("ACVAE_CONV_STRIP")[0] == '0');   // A/B switch
+  // A/B switch: 0 = one tap per stage (conv_igemm_kernel), 1 = strip kernel, 2 = strip kernel + weight panels by LDS-DMA
+  static const int strip = getenv("ACVAE_CONV_STRIP") ? atoi(getenv("ACVAE_CONV_STRIP")) : 2;
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
   if (strip) {
     ConvStripLoader al{X, scale, shift, H, W, Cin, M};
-    if (Cout <= 64) {
-      dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, 64));
-      hipLaunchKernelGGL((conv_igemm3_kernel<64>), grid, dim3(nt_threads<CV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+    const int bn = Cout <= 64 ? 64 : 128;
+    const dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, bn)), block(nt_threads<CV_BMT>());
+    const bool dma = strip == 2 && Cout % bn == 0;
+    if (bn == 64) {
+      if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<64, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+      else hipLaunchKernelGGL((conv_igemm3_kernel<64, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
     } else {
-      dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, 128));
-      hipLaunchKernelGGL((conv_igemm3_kernel<128>), grid, dim3(nt_threads<CV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
+      if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<128, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+      else hipLaunchKernelGGL((conv_igemm3_kernel<128, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
     }
   } else {
     ConvRowLoader<CONV_BMT / 32> al{X, scale, shift, H, W, Cin, M};
