@@ -77,11 +77,20 @@ struct ConvRowLoader {  // NT A-operand: tile rows = output pixels (NR per loade
   }
 };
 
+// x / d for 0 <= x < 2^40 / d by one 64-bit multiply (mul = ceil(2^40 / d)): the pixel -> (row, column) split of the
+// weight-gradient loader runs every K-step, where two integer divisions cost more issue slots than the loads they feed
+struct FastDiv {
+  unsigned long long mul;
+  static FastDiv make(int d) { return FastDiv{((1ULL << 40) + (unsigned long long)d - 1) / (unsigned long long)d}; }
+  __device__ __forceinline__ int div(int x) const { return (int)(((unsigned long long)(unsigned)x * mul) >> 40); }
+};
+
 struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
   const float* X;
   const float* scale;
   const float* shift;
   int H, W, C, M, NC;  // NC = 9*C
+  FastDiv dW, dH;
   int dy, dx, ci;
   bool colok;
   float4 sc, sh;
@@ -108,7 +117,8 @@ struct ConvKMajorLoader {  // TN B-operand: k = pixel, n = (tap, ci)
       const int kr = threadIdx.x / TPR + it * RPI;
       const int px = k0 + kr;
       bool ok = colok && px < M && (EXACT || (threadIdx.x < RPI * TPR && kr < BKT));
-      const int w = px % W, h = (px / W) % H;
+      const int row = dW.div(px);
+      const int w = px - row * W, h = row - dH.div(row) * H;
       const int hh = h + dy, ww = w + dx;
       ok = ok && hh >= 0 && hh < H && ww >= 0 && ww < W;
       p.v[it] = *reinterpret_cast<const float4*>(ok ? X + ((long)px + dy * W + dx) * C + ci : X);
@@ -1037,7 +1047,8 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
   const int M = N * H * W, NC = 9 * Cin;
   const int s = wgrad_splits(M, Cout, NC);            // slices past the last pixel just write zero slabs
   const int k_per = cdiv(cdiv(M, s), BKT) * BKT;
-  ConvKMajorLoader bl{X, scale, shift, H, W, Cin, M, NC};
+  if ((long)(M + 4096) * (W > H ? W : H) >= (1L << 40)) return ACVAE_EUNSUPPORTED;   // FastDiv range
+  ConvKMajorLoader bl{X, scale, shift, H, W, Cin, M, NC, FastDiv::make(W), FastDiv::make(H)};
   prof_begin(ACVAE_PROF_CONV_WGRAD, st);
   if (wgrad_use192(NC)) {
     if (Cout <= 64) {

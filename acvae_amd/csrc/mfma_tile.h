@@ -369,17 +369,30 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
       *reinterpret_cast<float4*>(&sm.b[buf][k * TN_ + (tid % (TN_ / 4)) * 4]) = pb.v[it];
     }
   };
+#ifdef ACVAE_ABL
+  // dev-only ablations (tools/ablate.sh): 1/3 = no global loads, 4 = only B loads, 5 = only A loads
+  auto fake = [&](Pending<4>& p) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.v[j] = make_float4(1.f, 2.f, 3.f, 4.f);
+    p.mask = 0xffffffffu; p.sc = make_float4(1.f, 1.f, 1.f, 1.f); p.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+#define TN_ISSUE_A(k0_) do { if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 4) fake(pa); else al.template issue<TM>(row0, k0_, pa); } while (0)
+#define TN_ISSUE_B(k0_) do { if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 5) fake(pb); else bl.template issue<TN_>(col0, k0_, pb); } while (0)
+#else
+#define TN_ISSUE_A(k0_) al.template issue<TM>(row0, k0_, pa)
+#define TN_ISSUE_B(k0_) bl.template issue<TN_>(col0, k0_, pb)
+#endif
   if (nk > 0) {
-    al.template issue<TM>(row0, k_begin, pa);
-    bl.template issue<TN_>(col0, k_begin, pb);
+    TN_ISSUE_A(k_begin);
+    TN_ISSUE_B(k_begin);
     stash(0);
   }
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < nk) {
-      al.template issue<TM>(row0, k_begin + (ks + 1) * BKT, pa);
-      bl.template issue<TN_>(col0, k_begin + (ks + 1) * BKT, pb);
+      TN_ISSUE_A(k_begin + (ks + 1) * BKT);
+      TN_ISSUE_B(k_begin + (ks + 1) * BKT);
     }
     const float* As = sm.a[cur] + lh * TM + wm * 64 + 2 * li;
     const float* Bs = sm.b[cur] + lh * TN_ + wn * 64 + 2 * li;
@@ -415,6 +428,9 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
       }
     }
 }
+
+#undef TN_ISSUE_A
+#undef TN_ISSUE_B
 
 // Same pipeline with a free wave tile: 4 wavefronts as WM x WN, each EM x EN MFMA tiles (32 x 32), for operand widths
 // that the 64 x 64 wave tile covers badly (9*64 = 576 columns = 3 x 192).  Plain tile-to-lane map (one ds_read_b32 per

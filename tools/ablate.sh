@@ -23,6 +23,6 @@ else
     rm -rf /tmp/abl_tr
     ACVAE_DEV_LIB="$lib" rocprofv3 --kernel-trace -d /tmp/abl_tr -o t --output-format csv -- python3 "$ROOT/tools/bench_encoder.py" 32 1000 6 > /dev/null 2>&1 || true
     echo "== ablation $n"
-    python3 "$ROOT/tools/conv_kernels.py" /tmp/abl_tr/t_kernel_trace.csv | grep igemm | head -7
+    python3 "$ROOT/tools/conv_kernels.py" /tmp/abl_tr/t_kernel_trace.csv | grep -E "${ABL_GREP:-igemm}" | head -9
   done
 fi
