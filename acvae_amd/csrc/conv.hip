@@ -1030,11 +1030,16 @@ static int wgrad_splits(int M, int Cout, int NC) {
                                       : (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
   // 2 workgroups fit per CU -> 512 slots; aim just under 4 full rounds (a few blocks over a round boundary cost a
   // whole extra round: 1040 blocks ran 18 % slower than 2030), and keep the count a multiple of 8: one group of
-  // pixel slices per XCD (conv_wgrad_kernel)
-  int s = (int)(2048 / tiles) & ~7;
+  // pixel slices per XCD (conv_wgrad_kernel).  When that count leaves the last round less than 85 % full (many tiles:
+  // 144 tiles x 8 slices = 2.25 rounds), take the next counts up to 5 rounds and keep the fullest.
   const int maxs = cdiv(M, 16 * BKT) & ~7;
+  int s = (int)(2048 / tiles) & ~7;
   if (s > maxs) s = maxs;
   if (s < 8) s = 8;
+  auto eff = [&](int k) { const long b = tiles * k; return (double)b / (512.0 * (double)((b + 511) / 512)); };
+  if (eff(s) < 0.85)
+    for (int k = s + 8; k <= maxs && tiles * k <= 5 * 512; k += 8)
+      if (eff(k) > eff(s) + 0.02) s = k;
   return s;
 }
 long conv3x3_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout) {
