@@ -1025,22 +1025,28 @@ int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, CONV_
 
 static bool wgrad_use192(int NC) { return NC % 192 == 0 && NC % 128 != 0; }
 static int wgrad_splits(int M, int Cout, int NC) {
-  const bool narrow = Cout <= 64;
-  const long tiles = wgrad_use192(NC) ? (long)cdiv(Cout, narrow ? 64 : 128) * (NC / 192)
-                                      : (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
-  // 2 workgroups fit per CU -> 512 slots; aim just under 4 full rounds (a few blocks over a round boundary cost a
-  // whole extra round: 1040 blocks ran 18 % slower than 2030), and keep the count a multiple of 8: one group of
-  // pixel slices per XCD (conv_wgrad_kernel).  When that count leaves the last round less than 85 % full (many tiles:
-  // 144 tiles x 8 slices = 2.25 rounds), take the next counts up to 5 rounds and keep the fullest.
+  const bool narrow = Cout <= 64, w192 = wgrad_use192(NC);
+  const long tiles = w192 ? (long)cdiv(Cout, narrow ? 64 : 128) * (NC / 192)
+                          : (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
+  // Resident workgroups per CU of the kernel variant (256 threads; from the compiler's resource report: 120 / 111 VGPRs
+  // and 32 KB LDS -> 4, 165 / 134 VGPRs -> 3): the grid should fill whole rounds of 256 x that many slots, because a few
+  // blocks over a round boundary cost a whole extra round (1040 blocks ran 18 % slower than 2030).  The slice count is a
+  // multiple of 8 (one group of pixel slices per XCD, conv_wgrad_kernel); every slice adds one slab of Cout x NC floats
+  // that is written and then read by the reduce, so: minimise (MFMA time / fill of the last round) + slab traffic.
+  const long slots = 256L * ((w192 ? !narrow : narrow) ? 3 : 4);
   const int maxs = cdiv(M, 16 * BKT) & ~7;
-  int s = (int)(2048 / tiles) & ~7;
-  if (s > maxs) s = maxs;
-  if (s < 8) s = 8;
-  auto eff = [&](int k) { const long b = tiles * k; return (double)b / (512.0 * (double)((b + 511) / 512)); };
-  if (eff(s) < 0.85)
-    for (int k = s + 8; k <= maxs && tiles * k <= 5 * 512; k += 8)
-      if (eff(k) > eff(s) + 0.02) s = k;
-  return s;
+  const double t_mfma = 2.0 * (double)M * Cout * NC / 1.1e14;
+  const double t_slab = 2.0 * (double)Cout * NC * 4.0 / 0.67e12;   // measured: a slab costs ~6x its bytes / HBM rate
+  int best = 8;
+  double best_t = 1e30;
+  for (int k = 8; k <= (maxs < 8 ? 8 : maxs) && tiles * k <= 5 * slots; k += 8) {
+    const long b = tiles * k;
+    const double fill = (double)b / (double)(slots * ((b + slots - 1) / slots));
+    // under ~2 rounds there is nothing to balance slow blocks against: price a single round like a 3/4-full one
+    const double t = t_mfma / (2 * b < 3 * slots ? fill * 0.75 : fill) + k * t_slab;
+    if (t < best_t) { best_t = t; best = k; }
+  }
+  return best;
 }
 long conv3x3_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout) {
   return (long)wgrad_splits(N * H * W, Cout, 9 * Cin) * Cout * 9 * Cin;
