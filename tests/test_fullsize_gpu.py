@@ -127,3 +127,36 @@ def test_inference_n5_samples_config5():
         idx = (r == 2).nonzero()
         if len(idx):
             assert bool((r[int(idx[0]):] == 2).all())
+
+
+def test_loss_vs_oracle_at_config2_full_size():
+    """BASELINE configs[1] itself (B=32, T=1000, V=5000, E=512, 22-token captions): one forward + loss on the HIP path
+    against the oracle on the same weights, batch, dropout masks and noise — north_star's bar, |loss diff| <= 1e-4,
+    plus token ids exact; the gradient norm (through the whole backward) within 2e-4."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import acvae_oracle as O
+    from acvae_amd.train_util import LabelSmoothingLoss, MSELoss, Normal_kl_loss
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    model = build(5).train()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    feats, caps, fl, cl = O.synthetic_batch(32, 1000, V, L, seed=4, ragged=True)
+    rec = {}
+    torch.manual_seed(9); random.seed(9)
+    ores = O.OracleTrainer(state, V).step(feats, fl.copy(), caps, cl, 1.0, 0, record=rec, apply_update=False)
+    model.encoder.dropout_masks = rec["dropout"]
+    model.noise = dict(eps_q=rec["eps_q"], eps_p=rec["eps_p"])
+    random.seed(9)
+    out = model(feats.cuda(), fl.copy(), caps, cl, ss_ratio=1.0, dis_ratio=0)
+    lens1 = np.asarray(cl) - 1
+    ce = LabelSmoothingLoss(V, 0.1).masked(out["logits"], caps[:, 1:].to(torch.long), lens1)
+    kl = Normal_kl_loss()(out["q_means"], out["q_logs"], out["p_means"], out["p_logs"])
+    mse = MSELoss()(out["q_means_utt"], out["p_means_utt"])
+    loss = ce + 0.5 * kl + 1.0 * mse
+    for name, got, want in (("loss", loss, ores["loss"]), ("ce", ce, ores["ce"]), ("kl", kl, ores["kl"]), ("mse", mse, ores["mse"])):
+        got, want = float(got.detach()), float(want.detach())
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (name, got, want)
+    assert torch.equal(out["seqs"].cpu(), ores["out"]["seqs"])
+    loss.backward()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+    assert abs(float(gn) - float(ores["grad_norm"])) <= 2e-4 * float(ores["grad_norm"]), (float(gn), float(ores["grad_norm"]))
