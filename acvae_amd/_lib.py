@@ -111,10 +111,7 @@ class _PinnedRing:
         self.head = 0
         self.live = []           # (start, end, event) in allocation order
 
-    def stage(self, t, dev):
-        n = t.numel() * t.element_size()
-        if n == 0 or n > self.buf.numel() // 4:
-            return t.pin_memory().to(dev, non_blocking=True)
+    def _reserve(self, n):
         span = (n + 255) & ~255
         if self.head + span > self.buf.numel():
             self.head = 0
@@ -122,13 +119,35 @@ class _PinnedRing:
         self.head = e
         while self.live and self.live[0][0] < e and self.live[0][1] > s:
             self.live.pop(0)[2].synchronize()
-        slot = self.buf[s:s + n].view(t.dtype).view(t.shape)
-        np.copyto(slot.numpy(), t.numpy())       # plain memcpy: torch's copy_ fans a 1 MB copy out over the intra-op pool
+        return s, e
+
+    def _send(self, slot, s, e, dev):
         out = slot.to(dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         self.live.append((s, e, ev))
         return out
+
+    def stage(self, t, dev):
+        n = t.numel() * t.element_size()
+        if n == 0 or n > self.buf.numel() // 4:
+            return t.pin_memory().to(dev, non_blocking=True)
+        s, e = self._reserve(n)
+        slot = self.buf[s:s + n].view(t.dtype).view(t.shape)
+        np.copyto(slot.numpy(), t.numpy())       # plain memcpy: torch's copy_ fans a 1 MB copy out over the intra-op pool
+        return self._send(slot, s, e, dev)
+
+    def fill(self, shape, dtype, dev, fill):
+        """Reserve a slot, let ``fill(slot_tensor)`` produce the data in place (e.g. torch.randn(..., out=)), send it."""
+        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        if n == 0 or n > self.buf.numel() // 4:
+            t = torch.empty(shape, dtype=dtype)
+            fill(t)
+            return t.pin_memory().to(dev, non_blocking=True)
+        s, e = self._reserve(n)
+        slot = self.buf[s:s + n].view(dtype).view(shape)
+        fill(slot)
+        return self._send(slot, s, e, dev)
 
 
 _RINGS = {}
@@ -150,3 +169,15 @@ def h2d(t, dev, dtype=None):
     if ring is None:
         ring = _RINGS[key] = _PinnedRing()
     return ring.stage(t.contiguous(), dev)
+
+
+def h2d_fill(shape, dtype, dev, fill):
+    """Like h2d, but the host data is produced by ``fill(tensor)`` directly in the page-locked staging slot."""
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise RuntimeError("acvae_amd: the HIP path needs a GPU device (no CPU fallback)")
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ring = _RINGS.get(key)
+    if ring is None:
+        ring = _RINGS[key] = _PinnedRing()
+    return ring.fill(tuple(shape), dtype, dev, fill)

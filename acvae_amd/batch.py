@@ -76,6 +76,23 @@ def replicate_for_sampling(keys, feats, feat_lens, n):
     return keys, feats, feat_lens
 
 
+def forward_batch_shared_encoder(model, batch, device=None, **kwargs):
+    """Evaluation forward with N z-samples per clip that runs the encoder ONCE per clip: in evaluation mode (running
+    BatchNorm statistics, no dropout) the encoder output of a replica equals that of its clip bit for bit, so the
+    replicas share it and only the decode loop sees N rows per clip.  Same outputs as ``forward_batch(mode="eval")``
+    with the clip-major replication; ``batch[0]`` is replaced by the replicated keys likewise."""
+    n = kwargs["beam_size"]
+    assert not model.training and n > 1 and kwargs["method"] != "dbs"
+    device = device if device is not None else next(model.parameters()).device
+    encoded = model.encoder(batch[1].to(device), batch[-1])
+    batch[0] = [k for k in batch[0] for _ in range(n)]
+    lens = torch.as_tensor(encoded["audio_embeds_lens"]).repeat_interleave(n, dim=0)
+    rep = {"audio_embeds": encoded["audio_embeds"].repeat_interleave(n, dim=0),
+           "audio_embeds_pooled": encoded["audio_embeds_pooled"].repeat_interleave(n, dim=0),
+           "audio_embeds_lens": lens, "state": None}
+    return model.inference_forward(rep, **kwargs)
+
+
 def forward_batch(model, batch, mode, device=None, **kwargs):
     """Runner._forward (pytorch_runner_vae.py:76-108).  ``batch`` is what ``collate_fn`` returned.  In evaluation mode
     with beam_size > 1 and a method other than "dbs", ``batch[0]`` (the keys) is replaced by the replicated keys, as

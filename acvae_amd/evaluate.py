@@ -16,7 +16,7 @@ from pathlib import Path
 
 import torch
 
-from .batch import collate_fn, forward_batch
+from .batch import collate_fn, forward_batch, forward_batch_shared_encoder
 
 
 class Vocabulary(object):
@@ -119,7 +119,10 @@ def evaluate(model, items, vocabulary, caption_output=None, zh=False, batch_size
         batch = collate(list(pending))
         pending.clear()
         with torch.no_grad():
-            output = forward_batch(model, batch, "eval", device=device, **kwargs)
+            if kwargs["beam_size"] > 1 and kwargs["method"] != "dbs":     # N samples per clip: one encoder pass per clip
+                output = forward_batch_shared_encoder(model, batch, device=device, **kwargs)
+            else:
+                output = forward_batch(model, batch, "eval", device=device, **kwargs)
         collect_predictions(batch[0], output["seqs"].cpu().numpy(), vocabulary, zh, key2pred)
 
     for item in items:

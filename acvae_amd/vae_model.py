@@ -374,16 +374,23 @@ class Hybrid_VAEModel(CaptionModel):
             Tc = kwargs.get("max_length", self.max_length)
         replay = self.noise
         self.noise = None
-        ss_flags, dis_flags, eps_list = [], [], []
-        for t in range(Tc):
-            if train:
-                ss_flags.append(random.random() < ss_ratio)                    # :826
-            if replay is None or replay.get("eps_p") is None:
-                eps_list.append(torch.randn(N, E))                               # text_encoder.py:259 (CPU, F9)
-            if train:
-                dis_flags.append(bool(dis_ratio != 0 and torch.rand(1) <= dis_ratio))   # :802-806
-        eps_p = torch.stack(eps_list, 0) if eps_list else replay["eps_p"][:Tc]
-        eps_p = _lib.h2d(eps_p, dev, torch.float32).contiguous()
+        ss_flags, dis_flags = [], []
+        draw = replay is None or replay.get("eps_p") is None
+
+        def host_draws(eps):            # eps: [Tc, N, E] staging slot (None when the noise is replayed)
+            for t in range(Tc):
+                if train:
+                    ss_flags.append(random.random() < ss_ratio)                    # :826
+                if eps is not None:
+                    torch.randn(N, E, out=eps[t])                                    # text_encoder.py:259 (CPU, F9)
+                if train:
+                    dis_flags.append(bool(dis_ratio != 0 and torch.rand(1) <= dis_ratio))   # :802-806
+
+        if draw:
+            eps_p = _lib.h2d_fill((Tc, N, E), torch.float32, dev, host_draws)
+        else:
+            host_draws(None)
+            eps_p = _lib.h2d(replay["eps_p"][:Tc], dev, torch.float32).contiguous()
         caps_d = lens1_d = None
         if train:
             caps_d = _lib.h2d(caps, dev, torch.long).contiguous()
