@@ -294,11 +294,19 @@ __global__ __launch_bounds__(256) void dbs_scores_kernel(const float* __restrict
 // distinct values); one workgroup, k selection passes.  Also emits idx / V and idx % V.
 __global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict__ x, long n, int k, int V,
                                                          float* __restrict__ vals, int64_t* __restrict__ idx,
-                                                         int64_t* __restrict__ row, int64_t* __restrict__ col) {
+                                                         int64_t* __restrict__ row, int64_t* __restrict__ col,
+                                                         int row_base) {
   __shared__ float rv[16];
   __shared__ long ri[16];
   __shared__ float sel_v[16];
   __shared__ long sel_i[16];
+  // one workgroup per group (batched beam search: group = clip, x[g][n], outputs [g][k]); row_base offsets `row` so
+  // that it indexes the rows of the whole batch (g * row_base + idx / V)
+  x += (long)blockIdx.x * n;
+  vals += (long)blockIdx.x * k; idx += (long)blockIdx.x * k;
+  if (row) row += (long)blockIdx.x * k;
+  if (col) col += (long)blockIdx.x * k;
+  const long rbase = (long)blockIdx.x * row_base;
   for (int j = 0; j < k; ++j) {
     float bv = -INFINITY;
     long bi = 0x7fffffffffffffffL;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict
         if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
       sel_v[j] = bv; sel_i[j] = bi;
       vals[j] = bv; idx[j] = bi;
-      if (row) row[j] = bi / V;
+      if (row) row[j] = rbase + bi / V;
       if (col) col[j] = bi % V;
     }
     __syncthreads();
@@ -464,7 +472,16 @@ extern "C" int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* v
                                int64_t* col, void* stream) {
   if (!x || !vals || !idx || n <= 0 || k <= 0 || k > 16 || k > n || V <= 0) return ACVAE_EINVAL;
   hipLaunchKernelGGL(topk_flat_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, k, V, vals, idx, row,
-                     col);
+                     col, 0);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_topk_flat_batched(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx,
+                                       int64_t* row, int64_t* col, int groups, int row_base, void* stream) {
+  if (!x || !vals || !idx || n <= 0 || k <= 0 || k > 16 || k > n || V <= 0 || groups <= 0) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(topk_flat_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, x, (long)n, k, V, vals, idx,
+                     row, col, row_base);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

@@ -158,9 +158,9 @@ class Hybrid_VAEModel(CaptionModel):
 
     @torch.no_grad()
     def beam_search(self, encoded, max_length, beam_size):
-        """Validation beam search, models/vae_model.py:896-995: clip by clip, beams expanded over the flat
-        beam*V log-probabilities, states re-gathered by prev_word_inds; returns beam 0 (the reference never fills
-        done_beams, :986-995).  Host logic as in the reference; every tensor op is a library call."""
+        """Validation beam search, models/vae_model.py:896-995: beams expanded over the flat beam*V log-probabilities of
+        a clip, states re-gathered by prev_word_inds; returns beam 0 (the reference never fills done_beams, :986-995).
+        All clips advance together; no host synchronisation inside the loop."""
         mem_all = encoded["audio_embeds"].contiguous()
         dev = mem_all.device
         if hasattr(self, "ln"):                              # vae_model.py:754-755
@@ -171,47 +171,53 @@ class Hybrid_VAEModel(CaptionModel):
             mem_all = proj
         lens_all = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long)
         N, S, E = mem_all.shape
-        H, V = self.decoder.model.hidden_size, self.vocab_size
+        V = self.vocab_size
+        R = N * beam_size
         replay = self.noise.get("eps_beam") if self.noise is not None else None
         self.noise = None
-        seqs_out = torch.full((N, max_length), self.end_idx, dtype=torch.long, device=dev)
-        attn_out = torch.zeros(N, S, max_length, device=dev)
+        # The reference walks the clips one after the other; their searches are independent, so all N x beam rows advance
+        # together here: one prior / decoder step per time step for the whole batch, one top-k workgroup per clip, state
+        # gathers by batch-global parent row.  Its noise order (clip-major: text_encoder.py:259 inside the clip loop) is
+        # kept by drawing eps[clip][t] up front.
+        if replay is None:
+            eps_all = _lib.h2d_fill((N, max_length, beam_size, E), torch.float32, dev,
+                                    lambda buf: [torch.randn(beam_size, E, out=buf[i, t]) for i in range(N)
+                                                 for t in range(max_length)])
+        else:
+            eps_all = _lib.h2d(replay, dev, torch.float32)
+        mem = mem_all.repeat_interleave(beam_size, dim=0).contiguous()
+        lens = lens_all.repeat_interleave(beam_size)
+        state = self.decoder.init_hidden(R).to(dev)
+        hid = self.pnet.init_hidden(R, dev)
+        last_z = torch.zeros(R, E, device=dev)
+        top_k = torch.zeros(R, device=dev)
+        lse = torch.empty(R, device=dev)
+        scores = torch.empty(R, V, device=dev)
+        vals = torch.empty(R, device=dev)
+        idx, prev, nxt = (torch.empty(R, dtype=torch.long, device=dev) for _ in range(3))
         st = _lib.current_stream
-        for i in range(N):
-            mem = mem_all[i].unsqueeze(0).repeat(beam_size, 1, 1).contiguous()
-            lens = lens_all[i].repeat(beam_size)
-            state = self.decoder.init_hidden(beam_size).to(dev)
-            hid = self.pnet.init_hidden(beam_size, dev)
-            last_z = torch.zeros(beam_size, E, device=dev)
-            top_k = torch.zeros(beam_size, device=dev)
-            lse = torch.empty(beam_size, device=dev)
-            scores = torch.empty(beam_size, V, device=dev)
-            vals = torch.empty(beam_size, device=dev)
-            idx, prev, nxt = (torch.empty(beam_size, dtype=torch.long, device=dev) for _ in range(3))
-            seqs = attw = None
-            for t in range(max_length):
-                if t == 0:
-                    w = torch.full((beam_size,), self.start_idx, dtype=torch.long, device=dev)
-                else:
-                    w = nxt.clone()
-                    state = state[:, prev].contiguous()
-                    hid = (hid[0][:, prev].contiguous(), hid[1][:, prev].contiguous())
-                    last_z = last_z[prev].contiguous()
-                eps = replay[i, t] if replay is not None else None
-                pn = self.pnet(w.unsqueeze(1), mem, hid, last_z, lens, eps=eps)
-                dn = self.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
-                logits = dn["logits"].squeeze(1)
-                _lib.call("acvae_row_logsoftmax_argmax", logits, V, V, None, None, lse, 1, 1, beam_size, 1, V, st())
-                _lib.call("acvae_logprob_add", logits, V, lse, top_k, scores, beam_size, V, st())
-                _lib.call("acvae_topk_flat", scores, beam_size * V, beam_size, V, vals, idx, prev, nxt, st())
-                top_k = vals.clone()
-                seqs = nxt.unsqueeze(1).clone() if t == 0 else torch.cat([seqs[prev], nxt.unsqueeze(1)], dim=1)
-                w_t = dn["weights"].unsqueeze(2)                              # [beam,S,1]
-                attw = w_t if t == 0 else torch.cat([attw, w_t], dim=2)[prev]
-                state, hid, last_z = dn["state"], pn["hiddens_state"], pn["z"]
-            seqs_out[i] = seqs[0]
-            attn_out[i] = attw[0]
-        return {"seqs": seqs_out, "attn_weights": attn_out}
+        seqs = attw = None
+        for t in range(max_length):
+            if t == 0:
+                w = torch.full((R,), self.start_idx, dtype=torch.long, device=dev)
+            else:
+                w = nxt.clone()
+                state = state[:, prev].contiguous()
+                hid = (hid[0][:, prev].contiguous(), hid[1][:, prev].contiguous())
+                last_z = last_z[prev].contiguous()
+            pn = self.pnet(w.unsqueeze(1), mem, hid, last_z, lens, eps=eps_all[:, t].reshape(R, E))
+            dn = self.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
+            logits = dn["logits"].squeeze(1)
+            _lib.call("acvae_row_logsoftmax_argmax", logits, V, V, None, None, lse, 1, 1, R, 1, V, st())
+            _lib.call("acvae_logprob_add", logits, V, lse, top_k, scores, R, V, st())
+            _lib.call("acvae_topk_flat_batched", scores, beam_size * V, beam_size, V, vals, idx, prev, nxt, N, beam_size,
+                      st())
+            top_k = vals.clone()
+            seqs = nxt.unsqueeze(1).clone() if t == 0 else torch.cat([seqs[prev], nxt.unsqueeze(1)], dim=1)
+            w_t = dn["weights"].unsqueeze(2)                              # [R,S,1]
+            attw = w_t if t == 0 else torch.cat([attw, w_t], dim=2)[prev]
+            state, hid, last_z = dn["state"], pn["hiddens_state"], pn["z"]
+        return {"seqs": seqs[0::beam_size].contiguous(), "attn_weights": attw[0::beam_size].contiguous()}
 
     @torch.no_grad()
     def diverse_beam_search(self, encoded, max_length, beam_size, group_size, diversity_lambda, temperature, group_nbest):

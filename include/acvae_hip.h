@@ -255,6 +255,10 @@ int acvae_logprob_add(const float* logits, int64_t ld, const float* lse, const f
                       void* stream);
 int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx, int64_t* row, int64_t* col,
                     void* stream);
+/* All clips of a batch at once: x [groups][n] (n = beam*V scores of one clip), outputs [groups][k]; `row` comes back as
+ * group * row_base + idx / V, i.e. as an index into the batch's beam rows when row_base = beam. */
+int acvae_topk_flat_batched(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx, int64_t* row,
+                            int64_t* col, int groups, int row_base, void* stream);
 /* Diverse beam search, models/word_model.py:344-348 with add_diversity :298-312: per beam row
  *   out[n,c] = log_softmax(log_softmax(logits[n]) / temperature)[c] - diversity_lambda * counts[c] + prev[n]
  * counts [V] (may be NULL: first group) = how often the earlier groups chose word c at this local step; prev [N]
