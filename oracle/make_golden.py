@@ -366,6 +366,15 @@ def g10_host():
     ev = host.caption_dataset.collate_fn([1, ])([(k, f) for f, _, k in items[:3]])
     rows = np.array([[1, 5, 6, 7, 2, 2, 2, 2], [1, 9, 9, 4, 10, 11, 12, 13], [2, 5, 6, 7, 8, 9, 10, 11],
                      [5, 1, 6, 2, 7, 8, 2, 9]])
+    # CaptionSampler (caption_dataset.py:199-224): pair order, plain and shuffled under random.seed(77)
+    import types as _types
+    ncaps = [2, 1, 3, 1, 2]
+    info = [{"audio_id": f"clip{a}", "captions": [{"tokens": "x"}] * n} for a, n in enumerate(ncaps)]
+    src = _types.SimpleNamespace(_caption_info=info)
+    plain = list(host.caption_dataset.CaptionSampler(src))
+    random.seed(77)
+    shuffled = list(host.caption_dataset.CaptionSampler(src, shuffle=True))
+    subset = list(host.caption_dataset.CaptionSampler(src, audio_subset_indices=[4, 2]))
     sents = [host.base_runner.BaseRunner._convert_idx2sentence(r, vocab) for r in rows]
     sents_zh = [" ".join(host.base_runner.BaseRunner._convert_idx2sentence(r, vocab, zh=True)) for r in rows]
     save("g10_host", in_feats=feats, in_caps=caps, in_T=np.array(T), in_L=np.array(L),
@@ -373,7 +382,9 @@ def g10_host():
          tr_caps_is_float=np.array(out[1].dtype == torch.float32),
          ev_keys=np.array(ev[0]), ev_feats=ev[1], ev_feat_lens=ev[2],
          words=np.array(words), vocab_pickle=np.frombuffer(pickle.dumps(vocab), dtype=np.uint8),
-         rows=rows, sentences=np.array(sents), sentences_zh=np.array(sents_zh))
+         rows=rows, sentences=np.array(sents), sentences_zh=np.array(sents_zh),
+         sampler_ncaps=np.array(ncaps), sampler_plain=np.array(plain), sampler_shuffled77=np.array(shuffled),
+         sampler_subset42=np.array(subset))
 
 
 def main():

@@ -116,3 +116,69 @@ def test_predictions_payload_structure():
     assert got == HO.predictions([["x"]], [rows[:1]], idx2word, zh=True)
     assert got["predictions"][0] == {"filename": "x", "caption": "w1w2w3", "tokens": "w1 w2 w3"}
     json.dumps(got)
+
+
+# ------------------------------------------------------------------------------------------------ batch source (N4)
+def annotations():
+    words = [f"w{i}" for i in range(16)]
+    rng = np.random.RandomState(3)
+    info = []
+    for a in range(5):
+        caps = [{"tokens": " ".join(rng.choice(words + ["zzz"], size=rng.randint(2, 7)))} for _ in range(1 + a % 3)]
+        info.append({"audio_id": f"clip{a}", "captions": caps})
+    feats = {f"clip{a}": rng.randn(1, 6 + a, 4).astype(np.float32) for a in range(5)}     # squeezed on read
+    return info, feats
+
+
+def test_caption_dataset_items_and_sampler_order():
+    from acvae_amd import dataset as DS
+    info, feats = annotations()
+    vocab = EV.load_vocabulary(G["vocab_pickle"].tobytes())
+    ds = DS.CaptionDataset(feats, info, vocab)
+    assert len(ds) == sum(len(i["captions"]) for i in info) == 9
+    feat, cap, key = ds[(3, 0)]
+    toks = info[3]["captions"][0]["tokens"].split()
+    assert key == "clip3" and tuple(feat.shape) == (9, 4) and torch.equal(feat, torch.from_numpy(feats["clip3"][0]))
+    assert cap.tolist() == [1] + [vocab(t) for t in toks] + [2] and vocab("zzz") == 3        # <start> ... <end>, <unk>
+    ev = DS.CaptionEvalDataset(lambda k: feats[k], [i["audio_id"] for i in info])
+    assert ev[1][0] == "clip1" and tuple(ev[1][1].shape) == (7, 4) and len(ev) == 5
+    # sampler: clip-major pairs; shuffled order = random.shuffle of that list under the caller's seed
+    import random
+    plain = list(DS.CaptionSampler(ds))
+    assert plain == [(a, c) for a in range(5) for c in range(len(info[a]["captions"]))] and len(DS.CaptionSampler(ds)) == 9
+    random.seed(5); got = list(DS.CaptionSampler(ds, shuffle=True))
+    want = list(plain); random.seed(5); random.shuffle(want)
+    assert got == want
+    assert list(DS.CaptionSampler(ds, audio_subset_indices=[4, 1])) == [(4, 0), (4, 1), (1, 0), (1, 1)]
+    # a training batch straight through the collate function
+    batch = B.collate_fn([0, 1], 1)([ds[p] for p in plain[:4]])
+    assert batch[0].shape[0] == 4 and list(batch[-1]) == sorted(batch[-1], reverse=True)
+
+
+def test_distributed_sampler_partitions_every_pair():
+    from acvae_amd import dataset as DS
+    info, feats = annotations()
+    ds = DS.CaptionDataset(feats, info, EV.load_vocabulary(G["vocab_pickle"].tobytes()))
+    world = 4
+    parts = [list(DS.CaptionDistributedSampler(ds, num_replicas=world, rank=r, seed=2)) for r in range(world)]
+    assert all(len(p) == 3 for p in parts)                       # ceil(9 / 4), padded by wrapping
+    flat = [x for p in parts for x in p]
+    assert set(flat) == set(DS.caption_pairs(info)) and len(flat) == 12
+    # every rank shuffles the same list the same way (random.seed(seed + epoch)), so the shards interleave one order
+    import random
+    order = DS.caption_pairs(info); random.seed(2); random.shuffle(order)
+    order += order[:3]
+    assert [parts[r] for r in range(world)] == [order[r::world] for r in range(world)]
+
+
+def test_sampler_matches_reference_fixture():
+    """pair order of the reference's own CaptionSampler (golden g10: plain, shuffled under random.seed(77), subset)"""
+    import random
+    import types
+    from acvae_amd import dataset as DS
+    info = [{"audio_id": f"clip{a}", "captions": [{"tokens": "x"}] * int(n)} for a, n in enumerate(G["sampler_ncaps"])]
+    src = types.SimpleNamespace(_caption_info=info)
+    assert [list(p) for p in DS.CaptionSampler(src)] == G["sampler_plain"].tolist()
+    random.seed(77)
+    assert [list(p) for p in DS.CaptionSampler(src, shuffle=True)] == G["sampler_shuffled77"].tolist()
+    assert [list(p) for p in DS.CaptionSampler(src, audio_subset_indices=[4, 2])] == G["sampler_subset42"].tolist()
