@@ -209,3 +209,51 @@ class TrainStep:
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+
+    # ------------------------------------------------------------------ checkpoint in the reference's format
+    def _offsets(self):
+        off, table = 0, {}
+        for p in self.order:
+            table[p] = off
+            off += (p.numel() + 3) // 4 * 4
+        return table
+
+    def optimizer_state_dict(self):
+        """The moments in ``torch.optim.Adam.state_dict()`` layout, parameters indexed in ``model.parameters()`` order
+        (the optimiser of the reference is built from it, ``runners/pytorch_runner_vae.py:233-236``), so that
+        ``{"model": model.state_dict(), "optimizer": ts.optimizer_state_dict()}`` is the checkpoint the reference writes
+        (``:380-388``) and a ``torch.optim.Adam`` over a reference model loads it."""
+        table = self._offsets()
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        state = {}
+        for i, p in enumerate(params):
+            if self.step_count == 0:
+                continue
+            o = table[p]
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """Inverse of ``optimizer_state_dict`` (also accepts the state dict of a ``torch.optim.Adam`` built over the
+        same model): resume training where the checkpoint left off."""
+        table = self._offsets()
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        group = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+        self.weight_decay = group.get("weight_decay", 0.0)
+        steps = set()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for i, st in sd["state"].items():
+            p = params[int(i)]
+            o = table[p]
+            self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: this optimiser keeps one step counter")
+        self.step_count = steps.pop() if steps else 0

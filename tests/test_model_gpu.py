@@ -320,3 +320,50 @@ def test_edge_shapes_vs_oracle(B, Tt, L, lens, flens):
             assert k.startswith("encoder.") and err <= 3e-2 * mx, (k, err, mx)
             loose.append(k)
     assert len(loose) <= 3, loose
+
+
+def test_checkpoint_round_trip_and_torch_adam_compat():
+    """{"model", "optimizer"} checkpoint in the reference's format: resuming from it continues bit for bit, and a
+    torch.optim.Adam over the same parameters accepts the optimiser part (it takes the same second step)."""
+    import io
+    from acvae_amd.trainer import TrainStep
+    V, E = 40, 64
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    feats, caps, fl, cl = O.synthetic_batch(3, 64, V, 7, seed=1, ragged=True)
+
+    def fresh():
+        m = build_model(V, E, state).train()
+        m.encoder.p_block = m.encoder.p_fc = 0.0
+        return m, TrainStep(m, V)
+
+    def one(ts):
+        torch.manual_seed(3); random.seed(3)
+        return ts.step(feats.cuda(), fl.copy(), caps, cl, 1.0, 0, 0.5)
+
+    m1, t1 = fresh()
+    one(t1)
+    buf = io.BytesIO()
+    torch.save({"model": m1.state_dict(), "optimizer": t1.optimizer_state_dict()}, buf)
+    one(t1)                                                   # second step, uninterrupted
+    ck = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)
+    assert list(ck["model"].keys()) == list(state.keys())
+    m2, t2 = fresh()
+    m2.load_state_dict(ck["model"])
+    t2.load_optimizer_state_dict(ck["optimizer"])
+    assert t2.step_count == 1
+    one(t2)                                                   # second step after the restore
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # torch.optim.Adam over the parameters of the restored model takes the checkpoint and the same step
+    m3, t3 = fresh()
+    m3.load_state_dict(ck["model"])
+    opt = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=5e-4)
+    opt.load_state_dict(ck["optimizer"])
+    torch.manual_seed(3); random.seed(3)
+    loss, _, _ = t3.forward_loss(feats.cuda(), fl.copy(), caps, cl, 1.0, 0, 0.5)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_([p for p in m3.parameters() if p.grad is not None], 1.0)
+    opt.step()
+    for (k, a), (_, b) in zip(m1.named_parameters(), m3.named_parameters()):
+        if b.grad is not None:
+            close(b, a, 1e-5, 1e-6, what="torch Adam vs fused " + k)
