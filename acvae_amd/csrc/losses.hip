@@ -264,9 +264,10 @@ __global__ void logprob_add_kernel(const float* __restrict__ logits, long ld, co
 __global__ __launch_bounds__(256) void dbs_scores_kernel(const float* __restrict__ logits, long ld, float temperature,
                                                          const float* __restrict__ counts, float lambda,
                                                          const float* __restrict__ prev, float* __restrict__ out,
-                                                         int V) {
+                                                         int V, int rows_per_count) {
   __shared__ float red[16];
   const int n = blockIdx.x;
+  if (counts && rows_per_count > 0) counts += (long)(n / rows_per_count) * V;   // one count vector per clip
   const float* x = logits + (long)n * ld;
   float m = -INFINITY;
   for (int c = threadIdx.x; c < V; c += blockDim.x) m = fmaxf(m, x[c]);
@@ -295,14 +296,14 @@ __global__ __launch_bounds__(256) void dbs_scores_kernel(const float* __restrict
 __global__ __launch_bounds__(1024) void topk_flat_kernel(const float* __restrict__ x, long n, int k, int V,
                                                          float* __restrict__ vals, int64_t* __restrict__ idx,
                                                          int64_t* __restrict__ row, int64_t* __restrict__ col,
-                                                         int row_base) {
+                                                         int row_base, long group_stride) {
   __shared__ float rv[16];
   __shared__ long ri[16];
   __shared__ float sel_v[16];
   __shared__ long sel_i[16];
   // one workgroup per group (batched beam search: group = clip, x[g][n], outputs [g][k]); row_base offsets `row` so
   // that it indexes the rows of the whole batch (g * row_base + idx / V)
-  x += (long)blockIdx.x * n;
+  x += (long)blockIdx.x * group_stride;
   vals += (long)blockIdx.x * k; idx += (long)blockIdx.x * k;
   if (row) row += (long)blockIdx.x * k;
   if (col) col += (long)blockIdx.x * k;
@@ -460,10 +461,11 @@ extern "C" int acvae_logprob_add(const float* logits, int64_t ld, const float* l
 }
 
 extern "C" int acvae_dbs_scores(const float* logits, int64_t ld, float temperature, const float* counts,
-                                float diversity_lambda, const float* prev, float* out, int N, int V, void* stream) {
-  if (!logits || !out || N <= 0 || V <= 0 || !(temperature > 0.f)) return ACVAE_EINVAL;
+                                float diversity_lambda, const float* prev, float* out, int N, int V,
+                                int rows_per_count, void* stream) {
+  if (!logits || !out || N <= 0 || V <= 0 || !(temperature > 0.f) || rows_per_count < 0) return ACVAE_EINVAL;
   hipLaunchKernelGGL(dbs_scores_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, ld, temperature, counts,
-                     diversity_lambda, prev, out, V);
+                     diversity_lambda, prev, out, V, rows_per_count);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
@@ -472,16 +474,18 @@ extern "C" int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* v
                                int64_t* col, void* stream) {
   if (!x || !vals || !idx || n <= 0 || k <= 0 || k > 16 || k > n || V <= 0) return ACVAE_EINVAL;
   hipLaunchKernelGGL(topk_flat_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, k, V, vals, idx, row,
-                     col, 0);
+                     col, 0, 0L);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
 
-extern "C" int acvae_topk_flat_batched(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx,
-                                       int64_t* row, int64_t* col, int groups, int row_base, void* stream) {
-  if (!x || !vals || !idx || n <= 0 || k <= 0 || k > 16 || k > n || V <= 0 || groups <= 0) return ACVAE_EINVAL;
+extern "C" int acvae_topk_flat_batched(const float* x, int64_t n, int64_t group_stride, int k, int V, float* vals,
+                                       int64_t* idx, int64_t* row, int64_t* col, int groups, int row_base,
+                                       void* stream) {
+  if (!x || !vals || !idx || n <= 0 || k <= 0 || k > 16 || k > n || V <= 0 || groups <= 0 || group_stride < n)
+    return ACVAE_EINVAL;
   hipLaunchKernelGGL(topk_flat_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, x, (long)n, k, V, vals, idx,
-                     row, col, row_base);
+                     row, col, row_base, (long)group_stride);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

@@ -210,8 +210,8 @@ class Hybrid_VAEModel(CaptionModel):
             logits = dn["logits"].squeeze(1)
             _lib.call("acvae_row_logsoftmax_argmax", logits, V, V, None, None, lse, 1, 1, R, 1, V, st())
             _lib.call("acvae_logprob_add", logits, V, lse, top_k, scores, R, V, st())
-            _lib.call("acvae_topk_flat_batched", scores, beam_size * V, beam_size, V, vals, idx, prev, nxt, N, beam_size,
-                      st())
+            _lib.call("acvae_topk_flat_batched", scores, beam_size * V, beam_size * V, beam_size, V, vals, idx, prev, nxt,
+                      N, beam_size, st())
             top_k = vals.clone()
             seqs = nxt.unsqueeze(1).clone() if t == 0 else torch.cat([seqs[prev], nxt.unsqueeze(1)], dim=1)
             w_t = dn["weights"].unsqueeze(2)                              # [R,S,1]
@@ -242,60 +242,72 @@ class Hybrid_VAEModel(CaptionModel):
         bdash = beam_size // group_size
         if bdash < 1 or bdash > 16:
             raise ValueError("diverse_beam_search: beam_size // group_size must be in 1..16")
+        R = N * bdash
         st = _lib.current_stream
+        # The clips are independent, so they advance together: rows = clips x bdash per (t, group) step; one host read-back
+        # per step for the whole batch (the reference reads back per clip and step).  The reference's noise order — clip,
+        # then t, then group (text_encoder.py:259 inside those loops) — is kept by drawing every eps up front in it.
+        steps = [(t, g) for t in range(max_length + group_size - 1) for g in range(group_size)
+                 if 0 <= t - g <= max_length - 1]
+        eps_all = _lib.h2d_fill((N, len(steps), bdash, E), torch.float32, dev,
+                                lambda buf: [torch.randn(bdash, E, out=buf[i, k]) for i in range(N)
+                                             for k in range(len(steps))])
+        mem = mem_all.repeat_interleave(bdash, dim=0).contiguous()
+        lens = lens_all.repeat_interleave(bdash)
+        scores = torch.empty(R, V, device=dev)
+        vals = torch.empty(R, device=dev)
+        idx, prev_d, nxt_d = (torch.empty(R, dtype=torch.long, device=dev) for _ in range(3))
+        seq = [[np.zeros((bdash, 0), np.int64) for _ in range(group_size)] for _ in range(N)]
+        score = [np.zeros((N, bdash), np.float32) for _ in range(group_size)]
+        done = [[[] for _ in range(group_size)] for _ in range(N)]
+        carry = [None] * group_size
+        base = (np.arange(N) * bdash)[:, None]
+        for k, (t, g) in enumerate(steps):
+            lt = t - g
+            if lt == 0:
+                w = torch.full((R,), self.start_idx, dtype=torch.long, device=dev)
+                state = self.decoder.init_hidden(R).to(dev)
+                hid = self.pnet.init_hidden(R, dev)
+                last_z = torch.zeros(R, E, device=dev)
+            else:
+                state0, hid0, z0, w, parent = carry[g]
+                state = state0[:, parent].contiguous()
+                hid = (hid0[0][:, parent].contiguous(), hid0[1][:, parent].contiguous())
+                last_z = z0[parent].contiguous()
+            pn = self.pnet(w.unsqueeze(1), mem, hid, last_z, lens, eps=eps_all[:, k].reshape(R, E))
+            dn = self.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
+            logits = dn["logits"].squeeze(1)
+            counts = None
+            if g > 0:                                        # add_diversity (:298-312), one count vector per clip
+                c = np.zeros((N, V), np.float32)
+                for i in range(N):
+                    for earlier in range(g):
+                        np.add.at(c[i], seq[i][earlier][:, lt], 1.0)
+                counts = _lib.h2d(c, dev)
+            _lib.call("acvae_dbs_scores", logits, V, float(temperature), counts, float(diversity_lambda),
+                      _lib.h2d(score[g].reshape(-1), dev), scores, R, V, bdash if g > 0 else 0, st())
+            _lib.call("acvae_topk_flat_batched", scores, V if lt == 0 else bdash * V, bdash * V, bdash, V, vals, idx, prev_d,
+                      nxt_d, N, bdash, st())
+            top = vals.cpu().numpy().reshape(N, bdash).copy()              # one read-back per step for all clips
+            parent_h = prev_d.cpu().numpy().reshape(N, bdash) - base        # beam index within the clip
+            nxt_h = nxt_d.cpu().numpy().reshape(N, bdash)
+            last = t == max_length + g - 1
+            for i in range(N):
+                sq = np.concatenate([seq[i][g][parent_h[i]] if lt > 0 else seq[i][g], nxt_h[i][:, None]], axis=1)
+                seq[i][g] = sq
+                ended = sq[:, lt] == self.end_idx
+                if last:
+                    ended[:] = True
+                for b_ in range(bdash):
+                    if ended[b_]:
+                        done[i][g].append({"seq": sq[b_].copy(), "score": float(top[i, b_]) / (lt + 1)})
+                top[i][ended] -= np.float32(1000)
+            score[g] = top
+            carry[g] = (dn["state"], pn["hiddens_state"], pn["z"], nxt_d.clone(), prev_d.clone())
         out = torch.full((N, beam_size if group_nbest else group_size, max_length), self.end_idx, dtype=torch.long)
-        scores = torch.empty(bdash, V, device=dev)
-        vals = torch.empty(bdash, device=dev)
-        idx, prev_d, nxt_d = (torch.empty(bdash, dtype=torch.long, device=dev) for _ in range(3))
         for i in range(N):
-            mem = mem_all[i].unsqueeze(0).repeat(bdash, 1, 1).contiguous()
-            lens = lens_all[i].repeat(bdash)
-            seq = [np.zeros((bdash, 0), np.int64) for _ in range(group_size)]
-            score = [np.zeros(bdash, np.float32) for _ in range(group_size)]
-            done = [[] for _ in range(group_size)]
-            carry = [None] * group_size
-            for t in range(max_length + group_size - 1):
-                for g in range(group_size):
-                    lt = t - g
-                    if lt < 0 or lt > max_length - 1:
-                        continue
-                    if lt == 0:
-                        w = torch.full((bdash,), self.start_idx, dtype=torch.long, device=dev)
-                        state = self.decoder.init_hidden(bdash).to(dev)
-                        hid = self.pnet.init_hidden(bdash, dev)
-                        last_z = torch.zeros(bdash, E, device=dev)
-                    else:
-                        state0, hid0, z0, w, parent = carry[g]
-                        state = state0[:, parent].contiguous()
-                        hid = (hid0[0][:, parent].contiguous(), hid0[1][:, parent].contiguous())
-                        last_z = z0[parent].contiguous()
-                    pn = self.pnet(w.unsqueeze(1), mem, hid, last_z, lens)
-                    dn = self.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
-                    logits = dn["logits"].squeeze(1)
-                    counts = None
-                    if g > 0:                                        # add_diversity (:298-312)
-                        c = np.zeros(V, np.float32)
-                        for earlier in range(g):
-                            np.add.at(c, seq[earlier][:, lt], 1.0)
-                        counts = _lib.h2d(c, dev)
-                    _lib.call("acvae_dbs_scores", logits, V, float(temperature), counts, float(diversity_lambda),
-                              _lib.h2d(score[g], dev), scores, bdash, V, st())
-                    _lib.call("acvae_topk_flat", scores, V if lt == 0 else bdash * V, bdash, V, vals, idx, prev_d, nxt_d,
-                              st())
-                    top = vals.cpu().numpy().copy()                  # the reference syncs here too (topk_words.cpu())
-                    parent_h, nxt_h = prev_d.cpu().numpy().copy(), nxt_d.cpu().numpy().copy()
-                    seq[g] = np.concatenate([seq[g][parent_h] if lt > 0 else seq[g], nxt_h[:, None]], axis=1)
-                    ended = seq[g][:, lt] == self.end_idx
-                    if t == max_length + g - 1:
-                        ended[:] = True
-                    for b in range(bdash):
-                        if ended[b]:
-                            done[g].append({"seq": seq[g][b].copy(), "score": float(top[b]) / (lt + 1)})
-                    top[ended] -= np.float32(1000)
-                    score[g] = top
-                    carry[g] = (dn["state"], pn["hiddens_state"], pn["z"], nxt_d.clone(), prev_d.clone())
-            done = [sorted(d, key=lambda x: -x["score"])[:bdash] for d in done]
-            chosen = sum(done, []) if group_nbest else [d[0] for d in done]
+            ranked = [sorted(d, key=lambda x: -x["score"])[:bdash] for d in done[i]]
+            chosen = sum(ranked, []) if group_nbest else [d[0] for d in ranked]
             for r, beam in enumerate(chosen):
                 out[i, r, :len(beam["seq"])] = torch.from_numpy(beam["seq"])
         return {"seqs": out.to(dev)}

@@ -255,16 +255,18 @@ int acvae_logprob_add(const float* logits, int64_t ld, const float* lse, const f
                       void* stream);
 int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx, int64_t* row, int64_t* col,
                     void* stream);
-/* All clips of a batch at once: x [groups][n] (n = beam*V scores of one clip), outputs [groups][k]; `row` comes back as
- * group * row_base + idx / V, i.e. as an index into the batch's beam rows when row_base = beam. */
-int acvae_topk_flat_batched(const float* x, int64_t n, int k, int V, float* vals, int64_t* idx, int64_t* row,
-                            int64_t* col, int groups, int row_base, void* stream);
+/* All clips of a batch at once: group g searches x[g * group_stride .. + n) (n = beam*V scores of one clip, or V: only
+ * its first beam row), outputs [groups][k]; `row` comes back as group * row_base + idx / V, i.e. as an index into the
+ * batch's beam rows when row_base = beam. */
+int acvae_topk_flat_batched(const float* x, int64_t n, int64_t group_stride, int k, int V, float* vals, int64_t* idx,
+                            int64_t* row, int64_t* col, int groups, int row_base, void* stream);
 /* Diverse beam search, models/word_model.py:344-348 with add_diversity :298-312: per beam row
  *   out[n,c] = log_softmax(log_softmax(logits[n]) / temperature)[c] - diversity_lambda * counts[c] + prev[n]
- * counts [V] (may be NULL: first group) = how often the earlier groups chose word c at this local step; prev [N]
- * (may be NULL) the running beam log-probabilities. */
+ * counts (may be NULL: first group) = how often the earlier groups chose word c at this local step: one vector [V] for
+ * all rows (rows_per_count = 0) or one per clip, [N / rows_per_count][V]; prev [N] (may be NULL) the running beam
+ * log-probabilities. */
 int acvae_dbs_scores(const float* logits, int64_t ld, float temperature, const float* counts, float diversity_lambda,
-                     const float* prev, float* out, int N, int V, void* stream);
+                     const float* prev, float* out, int N, int V, int rows_per_count, void* stream);
 
 #ifdef __cplusplus
 }

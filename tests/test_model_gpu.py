@@ -242,7 +242,7 @@ def test_dbs_scores_kernel_vs_torch():
     prev = torch.randn(N, generator=g).cuda()
     out = torch.empty(N, V, device="cuda")
     for temp, lam, cnt, pv in ((1.0, 0.5, counts, prev), (1.7, 2.0, counts, None), (0.6, 0.0, None, prev)):
-        _lib.call("acvae_dbs_scores", logits, V, temp, cnt, lam, pv, out, N, V, _lib.current_stream())
+        _lib.call("acvae_dbs_scores", logits, V, temp, cnt, lam, pv, out, N, V, 0, _lib.current_stream())
         want = torch.log_softmax(torch.log_softmax(logits.cpu(), 1) / temp, 1)
         if cnt is not None:
             want = want - cnt.cpu() * lam

@@ -17,8 +17,8 @@ for method, bs in (("greedy", N), ("greedy", 1), ("beam", 3), ("dbs", 5)):
     kw = dict(method=method, beam_size=bs, max_length=20, batch_size=B)
     if method == "dbs":
         kw["group_size"] = 5
-    n_items = items[:8] if method == "dbs" else items
-    EV.evaluate(model, n_items[:2 if method == "dbs" else B], voc, **kw)          # warm-up
+    n_items = items[:64] if method == "dbs" else items
+    EV.evaluate(model, n_items[:B], voc, **kw)          # warm-up
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = EV.evaluate(model, n_items, voc, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
