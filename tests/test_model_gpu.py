@@ -68,7 +68,7 @@ def close_grad_of(name, a, ref, what):
         close(a, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-3), what=what)
 
 
-def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=2e-4):
+def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
     g = load_golden(name)
     B, Tt, V, E, L = (int(x) for x in g["dims"])
     seed = int(g["seed"])
@@ -129,6 +129,7 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=2e-4):
             close(out[k], g["out_" + k], 1e-4, 2e-5, what=k)
     loss.backward()
     named = dict(model.named_parameters())
+    # the global norm is dominated by the encoder gradients: one ReLU-boundary flip (close_enc_grad) moves it by a few 1e-4
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None))
     assert abs(float(gn) - float(g["grad_norm"])) <= gn_tol * float(g["grad_norm"]), (float(gn), float(g["grad_norm"]))
     if tensors:
