@@ -64,12 +64,15 @@ class _PosteriorFn(torch.autograd.Function):
         utt = torch.empty(N, 2 * Hq, device=dev)
         _lib.call("acvae_posterior_fwd", ptr_table(params), caps_d, caps_d.stride(0), lens1_d, eps_q, qm, ql, qz, utt,
                   saved, saved_b, scratch, scratch_b, N, Tc, E, Hq, V, _lib.current_stream())
-        ctx.mod, ctx.saved, ctx.lens1_d, ctx.eps_q, ctx.ql, ctx.dims = mod, saved, lens1_d, eps_q, ql, (N, Tc, E, Hq, V)
+        ctx.mod, ctx.saved, ctx.dims = mod, saved, (N, Tc, E, Hq, V)
+        # an OUTPUT kept as a plain ctx attribute forms a tensor -> grad_fn -> ctx -> tensor cycle that is never collected
+        ctx.save_for_backward(lens1_d, eps_q, ql)
         return qm, ql, qz, utt
 
     @staticmethod
     def backward(ctx, d_qm, d_ql, d_qz, d_utt):
         mod = ctx.mod
+        lens1_d, eps_q, ql = ctx.saved_tensors
         N, Tc, E, Hq, V = ctx.dims
         params = mod._text_table()
         grads = [None] * len(params)
@@ -78,8 +81,8 @@ class _PosteriorFn(torch.autograd.Function):
                 grads[i] = mod._grad_buffer(p)
         c = lambda t: None if t is None else t.contiguous().float()
         scratch_b = _lib.call("acvae_posterior_scratch_bytes", N, Tc, E, Hq, V)
-        scratch = scratch_buffer(scratch_b, ctx.eps_q.device)
-        _lib.call("acvae_posterior_bwd", ptr_table(params), ptr_table(grads), ctx.lens1_d, ctx.eps_q, ctx.ql, c(d_qm),
+        scratch = scratch_buffer(scratch_b, eps_q.device)
+        _lib.call("acvae_posterior_bwd", ptr_table(params), ptr_table(grads), lens1_d, eps_q, ql, c(d_qm),
                   c(d_ql), c(d_qz), c(d_utt), ctx.saved, ctx.saved.numel(), scratch, scratch_b, N, Tc, E, Hq, V,
                   _lib.current_stream())
         ctx.saved = None

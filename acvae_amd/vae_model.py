@@ -56,7 +56,8 @@ class _DecodeFn(torch.autograd.Function):
                   saved, saved_b, scratch, scratch_b, *dims, model.start_idx, model.end_idx, _lib.current_stream(),
                   model._aux_stream())
         ctx.model, ctx.saved, ctx.dims, ctx.dis_arr = model, saved, dims, dis_arr
-        ctx.keep = (mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl)
+        # outputs kept as plain ctx attributes would form tensor -> grad_fn -> ctx -> tensor cycles that are never collected
+        ctx.save_for_backward(mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl)
         ctx.mark_non_differentiable(seqs, slp, attw, hfin, hp, cp)
         if not train:
             putt = torch.zeros(0, device=dev)
@@ -67,7 +68,7 @@ class _DecodeFn(torch.autograd.Function):
     def backward(ctx, d_logits, d_outputs, _s, _l, _a, d_pm, d_pl, d_pz, d_putt, *_rest):
         model = ctx.model
         N, Tc, S, E, H, A, V, Eenc = ctx.dims
-        mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl = ctx.keep
+        mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl = ctx.saved_tensors
         dev = mem.device
         params = model._text_table()
         grads = [None] * len(params)

@@ -160,3 +160,22 @@ def test_loss_vs_oracle_at_config2_full_size():
     loss.backward()
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
     assert abs(float(gn) - float(ores["grad_norm"])) <= 2e-4 * float(ores["grad_norm"]), (float(gn), float(ores["grad_norm"]))
+
+
+def test_training_steps_do_not_leak_device_memory():
+    """A tensor that an autograd Function both returns and keeps as a plain ctx attribute is never collected (tensor ->
+    grad_fn -> ctx -> tensor); the Functions keep such tensors through save_for_backward.  Guard: the allocated bytes
+    after step 4 and after step 14 are the same."""
+    import gc
+    model = build(2).train()
+    ts = TrainStep(model, V)
+    feats, caps, fl, cl = batch(4, 160, ragged=True)
+    f = feats.cuda()
+    marks = []
+    for i in range(14):
+        random.seed(i)
+        ts.step(f, fl.copy(), caps, cl, 1.0, 0, 0.5)
+        if i in (3, 13):
+            torch.cuda.synchronize(); gc.collect()
+            marks.append(torch.cuda.memory_allocated())
+    assert marks[1] <= marks[0] + (1 << 20), marks
