@@ -448,9 +448,14 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
     const int M = rows_of(cnt);
     ACVAE_TRY(acvae::embed_gather(words + t0, cnt == Tc ? 1 : Tc, P(TP_DEC_EMB), V, rnn_d + (long)t0 * 3 * E,
                                   ldof(cnt, 3 * E), M, E, st));
-    for (int t = t0; t < t0 + cnt; ++t) {  // z: posterior sample unless this step drew the prior (vae_model.py:800-808)
-      const float* zsrc = (train && !dis_flags_host[t]) ? q_z : p_z;
-      ACVAE_TRY(acvae::copy_rows(rnn_d + (long)t * 3 * E + 2 * E, ld3E, zsrc + (long)t * E, (long)Tc * E, N, E, st));
+    // z: posterior sample unless this step drew the prior (vae_model.py:800-808); one copy when no step did
+    if (cnt == Tc && train && !prior_feeds_decoder) {
+      ACVAE_TRY(acvae::copy_rows(rnn_d + 2 * E, 3 * E, q_z, E, R, E, st));
+    } else {
+      for (int t = t0; t < t0 + cnt; ++t) {
+        const float* zsrc = (train && !dis_flags_host[t]) ? q_z : p_z;
+        ACVAE_TRY(acvae::copy_rows(rnn_d + (long)t * 3 * E + 2 * E, ld3E, zsrc + (long)t * E, (long)Tc * E, N, E, st));
+      }
     }
     ACVAE_TRY(gemm2(rnn_d + (long)t0 * 3 * E, ldof(cnt, 3 * E), P(TP_DEC_WIH), 3 * E, E,
                     rnn_d + (long)t0 * 3 * E + 2 * E, ldof(cnt, 3 * E), P(TP_DEC_WIH) + 2 * E, 3 * E, E, P(TP_DEC_BIH),
@@ -658,9 +663,13 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, st));
   ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, st));
   // route dz to the posterior sample (here) or to the prior sample (prior chain, below), per step
-  for (int t = 0; t < Tc; ++t)
-    ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
-                               (long)Tc * E, N, E, st));
+  if (!prior_feeds_decoder) {
+    ACVAE_TRY(acvae::copy_rows(d_q_z, E, dz_dec, E, R, E, st));
+  } else {
+    for (int t = 0; t < Tc; ++t)
+      ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
+                                 (long)Tc * E, N, E, st));
+  }
     return ACVAE_OK;
   };
 
