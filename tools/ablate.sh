@@ -17,12 +17,13 @@ if [ "$1" = "build" ]; then
   done
 else
   export TMPDIR=/tmp
+  export ACVAE_CONV_STRIP=0     # the NT ablation hooks live in the one-tap-per-stage kernel (nt_block); wgrad is unaffected
   cd /tmp
   for n in 0 ${ABLS:-1 2 3 4 5}; do
     lib="$ROOT/tools/abl/libacvae_abl$n.so"; [ "$n" = 0 ] && lib="$ROOT/acvae_amd/libacvae_hip.so"
     rm -rf /tmp/abl_tr
     ACVAE_DEV_LIB="$lib" rocprofv3 --kernel-trace -d /tmp/abl_tr -o t --output-format csv -- python3 "$ROOT/tools/bench_encoder.py" 32 1000 6 > /dev/null 2>&1 || true
     echo "== ablation $n"
-    python3 "$ROOT/tools/conv_kernels.py" /tmp/abl_tr/t_kernel_trace.csv | grep -E "${ABL_GREP:-igemm}" | head -9
+    python3 "$ROOT/tools/conv_kernels.py" /tmp/abl_tr/t_kernel_trace.csv | grep -E "${ABL_GREP:-igemm|wgrad <2}" | head -14
   done
 fi
