@@ -315,10 +315,14 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     };
     // weight K-step of sub-stage (grp, dxi): tap = dyi*3 + dxi, channels chunk*32..
     auto kstep_of = [&](int grp, int dxi) { const int dyi = grp / nchunk; return (dyi * 3 + dxi) * nchunk + (grp - dyi * nchunk); };
+    // An LDS-DMA is ordered for the readers only by the issuing wave's vmcnt wait followed by a barrier; hipcc places
+    // that wait in front of __syncthreads() by itself, the explicit one keeps the kernel independent of that.
+    auto dma_wait = [&]() { if (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     al.issue(0, 0, pa);
     fetch_b(0, kstep_of(0, 0));
     put_a(0);
     put_b(0);
+    dma_wait();
     __syncthreads();
     for (int grp = 0; grp < ngrp; ++grp) {
 #pragma unroll
@@ -337,6 +341,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
           put_a(g1 & 1);
           put_b((s + 1) & 1);
         }
+        dma_wait();
         __syncthreads();
       }
     }
