@@ -44,6 +44,11 @@ extern "C" int acvae_prof_enable(int enable) {
   return ACVAE_OK;
 }
 
+extern "C" int acvae_prof_pause(int paused) {   // stop / resume marking without dropping what was recorded
+  g_enabled = paused == 0;
+  return ACVAE_OK;
+}
+
 extern "C" int acvae_prof_read(int tag, double* total_ms_host, int64_t* launches_host) {
   if (tag < 0 || tag >= ACVAE_PROF_NTAGS || !total_ms_host || !launches_host) return ACVAE_EINVAL;
   double tot = 0.0;

@@ -134,10 +134,17 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    # live roofline measurement: HIP events around the conv launches of every PROF_EVERY-th timed step (an event pair
+    # costs a few microseconds of queue bubble; 42 pairs in every step would take ~1 % off the headline)
+    PROF_EVERY = 4
     _lib.lib().acvae_prof_enable(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    sampled = 0
+    for i in range(args.steps):
+        on = i % PROF_EVERY == 0
+        _lib.lib().acvae_prof_pause(0 if on else 1)
+        sampled += int(on)
         parts = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -163,9 +170,9 @@ def main():
         # (all but the Cin=1 first conv) + 7 data gradients (all but the one into the Cin=1 input).  Algorithmic
         # flops of those launches: 2 x (26.03 - 0.074) GFLOP per clip (forward + data-gradient share the shape).
         flops_per_step = 2 * (ENC_FWD_GFLOP_PER_CLIP - 0.074) * 1e9 * B * (T / 1000.0)
-        launches_per_step = igemm_n / max(1, args.steps)
+        launches_per_step = igemm_n / max(1, sampled)
         avg_ms = igemm_ms / max(1, igemm_n)
-        achieved = flops_per_step * args.steps / (igemm_ms * 1e-3) / 1e12 if igemm_ms > 0 else 0.0
+        achieved = flops_per_step * sampled / (igemm_ms * 1e-3) / 1e12 if igemm_ms > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_conv_igemm.json")
         if os.path.exists(tp):
@@ -189,7 +196,7 @@ def main():
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_gflop_per_launch": flops_per_step / 1e9 / max(1.0, launches_per_step),
-                         "wgrad_avg_launch_ms": wgrad_ms / max(1, wgrad_n), "wgrad_launches_per_step": wgrad_n / max(1, args.steps)},
+                         "wgrad_avg_launch_ms": wgrad_ms / max(1, wgrad_n), "wgrad_launches_per_step": wgrad_n / max(1, sampled), "steps_sampled": sampled},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

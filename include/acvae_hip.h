@@ -229,6 +229,7 @@ int acvae_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * while enabled.  total_ms_host / launches_host are HOST pointers.
  * ------------------------------------------------------------------------------------------- */
 int acvae_prof_enable(int enable);
+int acvae_prof_pause(int paused);   /* stop / resume marking, keeping what was recorded (sampled measurement) */
 int acvae_prof_read(int tag, double* total_ms_host, int64_t* launches_host);
 
 /* ---------------------------------------------------------------------------------------------
