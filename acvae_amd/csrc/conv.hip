@@ -451,6 +451,155 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad192_kernel(const float* __re
   tn_block_g<2, 2, EM, 3>(al, bl, Cout, NC, kb, ke, bx, by, slab + (long)z * Cout * NC, NC, 0, sm);
 }
 
+// ------------------------------------------------------------------ weight gradient with horizontal-tap reuse
+// One workgroup owns a 128 (or 64) x 192 tile of dW whose columns are the THREE horizontal taps of one vertical tap dy
+// for 64 input channels.  Per K-step of 16 pixels it stages ONE strip of 18 pixels x 64 channels (pixels k0-1 .. k0+16 at
+// vertical offset dy, BN+ReLU applied once) and the three taps read it at row offsets 0 / 1 / 2; pixels whose horizontal
+// neighbour would cross the image border are switched off by per-pixel flags staged beside the strip (the border
+// depends on the reduction index here, not on the lane).  Activation loads per K-step: 18 x 64 instead of 16 x 192.
+template <int EM>
+struct alignas(16) WgStripSmem {
+  alignas(16) float a[2][BKT * EM * 64];
+  alignas(16) float s[2][(BKT + 2) * 64];
+  alignas(16) float mk[2][2 * BKT];       // [0..BKT) left-neighbour ok, [BKT..2BKT) right-neighbour ok (1.0 / 0.0)
+};
+
+template <int EM>
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ slab,
+                                                             int M, int Cout, int H, int W, int C, FastDiv dW_,
+                                                             FastDiv dH_, int k_per) {
+  constexpr int TM = EM * 64;
+  constexpr int AITS = tn_its<TM>();
+  __shared__ WgStripSmem<EM> sm;
+  const int NC = 9 * C;
+  // XCD-aware order as in conv_wgrad_kernel: the tiles of one pixel slice run back to back on one XCD
+  const int tiles = gridDim.x * gridDim.y;
+  const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int xcd = b & 7, idx = b >> 3;
+  const int z = (idx / tiles) * 8 + xcd, tile = idx % tiles;
+  const int bx = tile % gridDim.x, by = tile / gridDim.x;
+  const int ncg = C / 64;
+  const int dyi = by / ncg, c0 = (by - dyi * ncg) * 64, dy = dyi - 1;
+  const int k_begin = z * k_per, k_end = min(M, k_begin + k_per);
+  float* Cs = slab + (long)z * Cout * NC;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int row0 = bx * TM;
+  const int nk = (k_end - k_begin + BKT - 1) / BKT;
+
+  // per-wave column tiles: 96 columns = 3 MFMA tiles, each inside one horizontal tap
+  int dxj[3], cbj[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { const int col = wn * 96 + j * 32; dxj[j] = col >> 6; cbj[j] = col & 63; }
+
+  f32x16 acc[EM][3];
+#pragma unroll
+  for (int i = 0; i < EM; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  PlainKMajorLoader<true> al{dY, Cout, Cout, M};
+  Pending<4> pa;
+  // strip slots of this thread: slot 0 = row tid/16 (0..15), slot 1 = rows 16, 17 for tid < 32; 4 channels at (tid%16)*4
+  const int sc4 = (tid & 15) * 4;
+  float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (scale) {
+    bsc = *reinterpret_cast<const float4*>(scale + c0 + sc4);
+    bsh = *reinterpret_cast<const float4*>(shift + c0 + sc4);
+  }
+  float4 sv[2];
+  bool sok[2];
+  float mkv = 0.f;
+  auto issue = [&](int k0) {
+    al.template issue<TM>(row0, k0, pa);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int r = (tid >> 4) + 16 * sl;
+      const long q = (long)k0 - 1 + r;
+      bool ok = r < BKT + 2 && q >= 0 && q < M;
+      if (ok) {
+        const int rowq = dW_.div((int)q);
+        const int h = rowq - dH_.div(rowq) * H + dy;
+        ok = h >= 0 && h < H;
+      }
+      sok[sl] = ok;
+      sv[sl] = *reinterpret_cast<const float4*>(ok ? X + (q + (long)dy * W) * C + c0 + sc4 : X);
+    }
+    if (tid < 2 * BKT) {            // border flags of the BKT pixels of this K-step
+      const int k = tid < BKT ? tid : tid - BKT;
+      const int p = k0 + k;
+      const int w = p - dW_.div(p) * W;
+      mkv = (p < M && (tid < BKT ? w > 0 : w < W - 1)) ? 1.f : 0.f;
+    }
+  };
+  auto stash = [&](int buf) {
+    al.template finish<TM>(pa);
+#pragma unroll
+    for (int it = 0; it < AITS; ++it) {
+      const int k = tid / (TM / 4) + it * (256 / (TM / 4));
+      *reinterpret_cast<float4*>(&sm.a[buf][k * TM + (tid % (TM / 4)) * 4]) = pa.v[it];
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int r = (tid >> 4) + 16 * sl;
+      if (r < BKT + 2) {
+        float4 v = sv[sl];
+        if (scale) {
+          v.x = fmaxf(v.x * bsc.x + bsh.x, 0.f); v.y = fmaxf(v.y * bsc.y + bsh.y, 0.f);
+          v.z = fmaxf(v.z * bsc.z + bsh.z, 0.f); v.w = fmaxf(v.w * bsc.w + bsh.w, 0.f);
+        }
+        if (!sok[sl]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&sm.s[buf][r * 64 + sc4]) = v;
+      }
+    }
+    if (tid < 2 * BKT) sm.mk[buf][tid] = mkv;
+  };
+  if (nk > 0) { issue(k_begin); stash(0); }
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) issue(k_begin + (ks + 1) * BKT);
+    const float* As = sm.a[cur] + lh * TM + wm * EM * 32 + li;
+    const float* Ss = sm.s[cur] + lh * 64 + li;
+    const float* Mk = sm.mk[cur] + lh;
+#pragma unroll
+    for (int kk = 0; kk < BKT / 2; ++kk) {
+      float af[EM], bf[3];
+#pragma unroll
+      for (int i = 0; i < EM; ++i) af[i] = As[kk * 2 * TM + i * 32];
+      const float mL = Mk[kk * 2], mR = Mk[BKT + kk * 2];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v = Ss[(kk * 2 + dxj[j]) * 64 + cbj[j]];
+        bf[j] = dxj[j] == 0 ? v * mL : (dxj[j] == 2 ? v * mR : v);
+      }
+#pragma unroll
+      for (int i = 0; i < EM; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (ks + 1 < nk) stash(cur ^ 1);
+    __syncthreads();
+  }
+  // slab[co][(dy*3 + dx)*C + c]
+#pragma unroll
+  for (int i = 0; i < EM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = row0 + wm * EM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= Cout) continue;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        Cs[(long)m * NC + (dyi * 3 + dxj[j]) * C + c0 + cbj[j] + li] = acc[i][j][r];
+    }
+}
+
 // dW_oihw[co][ci][tap] = sum_z slab[z][co][tap*Cin + ci]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, float* __restrict__ dW, int Cout,
                                     int Cin) {
@@ -1048,8 +1197,15 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
 int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, CONV_BMT); }
 
 static bool wgrad_use192(int NC) { return NC % 192 == 0 && NC % 128 != 0; }
+// Strip kernel (conv_wgrad3_kernel) for the 64-output-channel layer, where it is 8 % faster than the one-tap-per-tile
+// kernels (1.62 -> 1.48 ms); with 128-row tiles it measured 3-4 % slower than conv_wgrad_kernel<2,2> (more LDS reads per
+// MFMA than its paired reads) and is not used.  ACVAE_WGRAD_STRIP = 0 / 2 force it off / on for every layer (A/B).
+static bool wgrad_strip(int NC, int Cout) {
+  static const int mode = getenv("ACVAE_WGRAD_STRIP") ? atoi(getenv("ACVAE_WGRAD_STRIP")) : 1;
+  return NC % 576 == 0 && (mode == 2 || (mode == 1 && Cout <= 64));
+}
 static int wgrad_splits(int M, int Cout, int NC) {
-  const bool narrow = Cout <= 64, w192 = wgrad_use192(NC);
+  const bool narrow = Cout <= 64, w192 = wgrad_use192(NC) || wgrad_strip(NC, Cout);
   const long tiles = w192 ? (long)cdiv(Cout, narrow ? 64 : 128) * (NC / 192)
                           : (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
   // Resident workgroups per CU of the kernel variant (256 threads; from the compiler's resource report: 120 / 111 VGPRs
@@ -1085,7 +1241,18 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
   if ((long)(M + 4096) * (W > H ? W : H) >= (1L << 40)) return ACVAE_EUNSUPPORTED;   // FastDiv range
   ConvKMajorLoader bl{X, scale, shift, H, W, Cin, M, NC, FastDiv::make(W), FastDiv::make(H)};
   prof_begin(ACVAE_PROF_CONV_WGRAD, st);
-  if (wgrad_use192(NC)) {
+  if (wgrad_strip(NC, Cout)) {
+    const FastDiv fw = FastDiv::make(W), fh = FastDiv::make(H);
+    if (Cout <= 64) {
+      dim3 grid(cdiv(Cout, 64), NC / 192, s);
+      hipLaunchKernelGGL((conv_wgrad3_kernel<1>), grid, dim3(256), 0, st, dY, X, scale, shift, slab, M, Cout, H, W, Cin,
+                         fw, fh, k_per);
+    } else {
+      dim3 grid(cdiv(Cout, 128), NC / 192, s);
+      hipLaunchKernelGGL((conv_wgrad3_kernel<2>), grid, dim3(256), 0, st, dY, X, scale, shift, slab, M, Cout, H, W, Cin,
+                         fw, fh, k_per);
+    }
+  } else if (wgrad_use192(NC)) {
     if (Cout <= 64) {
       dim3 grid(cdiv(Cout, 64), NC / 192, s);
       hipLaunchKernelGGL((conv_wgrad192_kernel<1>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
