@@ -7,7 +7,7 @@ struct DropoutSpec {
   float p;              // drop probability; 0 disables
   const uint8_t* mask;  // optional explicit keep-mask in the reference's NCHW / [N,C] order (parity tests)
   uint64_t seed;        // Philox key when mask == nullptr
-  uint32_t site;        // dropout call-site id (0..5 in Cnn10.forward order)
+  uint32_t site;        // dropout call-site id in forward order (0..5 for Cnn10, 0..7 for Cnn14_16k)
 };
 
 // upstream of a BN+ReLU output in the backward: UP_PLAIN = dO as is; UP_POOL = through dropout + 2x2 average pool;

@@ -116,7 +116,7 @@ int acvae_mse_bwd(const float* a, const float* b, const float* grad_out, float* 
  *   embed_pooled.{weight,bias}                                   (55 entries; weights in OIHW).
  * training != 0: BatchNorm uses batch statistics and updates the running buffers (momentum 0.1,
  * unbiased variance) and dropout (p_block after every block, p_fc around embed_pooled) is applied,
- * drawn from Philox(seed) unless `masks` supplies the 6 keep-masks explicitly (uint8, the reference's
+ * drawn from Philox(seed) unless `masks` supplies the 6 (Cnn14_16k: 8) keep-masks explicitly (uint8, the reference's
  * NCHW / [N,512] order: parity tests).  `saved` (acvae_encoder_saved_bytes) carries activations from
  * fwd to bwd; `scratch` (acvae_encoder_scratch_bytes) is free between calls.  Gradients are WRITTEN
  * (not accumulated) for every conv / bn weight and bias; embed_pooled receives none (its output is
