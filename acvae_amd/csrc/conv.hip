@@ -465,7 +465,7 @@ struct alignas(16) WgStripSmem {
 };
 
 template <int EM>
-__global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+__global__ __launch_bounds__(256, 3) void conv_wgrad3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ slab,
                                                              int M, int Cout, int H, int W, int C, FastDiv dW_,
@@ -565,6 +565,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(const float* __rest
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < nk) issue(k_begin + (ks + 1) * BKT);
+    if (EM == 2) {
+      // paired reads (as in tn_block): one ds_read_b64 gives two adjacent output rows / two adjacent channels, so MFMA tile
+      // e of the A side covers rows 2*rho + e and the two tiles of the wave's full tap (dx = 0 for wn = 0, dx = 2 for
+      // wn = 1) cover channels 2*li + e; the third tile is the wave's half of the centre tap (channels wn*32 + li)
+      const float* As = sm.a[cur] + lh * TM + wm * 64 + 2 * li;
+      const float* Sp = sm.s[cur] + (lh + 2 * wn) * 64 + 2 * li;      // strip row k + dx, dx = 2*wn
+      const float* Sc = sm.s[cur] + (lh + 1) * 64 + wn * 32 + li;     // centre tap
+      const float* Mk = sm.mk[cur] + wn * BKT + lh;
+#pragma unroll
+      for (int kk = 0; kk < BKT / 2; ++kk) {
+        const float2 af = *reinterpret_cast<const float2*>(As + kk * 2 * TM);
+        float2 bp = *reinterpret_cast<const float2*>(Sp + kk * 2 * 64);
+        const float bc = Sc[kk * 2 * 64];
+        const float m = Mk[kk * 2];
+        bp.x *= m; bp.y *= m;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bp.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bp.y, acc[0][1], 0, 0, 0);
+        acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bc, acc[0][2], 0, 0, 0);
+        acc[EM - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bp.x, acc[EM - 1][0], 0, 0, 0);
+        acc[EM - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bp.y, acc[EM - 1][1], 0, 0, 0);
+        acc[EM - 1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bc, acc[EM - 1][2], 0, 0, 0);
+      }
+    } else {
     const float* As = sm.a[cur] + lh * TM + wm * EM * 32 + li;
     const float* Ss = sm.s[cur] + lh * 64 + li;
     const float* Mk = sm.mk[cur] + lh;
@@ -584,10 +607,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    }
     if (ks + 1 < nk) stash(cur ^ 1);
     __syncthreads();
   }
   // slab[co][(dy*3 + dx)*C + c]
+  if (EM == 2) {
+#pragma unroll
+    for (int em = 0; em < 2; ++em)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = row0 + wm * 64 + 2 * rho + em;
+        if (m >= Cout) continue;
+        float* out = Cs + (long)m * NC + dyi * 3 * C + c0;
+        out[2 * wn * C + 2 * li + 0] = acc[em == 0 ? 0 : EM - 1][0][r];
+        out[2 * wn * C + 2 * li + 1] = acc[em == 0 ? 0 : EM - 1][1][r];
+        out[C + wn * 32 + li] = acc[em == 0 ? 0 : EM - 1][2][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < EM; ++i)
 #pragma unroll
@@ -1197,12 +1236,13 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
 int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, CONV_BMT); }
 
 static bool wgrad_use192(int NC) { return NC % 192 == 0 && NC % 128 != 0; }
-// Strip kernel (conv_wgrad3_kernel) for the 64-output-channel layer, where it is 8 % faster than the one-tap-per-tile
-// kernels (1.62 -> 1.48 ms); with 128-row tiles it measured 3-4 % slower than conv_wgrad_kernel<2,2> (more LDS reads per
-// MFMA than its paired reads) and is not used.  ACVAE_WGRAD_STRIP = 0 / 2 force it off / on for every layer (A/B).
+// Strip kernel (conv_wgrad3_kernel) whenever the input channels come in chunks of 64 (every layer but conv1): against the
+// one-tap-per-tile kernels it measured 1.62 -> 1.48 ms on the 64-output-channel layer and, with the paired LDS reads of
+// its 128-row variant, 1.335 -> 1.285 ms / 0.69 -> 0.655 ms on the wider ones.  ACVAE_WGRAD_STRIP = 0 turns it off,
+// 3 keeps it to the 64-output-channel layer (A/B).
 static bool wgrad_strip(int NC, int Cout) {
   static const int mode = getenv("ACVAE_WGRAD_STRIP") ? atoi(getenv("ACVAE_WGRAD_STRIP")) : 1;
-  return NC % 576 == 0 && (mode == 2 || (mode == 1 && Cout <= 64));
+  return NC % 576 == 0 && (mode == 1 || mode == 2 || (mode == 3 && Cout <= 64));
 }
 static int wgrad_splits(int M, int Cout, int NC) {
   const bool narrow = Cout <= 64, w192 = wgrad_use192(NC) || wgrad_strip(NC, Cout);
