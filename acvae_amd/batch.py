@@ -15,11 +15,15 @@ def _pad_stack(seqs):
     """Zero-pad tensors that differ in their first dimension into one float32 [n, max...] tensor (captions therefore
     arrive as floats, F10) and return it with the first-dimension sizes as a numpy array (caption_dataset.py:286-298)."""
     shapes = np.array([tuple(t.shape) for t in seqs])
-    out = torch.zeros((len(seqs),) + tuple(shapes.max(axis=0)))
+    # numpy row copies: torch's copy_/zeros fan each of these small operations out over the whole intra-op thread pool,
+    # which costs tens of milliseconds per batch on a host with fewer cores than pool threads
+    out = np.empty((len(seqs),) + tuple(shapes.max(axis=0)), dtype=np.float32)
     sizes = shapes[:, 0]
     for row, t in enumerate(seqs):
-        out[row, :sizes[row]] = t[:sizes[row]]
-    return out, sizes
+        n = sizes[row]
+        np.copyto(out[row, :n], t.detach().numpy()[:n], casting="unsafe")
+        out[row, n:] = 0
+    return torch.from_numpy(out), sizes
 
 
 def collate_fn(length_idxs: List = [], sort_idx=None):

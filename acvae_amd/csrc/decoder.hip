@@ -824,6 +824,53 @@ extern "C" int acvae_attn_precompute(const void* const* params, int which, const
   return gemm(mem, E, P(TP_P_ATT_W) + E, 2 * E, P(TP_P_ATT_B), encproj, E, N * S, E, E, 0, st);
 }
 
+namespace {
+// One prior / decoder step over R = Nm * Tq rows: row r = n * Tq + j attends over memory n (Tq = 1: one memory per row,
+// the sub-module API; Tq = beam: the beams of a clip share its memory, no replicated copy).
+int prior_step(const void* const* params, const int64_t* word, const float* mem, const int64_t* mem_lens, const float* ep,
+               const float* h_prev, const float* c_prev, const float* last_z, const float* eps, float* mean, float* logv,
+               float* z, float* h_out, float* c_out, float* attw, float* sc, const StepLayout& L, int Nm, int Tq, int S,
+               int E, int V, const Ctx& st) {
+  auto P = [&](int i) { return (const float*)params[i]; };
+  const int N = Nm * Tq, Hp = E;
+  float* rnn = sc + L.rnn;
+  float* q = sc + L.q;
+  float* gates = sc + L.gates;
+  float* ml = sc + L.ml;
+  ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_P_EMB), V, rnn, 3 * E, N, E, st));
+  ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_ATT_W), 2 * E, nullptr, q, E, N, E, E, 0, st));
+  ACVAE_TRY(acvae_attn_fwd(q, (long)Tq * E, E, ep, mem, mem_lens, P(TP_P_ATT_V), rnn + E, (long)Tq * 3 * E, 3 * E, attw,
+                           (long)Tq * S, S, Nm, Tq, S, E, E, st));
+  ACVAE_TRY(acvae::copy_rows(rnn + 2 * E, 3 * E, last_z, E, N, E, st));
+  ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_WIH), 3 * E, P(TP_P_BIH), gates, 4 * Hp, N, 4 * Hp, 3 * E, 0, st));
+  ACVAE_TRY(gemm(h_prev, Hp, P(TP_P_WHH), Hp, P(TP_P_BHH), gates, 4 * Hp, N, 4 * Hp, Hp, 1, st));
+  ACVAE_TRY(acvae::lstm_fwd(gates, 4 * Hp, c_prev, Hp, h_out, Hp, c_out, Hp, nullptr, 0, N, Hp, st));
+  ACVAE_TRY(gemm(h_out, Hp, P(TP_P_ML_W), Hp, P(TP_P_ML_B), ml, 2 * E, N, 2 * E, Hp, 0, st));
+  return acvae_reparam_fwd(ml, 2 * E, eps, E, mean, logv, z, E, nullptr, 0, N, E, st);
+}
+
+int decoder_step(const void* const* params, const int64_t* word, const float* h_prev, const float* mem,
+                 const int64_t* mem_lens, const float* ed, const float* z, float* logits, float* h_out, float* attw,
+                 float* rnn_input, float* sc, const StepLayout& L, int Nm, int Tq, int S, int E, int H, int A, int V,
+                 const Ctx& st) {
+  auto P = [&](int i) { return (const float*)params[i]; };
+  const int N = Nm * Tq;
+  float* q = sc + L.q;
+  float* gi = sc + L.gates;
+  float* gh = sc + L.gh;
+  ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_DEC_EMB), V, rnn_input, 3 * E, N, E, st));
+  ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_ATT_W), E + H, nullptr, q, A, N, A, H, 0, st));
+  ACVAE_TRY(acvae_attn_fwd(q, (long)Tq * A, A, ed, mem, mem_lens, P(TP_DEC_ATT_V), rnn_input + E, (long)Tq * 3 * E, 3 * E,
+                           attw, (long)Tq * S, S, Nm, Tq, S, A, E, st));
+  ACVAE_TRY(acvae::copy_rows(rnn_input + 2 * E, 3 * E, z, E, N, E, st));
+  ACVAE_TRY(gemm(rnn_input, 3 * E, P(TP_DEC_WIH), 3 * E, P(TP_DEC_BIH), gi, 3 * H, N, 3 * H, 3 * E, 0, st));
+  ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_WHH), H, P(TP_DEC_BHH), gh, 3 * H, N, 3 * H, H, 0, st));
+  ACVAE_TRY(acvae::gru_fwd(gi, 3 * H, gh, 3 * H, h_prev, H, h_out, H, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, N,
+                           H, st));
+  return gemm(h_out, H, P(TP_DEC_CLS_W), H, P(TP_DEC_CLS_B), logits, V, N, V, H, 0, st);
+}
+}  // namespace
+
 extern "C" int acvae_prior_step_fwd(const void* const* params, const int64_t* word, const float* mem,
                                     const int64_t* mem_lens, const float* encproj_p, const float* h_prev,
                                     const float* c_prev, const float* last_z, const float* eps, float* mean, float* logv,
@@ -838,26 +885,13 @@ extern "C" int acvae_prior_step_fwd(const void* const* params, const int64_t* wo
   float* sc = (float*)scratch_v;
   Ctx st{(hipStream_t)stream, sc + L.skws};
   ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
-  auto P = [&](int i) { return (const float*)params[i]; };
-  const int Hp = E;
-  float* rnn = sc + L.rnn;
-  float* q = sc + L.q;
-  float* gates = sc + L.gates;
-  float* ml = sc + L.ml;
   const float* ep = encproj_p;
   if (!ep) {
-    ACVAE_TRY(gemm(mem, E, P(TP_P_ATT_W) + E, 2 * E, P(TP_P_ATT_B), sc + L.encproj, E, N * S, E, E, 0, st));
+    ACVAE_TRY(acvae_attn_precompute(params, 1, mem, sc + L.encproj, N, S, E, E, E, stream));
     ep = sc + L.encproj;
   }
-  ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_P_EMB), V, rnn, 3 * E, N, E, st));
-  ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_ATT_W), 2 * E, nullptr, q, E, N, E, E, 0, st));
-  ACVAE_TRY(acvae_attn_fwd(q, E, 0, ep, mem, mem_lens, P(TP_P_ATT_V), rnn + E, 3 * E, 0, attw, S, 0, N, 1, S, E, E, st));
-  ACVAE_TRY(acvae::copy_rows(rnn + 2 * E, 3 * E, last_z, E, N, E, st));
-  ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_WIH), 3 * E, P(TP_P_BIH), gates, 4 * Hp, N, 4 * Hp, 3 * E, 0, st));
-  ACVAE_TRY(gemm(h_prev, Hp, P(TP_P_WHH), Hp, P(TP_P_BHH), gates, 4 * Hp, N, 4 * Hp, Hp, 1, st));
-  ACVAE_TRY(acvae::lstm_fwd(gates, 4 * Hp, c_prev, Hp, h_out, Hp, c_out, Hp, nullptr, 0, N, Hp, st));
-  ACVAE_TRY(gemm(h_out, Hp, P(TP_P_ML_W), Hp, P(TP_P_ML_B), ml, 2 * E, N, 2 * E, Hp, 0, st));
-  return acvae_reparam_fwd(ml, 2 * E, eps, E, mean, logv, z, E, nullptr, 0, N, E, st);
+  return prior_step(params, word, mem, mem_lens, ep, h_prev, c_prev, last_z, eps, mean, logv, z, h_out, c_out, attw, sc,
+                    L, N, 1, S, E, V, st);
 }
 
 extern "C" int acvae_decoder_step_fwd(const void* const* params, const int64_t* word, const float* h_prev,
@@ -872,23 +906,134 @@ extern "C" int acvae_decoder_step_fwd(const void* const* params, const int64_t* 
   float* sc = (float*)scratch_v;
   Ctx st{(hipStream_t)stream, sc + L.skws};
   ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
-  auto P = [&](int i) { return (const float*)params[i]; };
-  float* q = sc + L.q;
-  float* gi = sc + L.gates;
-  float* gh = sc + L.gh;
   const float* ed = encproj_d;
   if (!ed) {
-    ACVAE_TRY(gemm(mem, E, P(TP_DEC_ATT_W) + H, E + H, P(TP_DEC_ATT_B), sc + L.encproj, A, N * S, A, E, 0, st));
+    ACVAE_TRY(acvae_attn_precompute(params, 0, mem, sc + L.encproj, N, S, E, H, A, stream));
     ed = sc + L.encproj;
   }
-  ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_DEC_EMB), V, rnn_input, 3 * E, N, E, st));
-  ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_ATT_W), E + H, nullptr, q, A, N, A, H, 0, st));
-  ACVAE_TRY(acvae_attn_fwd(q, A, 0, ed, mem, mem_lens, P(TP_DEC_ATT_V), rnn_input + E, 3 * E, 0, attw, S, 0, N, 1, S, A,
-                           E, st));
-  ACVAE_TRY(acvae::copy_rows(rnn_input + 2 * E, 3 * E, z, E, N, E, st));
-  ACVAE_TRY(gemm(rnn_input, 3 * E, P(TP_DEC_WIH), 3 * E, P(TP_DEC_BIH), gi, 3 * H, N, 3 * H, 3 * E, 0, st));
-  ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_WHH), H, P(TP_DEC_BHH), gh, 3 * H, N, 3 * H, H, 0, st));
-  ACVAE_TRY(acvae::gru_fwd(gi, 3 * H, gh, 3 * H, h_prev, H, h_out, H, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, N,
-                           H, st));
-  return gemm(h_out, H, P(TP_DEC_CLS_W), H, P(TP_DEC_CLS_B), logits, V, N, V, H, 0, st);
+  return decoder_step(params, word, h_prev, mem, mem_lens, ed, z, logits, h_out, attw, rnn_input, sc, L, N, 1, S, E, H,
+                      A, V, st);
+}
+
+// ==========================================================================================
+// validation beam search as ONE call (models/vae_model.py:896-995): all clips advance together, the
+// beams of a clip share its memory, and nothing but kernels is enqueued per step.  Instead of re-gathering the word and
+// attention-weight histories by prev_word_inds every step (:917-921, :979), each step's parent row, word and weights are
+// kept and beam 0 is traced back once at the end, which yields the same seqs[0] / attn_weights[0] (:990-995).
+// ==========================================================================================
+namespace {
+struct BeamLayout { long step, encd, encp, h, hp, cp, lz, mean, logv, z, h2, hp2, cp2, attp, logits, rnn, lse, topk, scores,
+                    attw, words, total; };
+int beam_layout(int N, int beam, int T, int S, int E, int H, int A, int V, BeamLayout& L) {
+  if (N <= 0 || beam <= 0 || T <= 0) return ACVAE_EINVAL;
+  StepLayout sl;
+  const long R = (long)N * beam;
+  if (R > (1L << 20)) return ACVAE_EUNSUPPORTED;
+  ACVAE_TRY(step_layout((int)R, S, E, H, A, V, sl));
+  Bump b;
+  L.step = b.take(sl.total);
+  L.encd = b.take((long)N * S * A);
+  L.encp = b.take((long)N * S * E);
+  L.h = b.take(R * H); L.hp = b.take(R * E); L.cp = b.take(R * E); L.lz = b.take(R * E);
+  L.mean = b.take(R * E); L.logv = b.take(R * E); L.z = b.take(R * E);
+  L.h2 = b.take(R * H); L.hp2 = b.take(R * E); L.cp2 = b.take(R * E);
+  L.attp = b.take(R * S);
+  L.logits = b.take(R * V);
+  L.rnn = b.take(R * 3 * E);
+  L.lse = b.take(R);
+  L.topk = b.take(R);
+  L.scores = b.take(R * V);
+  L.attw = b.take((long)T * R * S);
+  L.words = b.take(2 * ((long)(3 * T + 1) * R));        // int64: word [R], then per step idx / parent / word [T][R]
+  L.total = b.off;
+  return ACVAE_OK;
+}
+
+struct GatherJob { const float* src; float* dst; int width; };
+__global__ __launch_bounds__(256) void beam_gather_kernel(GatherJob a, GatherJob b, GatherJob c, GatherJob d,
+                                                          const int64_t* __restrict__ parent) {
+  const GatherJob j = blockIdx.y == 0 ? a : blockIdx.y == 1 ? b : blockIdx.y == 2 ? c : d;
+  const long r = blockIdx.x, p = parent[r];
+  for (int i = threadIdx.x; i < j.width; i += blockDim.x) j.dst[r * j.width + i] = j.src[p * j.width + i];
+}
+
+// one workgroup per clip: follow beam 0's parents from the last step to the first
+__global__ __launch_bounds__(256) void beam_trace_kernel(const int64_t* __restrict__ parent, const int64_t* __restrict__ word,
+                                                         const float* __restrict__ attw, int64_t* __restrict__ seqs,
+                                                         float* __restrict__ attw_out, long hist_stride, int R, int beam, int T,
+                                                         int S) {
+  const int n = blockIdx.x;
+  long r = (long)n * beam;
+  for (int t = T - 1; t >= 0; --t) {
+    const long p = parent[t * hist_stride + r];
+    if (threadIdx.x == 0) seqs[(long)n * T + t] = word[t * hist_stride + r];
+    const float* w = attw + ((long)t * R + p) * S;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) attw_out[((long)n * S + s) * T + t] = w[s];
+    r = p;
+  }
+}
+__global__ void fill_words_kernel(int64_t* w, int64_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = v;
+}
+}  // namespace
+
+extern "C" int64_t acvae_beam_search_scratch_bytes(int N, int beam, int max_length, int S, int E, int H, int A, int V) {
+  BeamLayout L;
+  return beam_layout(N, beam, max_length, S, E, H, A, V, L) == ACVAE_OK ? L.total * 4 : -1;
+}
+
+extern "C" int acvae_beam_search(const void* const* params, const float* mem, const int64_t* mem_lens, const float* eps,
+                                 int64_t start_idx, int64_t* seqs, float* attw_out, void* scratch_v, int64_t scratch_bytes,
+                                 int N, int beam, int max_length, int S, int E, int H, int A, int V, void* stream) {
+  BeamLayout L;
+  ACVAE_TRY(beam_layout(N, beam, max_length, S, E, H, A, V, L));
+  if (!params || !mem || !mem_lens || !eps || !seqs || !attw_out || !scratch_v) return ACVAE_EINVAL;
+  if (start_idx < 0 || start_idx >= V || beam > 64 || H != E) return ACVAE_EINVAL;   // the prior LSTM is E wide
+  if (scratch_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  StepLayout SL;
+  const int R = N * beam, T = max_length;
+  ACVAE_TRY(step_layout(R, S, E, H, A, V, SL));
+  float* sc = (float*)scratch_v;
+  float* ssc = sc + L.step;
+  Ctx st{(hipStream_t)stream, ssc + SL.skws};
+  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  ACVAE_TRY(acvae_attn_precompute(params, 0, mem, sc + L.encd, N, S, E, H, A, stream));
+  ACVAE_TRY(acvae_attn_precompute(params, 1, mem, sc + L.encp, N, S, E, E, E, stream));
+  float *h = sc + L.h, *hp = sc + L.hp, *cp = sc + L.cp, *lz = sc + L.lz;
+  float *h2 = sc + L.h2, *hp2 = sc + L.hp2, *cp2 = sc + L.cp2, *z = sc + L.z;
+  float* topk = sc + L.topk;
+  int64_t* word = (int64_t*)(sc + L.words);
+  int64_t* hist = word + R;                              // [T][3][R]: flat index, parent row, word
+  ACVAE_TRY(zero(h, (long)R * H, st));
+  ACVAE_TRY(zero(hp, (long)R * E, st));
+  ACVAE_TRY(zero(cp, (long)R * E, st));
+  ACVAE_TRY(zero(lz, (long)R * E, st));
+  ACVAE_TRY(zero(topk, R, st));
+  hipLaunchKernelGGL(fill_words_kernel, dim3((R + 255) / 256), dim3(256), 0, st.s, word, start_idx, R);
+  const int64_t* w_t = word;
+  for (int t = 0; t < T; ++t) {
+    float* attw_t = sc + L.attw + (long)t * R * S;
+    int64_t* idx_t = hist + (long)t * 3 * R;
+    int64_t* par_t = idx_t + R;
+    int64_t* nxt_t = par_t + R;
+    ACVAE_TRY(prior_step(params, w_t, mem, mem_lens, sc + L.encp, hp, cp, lz, eps + (long)t * R * E, sc + L.mean,
+                         sc + L.logv, z, hp2, cp2, sc + L.attp, ssc, SL, N, beam, S, E, V, st));
+    ACVAE_TRY(decoder_step(params, w_t, h, mem, mem_lens, sc + L.encd, z, sc + L.logits, h2, attw_t, sc + L.rnn, ssc, SL,
+                           N, beam, S, E, H, A, V, st));
+    ACVAE_TRY(acvae_row_logsoftmax_argmax(sc + L.logits, V, V, nullptr, nullptr, sc + L.lse, 1, 1, R, 1, V, stream));
+    ACVAE_TRY(acvae_logprob_add(sc + L.logits, V, sc + L.lse, topk, sc + L.scores, R, V, stream));
+    ACVAE_TRY(acvae_topk_flat_batched(sc + L.scores, (int64_t)beam * V, (int64_t)beam * V, beam, V, topk, idx_t, par_t,
+                                      nxt_t, N, beam, stream));
+    if (t + 1 < T) {                                     // vae_model.py:961-968: next step's states follow their parents
+      hipLaunchKernelGGL(beam_gather_kernel, dim3(R, 4), dim3(256), 0, st.s, GatherJob{h2, h, H}, GatherJob{hp2, hp, E},
+                         GatherJob{cp2, cp, E}, GatherJob{z, lz, E}, par_t);
+      w_t = nxt_t;
+    }
+  }
+  // hist rows are [idx | parent | word] per step: strided views for the trace
+  hipLaunchKernelGGL(beam_trace_kernel, dim3(N), dim3(256), 0, st.s, hist + R, hist + 2 * R, sc + L.attw, seqs, attw_out,
+                     3L * R, R, beam, T, S);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
 }

@@ -170,55 +170,29 @@ class Hybrid_VAEModel(CaptionModel):
             _lib.call("acvae_gemm_nt", mem_all, Ee, self.ln.weight, Ee, self.ln.bias, proj, self.decoder.embed_size,
                       Nn * Ss, self.decoder.embed_size, Ee, 0, _lib.current_stream())
             mem_all = proj
-        lens_all = torch.as_tensor(encoded["audio_embeds_lens"]).to(torch.long)
+        lens_all = torch.as_tensor(encoded["audio_embeds_lens"]).to(device=dev, dtype=torch.long).contiguous()
         N, S, E = mem_all.shape
         V = self.vocab_size
-        R = N * beam_size
+        H, A = self.decoder.model.hidden_size, self.decoder.attn.attn_size
         replay = self.noise.get("eps_beam") if self.noise is not None else None
         self.noise = None
         # The reference walks the clips one after the other; their searches are independent, so all N x beam rows advance
-        # together here: one prior / decoder step per time step for the whole batch, one top-k workgroup per clip, state
-        # gathers by batch-global parent row.  Its noise order (clip-major: text_encoder.py:259 inside the clip loop) is
-        # kept by drawing eps[clip][t] up front.
+        # together inside one library call.  Its noise order (clip-major: text_encoder.py:259 inside the clip loop) is
+        # kept by drawing eps[clip][t] in that order on the host; the library reads it step-major.
         if replay is None:
-            eps_all = _lib.h2d_fill((N, max_length, beam_size, E), torch.float32, dev,
-                                    lambda buf: [torch.randn(beam_size, E, out=buf[i, t]) for i in range(N)
+            eps_all = _lib.h2d_fill((max_length, N, beam_size, E), torch.float32, dev,
+                                    lambda buf: [torch.randn(beam_size, E, out=buf[t, i]) for i in range(N)
                                                  for t in range(max_length)])
         else:
-            eps_all = _lib.h2d(replay, dev, torch.float32)
-        mem = mem_all.repeat_interleave(beam_size, dim=0).contiguous()
-        lens = lens_all.repeat_interleave(beam_size)
-        state = self.decoder.init_hidden(R).to(dev)
-        hid = self.pnet.init_hidden(R, dev)
-        last_z = torch.zeros(R, E, device=dev)
-        top_k = torch.zeros(R, device=dev)
-        lse = torch.empty(R, device=dev)
-        scores = torch.empty(R, V, device=dev)
-        vals = torch.empty(R, device=dev)
-        idx, prev, nxt = (torch.empty(R, dtype=torch.long, device=dev) for _ in range(3))
-        st = _lib.current_stream
-        seqs = attw = None
-        for t in range(max_length):
-            if t == 0:
-                w = torch.full((R,), self.start_idx, dtype=torch.long, device=dev)
-            else:
-                w = nxt.clone()
-                state = state[:, prev].contiguous()
-                hid = (hid[0][:, prev].contiguous(), hid[1][:, prev].contiguous())
-                last_z = last_z[prev].contiguous()
-            pn = self.pnet(w.unsqueeze(1), mem, hid, last_z, lens, eps=eps_all[:, t].reshape(R, E))
-            dn = self.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
-            logits = dn["logits"].squeeze(1)
-            _lib.call("acvae_row_logsoftmax_argmax", logits, V, V, None, None, lse, 1, 1, R, 1, V, st())
-            _lib.call("acvae_logprob_add", logits, V, lse, top_k, scores, R, V, st())
-            _lib.call("acvae_topk_flat_batched", scores, beam_size * V, beam_size * V, beam_size, V, vals, idx, prev, nxt,
-                      N, beam_size, st())
-            top_k = vals.clone()
-            seqs = nxt.unsqueeze(1).clone() if t == 0 else torch.cat([seqs[prev], nxt.unsqueeze(1)], dim=1)
-            w_t = dn["weights"].unsqueeze(2)                              # [R,S,1]
-            attw = w_t if t == 0 else torch.cat([attw, w_t], dim=2)[prev]
-            state, hid, last_z = dn["state"], pn["hiddens_state"], pn["z"]
-        return {"seqs": seqs[0::beam_size].contiguous(), "attn_weights": attw[0::beam_size].contiguous()}
+            eps_all = _lib.h2d(torch.as_tensor(replay).reshape(N, max_length, beam_size, E).transpose(0, 1).contiguous(),
+                               dev, torch.float32)
+        seqs = torch.empty(N, max_length, dtype=torch.long, device=dev)
+        attw = torch.empty(N, S, max_length, device=dev)
+        sb = _lib.call("acvae_beam_search_scratch_bytes", N, beam_size, max_length, S, E, H, A, V)
+        scratch = scratch_buffer(sb, dev)
+        _lib.call("acvae_beam_search", ptr_table(self._text_table()), mem_all, lens_all, eps_all, int(self.start_idx), seqs,
+                  attw, scratch, sb, N, beam_size, max_length, S, E, H, A, V, _lib.current_stream())
+        return {"seqs": seqs, "attn_weights": attw}
 
     @torch.no_grad()
     def diverse_beam_search(self, encoded, max_length, beam_size, group_size, diversity_lambda, temperature, group_nbest):

@@ -261,6 +261,15 @@ int acvae_topk_flat(const float* x, int64_t n, int k, int V, float* vals, int64_
  * batch's beam rows when row_base = beam. */
 int acvae_topk_flat_batched(const float* x, int64_t n, int64_t group_stride, int k, int V, float* vals, int64_t* idx,
                             int64_t* row, int64_t* col, int groups, int row_base, void* stream);
+/* Validation beam search as one call: Hybrid_VAEModel.beam_search, models/vae_model.py:896-995, for
+ * all N clips at once.  mem [N,S,E] (after the optional `ln` projection), mem_lens [N], eps [max_length][N*beam][E]
+ * (the N(0,1) draws of PriorRNN.forward, text_encoder.py:259, step-major), start_idx = vocabulary index of <start>.
+ * Outputs, as the reference keeps them (beam 0 of each clip, :990-995): seqs int64 [N,max_length],
+ * attn_weights [N,S,max_length].  No host synchronisation; scratch of acvae_beam_search_scratch_bytes(). */
+int64_t acvae_beam_search_scratch_bytes(int N, int beam, int max_length, int S, int E, int H, int A, int V);
+int acvae_beam_search(const void* const* params, const float* mem, const int64_t* mem_lens, const float* eps,
+                      int64_t start_idx, int64_t* seqs, float* attn_weights, void* scratch, int64_t scratch_bytes, int N,
+                      int beam, int max_length, int S, int E, int H, int A, int V, void* stream);
 /* Diverse beam search, models/word_model.py:344-348 with add_diversity :298-312: per beam row
  *   out[n,c] = log_softmax(log_softmax(logits[n]) / temperature)[c] - diversity_lambda * counts[c] + prev[n]
  * counts (may be NULL: first group) = how often the earlier groups chose word c at this local step: one vector [V] for
