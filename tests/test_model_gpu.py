@@ -214,6 +214,55 @@ def test_g9_beam_search_token_exact():
     assert np.array_equal(o["seqs"].cpu().numpy(), g["seqs"])
 
 
+def test_beam_search_call_equals_the_step_api_loop():
+    """The one-call beam search against the reference's loop written with the sub-module step API (PriorRNN.forward /
+    decoder.forward per step, state and history re-gathered by prev_word_inds every step, vae_model.py:905-921,961-979)
+    on a ragged batch: same tokens and the same attention-weight history, bit for bit."""
+    from acvae_amd import _lib
+    V, E, beam, ml = 300, 512, 3, 12
+    torch.manual_seed(3)
+    model = build_model(V, E)
+    model.eval()
+    feats = torch.randn(5, 160, 64)
+    feat_lens = np.array([160, 150, 97, 64, 33])
+    eps = torch.randn(5, ml, beam, E)
+    with torch.no_grad():
+        enc = model.encoder(feats.cuda(), feat_lens.copy())
+        model.noise = dict(eps_beam=eps)
+        got = model.beam_search(dict(enc), ml, beam)
+        mem1, lens1 = enc["audio_embeds"].contiguous(), torch.as_tensor(enc["audio_embeds_lens"])
+        N, S, _ = mem1.shape
+        R = N * beam
+        mem = mem1.repeat_interleave(beam, dim=0).contiguous()
+        lens = lens1.repeat_interleave(beam)
+        state = model.decoder.init_hidden(R).cuda()
+        hid = model.pnet.init_hidden(R, "cuda")
+        last_z = torch.zeros(R, E, device="cuda")
+        top_k = torch.zeros(R, device="cuda")
+        seqs = attw = None
+        w = torch.full((R,), model.start_idx, dtype=torch.long, device="cuda")
+        for t in range(ml):
+            pn = model.pnet(w.unsqueeze(1), mem, hid, last_z, lens, eps=eps[:, t].reshape(R, E))
+            dn = model.decoder(word=w.unsqueeze(1), state=state, enc_mem=mem, enc_mem_lens=lens, z=pn["z"])
+            logits = dn["logits"].squeeze(1).contiguous()
+            lse, scores, vals = torch.empty(R, device="cuda"), torch.empty(R, V, device="cuda"), torch.empty(R, device="cuda")
+            idx, prev, w = (torch.empty(R, dtype=torch.long, device="cuda") for _ in range(3))
+            st = _lib.current_stream()
+            _lib.call("acvae_row_logsoftmax_argmax", logits, V, V, None, None, lse, 1, 1, R, 1, V, st)
+            _lib.call("acvae_logprob_add", logits, V, lse, top_k, scores, R, V, st)
+            _lib.call("acvae_topk_flat_batched", scores, beam * V, beam * V, beam, V, vals, idx, prev, w, N, beam, st)
+            top_k = vals
+            seqs = w.unsqueeze(1) if t == 0 else torch.cat([seqs[prev], w.unsqueeze(1)], dim=1)
+            w_t = dn["weights"].unsqueeze(2)
+            attw = (w_t if t == 0 else torch.cat([attw, w_t], dim=2))[prev]
+            state = dn["state"][:, prev].contiguous()
+            hid = (pn["hiddens_state"][0][:, prev].contiguous(), pn["hiddens_state"][1][:, prev].contiguous())
+            last_z = pn["z"][prev].contiguous()
+    assert np.array_equal(got["seqs"].cpu().numpy(), seqs[0::beam].cpu().numpy())
+    assert torch.equal(got["attn_weights"].cpu(), attw[0::beam].cpu())
+    assert got["attn_weights"].shape == (N, S, ml)
+
+
 DBS_CASES = [dict(beam_size=4, group_size=2), dict(beam_size=6, group_size=3, diversity_lambda=0.8, temperature=1.5,
              group_nbest=False), dict(), dict(beam_size=6, group_size=2, diversity_lambda=2.0)]
 
