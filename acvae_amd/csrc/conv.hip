@@ -199,10 +199,11 @@ struct ConvStatsEpilogue {
 constexpr int CV_BMT = 128;
 constexpr int CV_ROWS = CV_BMT + 2;
 constexpr int CV_AR = 5;            // float4 slots per loader thread for the strip: 4 full passes + rows 128, 129
-template <int BN>
+// 53.8 KB for BN = 64 with LDS-DMA panels (three workgroups per CU), 74.9 KB for BN = 128 (two)
+template <int BN, bool BDMA>
 struct alignas(16) ConvSmem {
-  alignas(16) float a[2][(CV_ROWS + 2) * LDS_LD];
-  alignas(16) float b[2][BN * LDS_LD];
+  alignas(16) float a[2][CV_ROWS * LDS_LD];
+  alignas(16) float b[2][BN * (BDMA ? BK : LDS_LD)];
 };
 
 struct ConvStripLoader {   // strip row j <-> pixel q = row0 - 1 + j, read at vertical tap offset dy
@@ -261,9 +262,17 @@ struct ConvStripLoader {   // strip row j <-> pixel q = row0 - 1 + j, read at ve
 // read address by the matrix waves.  Needs N % BN == 0 (an LDS-DMA cannot zero-fill).
 template <int BN, bool BDMA, class Epilogue>
 __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<true, BN / 32> bl, int M, int N, int C,
-                                              int W, int block_m, int block_n, const Epilogue& ep, ConvSmem<BN>& sm) {
-  constexpr int NTN = BN / 64;     // MFMA tiles per matrix wave along N
-  constexpr int NMW = CV_BMT / 32; // matrix wavefronts (2 x 2)
+                                              int W, int block_m, int block_n, const Epilogue& ep,
+                                              ConvSmem<BN, BDMA>& sm) {
+  // Matrix wavefronts 2 x 2: (64-row half, BN/2-column half).  KSPLIT = the second index splits the 32-channel K-step
+  // instead, every wave a 64 x 64 tile with fewer LDS fragment reads per MFMA, halves added through LDS before the
+  // epilogue; measured for BN = 64: 1353 -> 1390 us, i.e. that kernel is not bound by LDS reads (nor by occupancy: three
+  // workgroups per CU instead of two changed nothing either) but by its strip fetches - K = 9 * 64 is only 18 stages
+  // per tile and every tile reads its image rows three times.  Off.
+  constexpr bool KSPLIT = false;
+  constexpr int NTN = KSPLIT ? 2 : BN / 64;   // MFMA tiles per matrix wave along N
+  constexpr int NG = KSPLIT ? BK / 16 : BK / 8;   // 8-channel groups per wave and K-step
+  constexpr int NMW = CV_BMT / 32;
   constexpr int BR = BN / RPP;     // B rows per loader thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool matrix_wave = wave < NMW;
@@ -349,6 +358,9 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     // ------------------------------------------------------------------ matrix wavefronts
     // border masks of this lane's two tile rows: pixel p = row0 + wm*64 + i*32 + li
     bool okl[2], okr[2];
+    // 16-byte chunk of this lane's first weight fragment in the swizzled panel row: (K-half, k pair) ^ (row & 7); the
+    // group index g * 2 occupies other bits than (4 * K-half + lh), so it can be xor-ed in
+    const int bsw = ((KSPLIT ? 4 * wn : 0) + lh) ^ (li & 7);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int w = (row0 + wm * 64 + i * 32 + li) % W;
@@ -356,13 +368,14 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     }
     __syncthreads();
     for (int grp = 0; grp < ngrp; ++grp) {
-      const float* Ag = sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh;
+      const float* Ag = sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh + (KSPLIT ? wn * (BK / 2) : 0);
 #pragma unroll
       for (int dxi = 0; dxi < 3; ++dxi) {
         const float* As = Ag + dxi * LDS_LD;           // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
-        const float* Bs = sm.b[(grp * 3 + dxi) & 1] + (wn * (BN / 2) + li) * (BDMA ? BK : LDS_LD) + (BDMA ? 0 : 4 * lh);
+        const float* Bs = sm.b[(grp * 3 + dxi) & 1] + ((KSPLIT ? 0 : wn * (BN / 2)) + li) * (BDMA ? BK : LDS_LD) +
+                          (BDMA ? 0 : 4 * lh + (KSPLIT ? wn * (BK / 2) : 0));
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        for (int g = 0; g < NG; ++g) {
           float4 af[2], bf[NTN];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
@@ -372,7 +385,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
           }
 #pragma unroll
           for (int j = 0; j < NTN; ++j)
-            bf[j] = BDMA ? *reinterpret_cast<const float4*>(Bs + j * 32 * BK + (((g * 2 + lh) ^ (li & 7)) << 2))
+            bf[j] = BDMA ? *reinterpret_cast<const float4*>(Bs + j * 32 * BK + (((g * 2) ^ bsw) << 2))
                          : *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -389,6 +402,29 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     }
   }
   // every wave is past the last LDS access (barrier above): LDS is free for the epilogue
+  if (KSPLIT) {
+    float* red = &sm.a[0][0];       // 2 row halves x 4 tiles x 16 registers x 64 lanes = 32 KB of the 37 KB strip ring
+    if (matrix_wave && wn == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((wm * 2 + i) * NTN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (matrix_wave && wn == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((wm * 2 + i) * NTN + j) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+    ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, 0, li, lh, M, N, &sm.a[0][0], matrix_wave && wn == 0);
+    return;
+  }
   ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], matrix_wave);
 }
 
@@ -397,7 +433,7 @@ __global__ __launch_bounds__(nt_threads<CV_BMT>(), 2) void conv_igemm3_kernel(Co
                                                                               const float* __restrict__ Wp,
                                                                               ConvStatsEpilogue ep, int M, int Cout,
                                                                               int K) {
-  __shared__ ConvSmem<BN> sm;
+  __shared__ ConvSmem<BN, BDMA> sm;
   PlainLoader<true, BN / 32> bl{Wp, K, Cout, K};
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
