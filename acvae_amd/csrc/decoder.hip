@@ -12,6 +12,7 @@
 // GEMMs whenever the words are known up front (teacher forcing), and the classifier / log-softmax /
 // argmax run once over all N*Tc rows.  Buffers are batch-major [N,Tc,*] like the reference's outputs;
 // "step t" addresses column t with row stride Tc*C.
+#include <cstdlib>
 #include "common.h"
 #include "conv.h"
 #include "rnn.h"
@@ -194,12 +195,12 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   L.attws_p = b.take(L.attws_bytes / 4 + 64);
   L.dencproj_p = b.take((long)N * S * E); L.dvpart_p = b.take((long)N * E); L.dmem_p = b.take((long)N * S * E);
   L.drnn_p = b.take(R * 3 * E);
-  tn = 0;
-  mx(4 * Hp, 3 * E, (int)R); mx(4 * Hp, Hp, (int)R); mx(2 * E, Hp, (int)R); mx(E, E, (int)R); mx(E, E, N * S);
-  L.tn_p_floats = tn;
-  L.tn_p = b.take(tn);
+  // the second stream's own split-K slab and column-sum scratch: as large as the first's, because the deferred
+  // parameter-gradient products of the decoder run there too (acvae_decode_bwd)
+  L.tn_p_floats = L.tn_floats;
+  L.tn_p = b.take(L.tn_p_floats);
   {
-    int w = 4 * Hp; if (2 * E > w) w = 2 * E;
+    int w = V; if (4 * Hp > w) w = 4 * Hp; if (3 * H > w) w = 3 * H; if (2 * E > w) w = 2 * E; if (A > w) w = A;
     L.dpart_p = b.take(2 * acvae::colsum_scratch_doubles(w));
   }
   L.scratch_bwd = b.off;
@@ -529,6 +530,14 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
   return ACVAE_OK;
 }
 
+extern "C" int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream) {
+  static const bool on = !(getenv("ACVAE_DECODE_DEFER") && atoi(getenv("ACVAE_DECODE_DEFER")) == 0);
+  if (!on || !aux_stream || aux_stream == stream || !dis_flags_host) return 0;
+  for (int t = 0; t < Tc; ++t)
+    if (dis_flags_host[t] != 0) return 0;      // the prior BPTT waits for the decoder's dz: nothing to overlap
+  return 1;
+}
+
 extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, const float* mem_in,
                                 const int64_t* mem_lens, const int64_t* lens1, const float* eps_p,
                                 const int* dis_flags_host, const float* outputs, const float* attn_w,
@@ -557,6 +566,13 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   auto P = [&](int i) { return (const float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc, Hp = E;
+  // Only d_mem_in is on the step's critical path (the encoder backward waits for it).  With a second stream and
+  // independent chains, everything d_mem_in does not depend on - the parameter-gradient products, the embedding
+  // gradients, d_q_z - is queued on the second stream AFTER the call has released the first one, where it runs beside
+  // the encoder backward.  The caller then owns two obligations (include/acvae_hip.h): the second stream must be joined
+  // before the gradients / d_q_z are read on another stream, and saved / scratch / the incoming gradients must stay
+  // untouched until it has drained.
+  const bool defer = acvae_decode_bwd_defers(dis_flags_host, Tc, stream, aux_stream) != 0;
   const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
   TnWs tn_p{sc + L.tn_p, L.tn_p_floats * 4};
@@ -592,23 +608,29 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   else ACVAE_TRY(zero(d_out, (long)R * H, st));
   if (d_p_means_utt) {
     float* dhid = sc + L.dhid;
-    const float* hidp = sv + L.pool_hid;
     ACVAE_TRY(gemm(d_p_means_utt, 2 * E, wt_mlo, 2 * E, nullptr, dhid, H, N, H, 2 * E, 0, st));
-    ACVAE_TRY(gemm_tn(d_p_means_utt, 2 * E, hidp, H, G(TP_MLO_W), H, 2 * E, H, N, tn, st));
-    ACVAE_TRY(acvae::colsum2(d_p_means_utt, N, 2 * E, dpart, G(TP_MLO_B), nullptr, 0, st));
     ACVAE_TRY(acvae::pool_bwd(dhid, lens1, (const int*)(sv + L.pool_arg), d_out, (long)Tc * H, H, 1, N, Tc, H, st));
-  } else {
-    ACVAE_TRY(zero(G(TP_MLO_W), (long)2 * E * H, st));
-    ACVAE_TRY(zero(G(TP_MLO_B), 2 * E, st));
   }
-  if (d_logits) {
-    ACVAE_TRY(gemm(d_logits, V, wt_cls, V, nullptr, d_out, H, R, H, V, 1, st));
-    ACVAE_TRY(gemm_tn(d_logits, V, outputs, H, G(TP_DEC_CLS_W), H, V, H, R, tn, st));
-    ACVAE_TRY(acvae::colsum2(d_logits, R, V, dpart, G(TP_DEC_CLS_B), nullptr, 0, st));
-  } else {
-    ACVAE_TRY(zero(G(TP_DEC_CLS_W), (long)V * H, st));
-    ACVAE_TRY(zero(G(TP_DEC_CLS_B), V, st));
-  }
+  if (d_logits) ACVAE_TRY(gemm(d_logits, V, wt_cls, V, nullptr, d_out, H, R, H, V, 1, st));
+  // parameter gradients of the two heads (c: the stream / workspaces they are queued with)
+  auto heads_params = [&](const Ctx& c, TnWs ws, double* dp) -> int {
+    if (d_p_means_utt) {
+      ACVAE_TRY(gemm_tn(d_p_means_utt, 2 * E, sv + L.pool_hid, H, G(TP_MLO_W), H, 2 * E, H, N, ws, c));
+      ACVAE_TRY(acvae::colsum2(d_p_means_utt, N, 2 * E, dp, G(TP_MLO_B), nullptr, 0, c));
+    } else {
+      ACVAE_TRY(zero(G(TP_MLO_W), (long)2 * E * H, c));
+      ACVAE_TRY(zero(G(TP_MLO_B), 2 * E, c));
+    }
+    if (d_logits) {
+      ACVAE_TRY(gemm_tn(d_logits, V, outputs, H, G(TP_DEC_CLS_W), H, V, H, R, ws, c));
+      ACVAE_TRY(acvae::colsum2(d_logits, R, V, dp, G(TP_DEC_CLS_B), nullptr, 0, c));
+    } else {
+      ACVAE_TRY(zero(G(TP_DEC_CLS_W), (long)V * H, c));
+      ACVAE_TRY(zero(G(TP_DEC_CLS_B), V, c));
+    }
+    return ACVAE_OK;
+  };
+  if (!defer) ACVAE_TRY(heads_params(st, tn, dpart));
 
   // ---- decoder BPTT
   float* dgi = sc + L.dgi;
@@ -645,31 +667,34 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     float* tmp = dh; dh = dh2; dh2 = tmp;
     return ACVAE_OK;
   };
-  auto dec_batched = [&]() -> int {
-  // batched parameter gradients of the decoder
-  ACVAE_TRY(gemm_tn(dgi, 3 * H, rnn_d, 3 * E, G(TP_DEC_WIH), 3 * E, 3 * H, 3 * E, R, tn, st));
-  ACVAE_TRY(acvae::colsum2(dgi, R, 3 * H, dpart, G(TP_DEC_BIH), nullptr, 0, st));
-  ACVAE_TRY(gemm_tn(dgh, 3 * H, hprev_d, H, G(TP_DEC_WHH), H, 3 * H, H, R, tn, st));
-  ACVAE_TRY(acvae::colsum2(dgh, R, 3 * H, dpart, G(TP_DEC_BHH), nullptr, 0, st));
-  // attention parameters: W = [query half | memory half]
-  ACVAE_TRY(gemm_tn(dqd, A, hprev_d, H, G(TP_DEC_ATT_W), E + H, A, H, R, tn, st));
-  ACVAE_TRY(gemm_tn(dencproj, A, mem, E, G(TP_DEC_ATT_W) + H, E + H, A, E, N * S, tn, st));
-  ACVAE_TRY(acvae::colsum2(dencproj, N * S, A, dpart, G(TP_DEC_ATT_B), nullptr, 0, st));
-  ACVAE_TRY(acvae::colsum2(dvpart, N, A, dpart, G(TP_DEC_ATT_V), nullptr, 0, st));
-  ACVAE_TRY(gemm(dencproj, A, wt_datt + (long)H * A, A, nullptr, dmem, E, N * S, E, A, 1, st));
-  // d(rnn_input) for the embedding and z columns
-  ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, st));                    // d emb
-  ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, st));  // d z
-  ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, st));
-  ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, st));
-  // route dz to the posterior sample (here) or to the prior sample (prior chain, below), per step
-  if (!prior_feeds_decoder) {
-    ACVAE_TRY(acvae::copy_rows(d_q_z, E, dz_dec, E, R, E, st));
-  } else {
-    for (int t = 0; t < Tc; ++t)
-      ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
-                                 (long)Tc * E, N, E, st));
-  }
+  // the decoder attention's share of the memory gradient (critical)
+  auto dec_memgrad = [&]() -> int {
+    return gemm(dencproj, A, wt_datt + (long)H * A, A, nullptr, dmem, E, N * S, E, A, 1, st);
+  };
+  // batched parameter gradients of the decoder, the embedding gradient and d_q_z
+  auto dec_params = [&](const Ctx& c, TnWs ws, double* dp) -> int {
+    ACVAE_TRY(gemm_tn(dgi, 3 * H, rnn_d, 3 * E, G(TP_DEC_WIH), 3 * E, 3 * H, 3 * E, R, ws, c));
+    ACVAE_TRY(acvae::colsum2(dgi, R, 3 * H, dp, G(TP_DEC_BIH), nullptr, 0, c));
+    ACVAE_TRY(gemm_tn(dgh, 3 * H, hprev_d, H, G(TP_DEC_WHH), H, 3 * H, H, R, ws, c));
+    ACVAE_TRY(acvae::colsum2(dgh, R, 3 * H, dp, G(TP_DEC_BHH), nullptr, 0, c));
+    // attention parameters: W = [query half | memory half]
+    ACVAE_TRY(gemm_tn(dqd, A, hprev_d, H, G(TP_DEC_ATT_W), E + H, A, H, R, ws, c));
+    ACVAE_TRY(gemm_tn(dencproj, A, mem, E, G(TP_DEC_ATT_W) + H, E + H, A, E, N * S, ws, c));
+    ACVAE_TRY(acvae::colsum2(dencproj, N * S, A, dp, G(TP_DEC_ATT_B), nullptr, 0, c));
+    ACVAE_TRY(acvae::colsum2(dvpart, N, A, dp, G(TP_DEC_ATT_V), nullptr, 0, c));
+    // d(rnn_input) for the embedding and z columns
+    ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, c));                    // d emb
+    ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, c));  // d z
+    ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, c));
+    ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, c));
+    // route dz to the posterior sample (here) or to the prior sample (prior chain, below), per step
+    if (!prior_feeds_decoder) {
+      ACVAE_TRY(acvae::copy_rows(d_q_z, E, dz_dec, E, R, E, c));
+    } else {
+      for (int t = 0; t < Tc; ++t)
+        ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
+                                   (long)Tc * E, N, E, c));
+    }
     return ACVAE_OK;
   };
 
@@ -724,51 +749,59 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     tmp = dlz; dlz = dlz2; dlz2 = tmp;
     return ACVAE_OK;
   };
-  auto prior_batched = [&]() -> int {
-  // batched parameter gradients of the prior
-  ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn_p, sp));
-  ACVAE_TRY(acvae::colsum2(dml_all, R, 2 * E, dpart_p, G(TP_P_ML_B), nullptr, 0, sp));
-  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, rnn_p, 3 * E, G(TP_P_WIH), 3 * E, 4 * Hp, 3 * E, R, tn_p, sp));
-  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BIH), nullptr, 0, sp));
-  ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BHH), nullptr, 0, sp));
-  ACVAE_TRY(gemm_tn(dgates, 4 * Hp, hpprev, Hp, G(TP_P_WHH), Hp, 4 * Hp, Hp, R, tn_p, sp));
-  // d[emb; ctx] of the prior
-  ACVAE_TRY(gemm(dgates, 4 * Hp, wt_pih, 4 * Hp, nullptr, drnn_p, 3 * E, R, 2 * E, 4 * Hp, 0, sp));   // cols 0:2E of drnn_p[R,3E]
-  // prior attention backward (all Tc queries of a clip inside one workgroup: deterministic accumulation)
-  float* dqp = sc + L.dqp;  // dpz is dead from here on
-  ACVAE_TRY(zero(dencproj_p, (long)N * S * E, sp));
-  ACVAE_TRY(zero(dvpart_p, (long)N * E, sp));
-  ACVAE_TRY(acvae_attn_bwd(drnn_p + E, (long)Tc * 3 * E, 3 * E, sv + L.qp, (long)Tc * E, E, sv + L.encproj_p, mem,
-                           mem_lens, P(TP_P_ATT_V), sv + L.attw_p, (long)Tc * S, S, dqp, (long)Tc * E, E, dencproj_p,
-                           dmem_p, dvpart_p, sc + L.attws_p, L.attws_bytes, N, Tc, S, E, E, sp));
-  // d emb_p = drnn[:, 0:E] + dqp . W_att[:, :E]
-  ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn_p, 3 * E, R, E, E, 1, sp));
-  ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn_p, sp));
-  ACVAE_TRY(gemm_tn(dencproj_p, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn_p, sp));
-  ACVAE_TRY(acvae::colsum2(dencproj_p, N * S, E, dpart_p, G(TP_P_ATT_B), nullptr, 0, sp));
-  ACVAE_TRY(acvae::colsum2(dvpart_p, N, E, dpart_p, G(TP_P_ATT_V), nullptr, 0, sp));
-  ACVAE_TRY(gemm(dencproj_p, E, wt_patt + (long)E * E, E, nullptr, dmem_p, E, N * S, E, E, 1, sp));
-  ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, sp));
-  ACVAE_TRY(acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp));
-    return ACVAE_OK;
+  float* dqp = sc + L.dqp;  // dpz is dead once the prior BPTT is through
+  // the prior attention's share of the memory gradient (critical)
+  auto prior_memgrad = [&]() -> int {
+    // d[emb; ctx] of the prior
+    ACVAE_TRY(gemm(dgates, 4 * Hp, wt_pih, 4 * Hp, nullptr, drnn_p, 3 * E, R, 2 * E, 4 * Hp, 0, sp));   // cols 0:2E of drnn_p[R,3E]
+    // prior attention backward (all Tc queries of a clip inside one workgroup: deterministic accumulation)
+    ACVAE_TRY(zero(dencproj_p, (long)N * S * E, sp));
+    ACVAE_TRY(zero(dvpart_p, (long)N * E, sp));
+    ACVAE_TRY(acvae_attn_bwd(drnn_p + E, (long)Tc * 3 * E, 3 * E, sv + L.qp, (long)Tc * E, E, sv + L.encproj_p, mem,
+                             mem_lens, P(TP_P_ATT_V), sv + L.attw_p, (long)Tc * S, S, dqp, (long)Tc * E, E, dencproj_p,
+                             dmem_p, dvpart_p, sc + L.attws_p, L.attws_bytes, N, Tc, S, E, E, sp));
+    return gemm(dencproj_p, E, wt_patt + (long)E * E, E, nullptr, dmem_p, E, N * S, E, E, 1, sp);
+  };
+  // batched parameter gradients of the prior and its embedding gradient
+  auto prior_params = [&]() -> int {
+    ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn_p, sp));
+    ACVAE_TRY(acvae::colsum2(dml_all, R, 2 * E, dpart_p, G(TP_P_ML_B), nullptr, 0, sp));
+    ACVAE_TRY(gemm_tn(dgates, 4 * Hp, rnn_p, 3 * E, G(TP_P_WIH), 3 * E, 4 * Hp, 3 * E, R, tn_p, sp));
+    ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BIH), nullptr, 0, sp));
+    ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BHH), nullptr, 0, sp));
+    ACVAE_TRY(gemm_tn(dgates, 4 * Hp, hpprev, Hp, G(TP_P_WHH), Hp, 4 * Hp, Hp, R, tn_p, sp));
+    // d emb_p = drnn[:, 0:E] + dqp . W_att[:, :E]
+    ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn_p, 3 * E, R, E, E, 1, sp));
+    ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn_p, sp));
+    ACVAE_TRY(gemm_tn(dencproj_p, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn_p, sp));
+    ACVAE_TRY(acvae::colsum2(dencproj_p, N * S, E, dpart_p, G(TP_P_ATT_B), nullptr, 0, sp));
+    ACVAE_TRY(acvae::colsum2(dvpart_p, N, E, dpart_p, G(TP_P_ATT_V), nullptr, 0, sp));
+    ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, sp));
+    return acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp);
   };
   if (prior_feeds_decoder) {   // the prior BPTT needs the decoder's dz: back to back
     for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(dec_bptt(t));
-    ACVAE_TRY(dec_batched());
+    ACVAE_TRY(dec_memgrad());
+    ACVAE_TRY(dec_params(st, tn, dpart));
     if (fork.on()) ACVAE_TRY(Fork::edge(st.s, sp.s));
     ACVAE_TRY(prior_begin());
     for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(prior_bptt(t));
-    ACVAE_TRY(prior_batched());
+    ACVAE_TRY(prior_memgrad());
+    ACVAE_TRY(prior_params());
   } else {                     // independent chains: feed both queues step by step
     ACVAE_TRY(prior_begin());
     for (int t = Tc - 1; t >= 0; --t) {
       ACVAE_TRY(dec_bptt(t));
       ACVAE_TRY(prior_bptt(t));
     }
-    ACVAE_TRY(dec_batched());
-    ACVAE_TRY(prior_batched());
+    ACVAE_TRY(dec_memgrad());
+    ACVAE_TRY(prior_memgrad());
+    if (!defer) {
+      ACVAE_TRY(dec_params(st, tn, dpart));
+      ACVAE_TRY(prior_params());
+    }
   }
-  ACVAE_TRY(fork.join());
+  ACVAE_TRY(fork.join());      // deferred mode: the second stream holds only the critical part so far
   ACVAE_TRY(acvae::add_rows(dmem, E, dmem_p, E, N * S, E, st));
   // ---- memory gradient back through the optional ln projection
   if (has_ln) {
@@ -778,6 +811,12 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(acvae::colsum2(dmem, N * S, E, dpart, G(TP_LN_B), nullptr, 0, st));
   } else {
     ACVAE_TRY(acvae::copy_rows(d_mem_in, E, dmem, E, N * S, E, st));
+  }
+  if (defer) {                 // everything else: behind the first stream's work so far, on the second stream
+    ACVAE_TRY(Fork::edge(st.s, sp.s));
+    ACVAE_TRY(heads_params(sp, tn_p, dpart_p));
+    ACVAE_TRY(dec_params(sp, tn_p, dpart_p));
+    ACVAE_TRY(prior_params());
   }
   return ACVAE_OK;
 }

@@ -17,10 +17,11 @@ from . import _lib
 _SCRATCH = {}
 
 
-def scratch_buffer(nbytes, device):
+def scratch_buffer(nbytes, device, tag=None):
     """Grow-only scratch per (device, stream): contents are dead between library calls, and calls on one stream
-    are ordered, so one buffer per stream is enough (the posterior runs on a side stream beside the encoder)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    are ordered, so one buffer per stream is enough (the posterior runs on a side stream beside the encoder).  A call
+    that leaves work behind on a second stream (acvae_decode_bwd) takes its own buffer (``tag``)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         _SCRATCH[key] = buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -80,11 +80,23 @@ class _DecodeFn(torch.autograd.Function):
         d_mem = torch.empty(N, S, Eenc, device=dev)
         d_qz = torch.empty(N, Tc, E, device=dev)
         scratch_b = _lib.call("acvae_decode_scratch_bytes", *ctx.dims)
-        scratch = scratch_buffer(scratch_b, dev)
+        scratch = scratch_buffer(scratch_b, dev, tag="decode")
+        ups = [c(t) for t in (d_logits, d_outputs, d_pm, d_pl, d_pz, d_putt)]
+        main, aux = _lib.current_stream(), model._aux_stream()
         _lib.call("acvae_decode_bwd", ptr_table(params), ptr_table(grads), mem, mem_lens_d, lens1_d, eps_p, ctx.dis_arr,
-                  outputs, attw, pl, c(d_logits), c(d_outputs), c(d_pm), c(d_pl), c(d_pz), c(d_putt), d_mem, d_qz,
-                  ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, _lib.current_stream(),
-                  model._aux_stream())
+                  outputs, attw, pl, *ups, d_mem, d_qz, ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, main,
+                  aux)
+        if _lib.lib().acvae_decode_bwd_defers(ctx.dis_arr, Tc, main, aux):      # a yes / no answer, not a status
+            # The parameter gradients and d_q_z are still being computed on the side stream (beside the encoder backward
+            # that starts now).  Their consumers: the posterior backward (same stream: ordered), the gradient exchange
+            # announced from there, and whoever reads .grad after backward() - joined here at the end of the pass.
+            side, cur = model._side_stream(torch.cuda.current_stream()), torch.cuda.current_stream()
+            for t in [ctx.saved, outputs, d_qz] + [u for u in ups if u is not None]:
+                t.record_stream(side)                      # freed by autograd while the side stream still reads them
+            if any(p is not None and p.grad is not None for p in params):
+                cur.wait_stream(side)                      # autograd will accumulate into .grad on this stream right away
+            else:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: cur.wait_stream(side))
         ctx.saved = None
         outs = [next((g for p, g in zip(params, grads) if p is w), None) for w in model._decode_weights()]
         return (None, d_mem, None, None, None, d_qz, None, None, None, None, *outs)

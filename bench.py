@@ -94,8 +94,9 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)     # steps 1-7 of a fresh process run 31-34 ms, later ones 28.7
+                                                         # (tools/step_times.py): allocator, event and clock warm-up
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -136,7 +137,7 @@ def main():
         dist.barrier()
     # live roofline measurement: HIP events around the conv launches of every PROF_EVERY-th timed step (an event pair
     # costs a few microseconds of queue bubble; 42 pairs in every step would take ~1 % off the headline)
-    PROF_EVERY = 4
+    PROF_EVERY = int(os.environ.get("ACVAE_BENCH_PROF_EVERY", "4"))
     _lib.lib().acvae_prof_enable(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -198,7 +198,14 @@ int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64
                      int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int Tc, int S, int E, int H,
                      int A, int V, int Eenc, int start_idx, int end_idx, void* stream, void* aux_stream);
 /* Backward for upstream gradients of logits / outputs / p_means / p_logs / p_z / p_means_utt (each may be
- * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E]. */
+ * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E].
+ * Stream contract: d_mem_in is ordered on `stream` when the call returns.  When acvae_decode_bwd_defers() says 1 for the
+ * same flags / streams (a second stream is given and no step fed the prior's z to the decoder), everything d_mem_in
+ * does not depend on - the parameter gradients and d_q_z - is queued on `aux_stream` behind the call, so that it runs
+ * beside whatever `stream` does next (the encoder backward): the caller joins aux_stream before those results are read
+ * on another stream, and keeps saved / scratch / outputs / the upstream gradients untouched until aux_stream has
+ * drained.  Otherwise (0) everything is ordered on `stream` on return.  ACVAE_DECODE_DEFER=0 forces 0. */
+int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream);
 int acvae_decode_bwd(const void* const* params, void* const* grads, const float* mem_in, const int64_t* mem_lens,
                      const int64_t* lens1, const float* eps_p, const int* dis_flags_host, const float* outputs,
                      const float* attn_w, const float* p_logs, const float* d_logits, const float* d_outputs_ext,
