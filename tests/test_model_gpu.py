@@ -417,3 +417,17 @@ def test_checkpoint_round_trip_and_torch_adam_compat():
     for (k, a), (_, b) in zip(m1.named_parameters(), m3.named_parameters()):
         if b.grad is not None:
             close(b, a, 1e-5, 1e-6, what="torch Adam vs fused " + k)
+
+
+def test_train_step_goldens_with_trailing_parameter_gradients():
+    """ACVAE_DECODE_DEFER=1 (acvae_decode_bwd leaves the parameter gradients and d_q_z on the second stream, joined at
+    the end of the backward pass): the training-step goldens and the ragged edge shapes must still hold.  The switch is
+    read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ACVAE_DECODE_DEFER="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "g6 or g13 or edge_shapes or checkpoint"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
