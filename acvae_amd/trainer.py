@@ -13,6 +13,7 @@ backward, ``clip_grad_norm_(max_grad_norm)``, ``Adam.step`` — with the MI355X-
     (DDP's default broadcast_buffers=True).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -92,6 +93,8 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if self._dist() else 1
         self.broadcast_buffers = broadcast_buffers
         self.step_count = 0
+        self.max_steps_in_flight = int(os.environ.get("ACVAE_STEPS_IN_FLIGHT", "2"))
+        self._in_flight = []
         self._flatten()
         self.exchange = FlatGradExchange(self.flat_g, [self.n_text, self.n_enc], process_group)
         model._grad_ready_cb = self._on_grads_ready
@@ -194,6 +197,15 @@ class TrainStep:
                   float(self.max_grad_norm or 0.0), tn, st)
         parts["loss"] = loss.detach()
         parts["grad_norm"] = self.total_norm
+        # Bound how far the host may run ahead of the GPU.  Unbounded, the first steps of a run queue several steps'
+        # worth of launches, the runtime grows its queues / kernel-argument / signal pools while the GPU is working and
+        # those steps run 31-36 ms instead of 28.7 (tools/step_times.py); two steps of slack hide every host hiccup.
+        if self.max_steps_in_flight > 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._in_flight.append(ev)
+            if len(self._in_flight) > self.max_steps_in_flight:
+                self._in_flight.pop(0).synchronize()
         return parts
 
     def _check_grad_aliasing(self):
