@@ -200,9 +200,9 @@ constexpr int CV_BMT = 128;
 constexpr int CV_ROWS = CV_BMT + 2;
 constexpr int CV_AR = 5;            // float4 slots per loader thread for the strip: 4 full passes + rows 128, 129
 // 53.8 KB for BN = 64 with LDS-DMA panels (three workgroups per CU), 74.9 KB for BN = 128 (two)
-template <int BN, bool BDMA>
+template <int BN, bool BDMA, bool ADMA>
 struct alignas(16) ConvSmem {
-  alignas(16) float a[2][CV_ROWS * LDS_LD];
+  alignas(16) float a[2][CV_ROWS * (ADMA ? BK : LDS_LD)];
   alignas(16) float b[2][BN * (BDMA ? BK : LDS_LD)];
 };
 
@@ -260,10 +260,17 @@ struct ConvStripLoader {   // strip row j <-> pixel q = row0 - 1 + j, read at ve
 // lane-linear, [BN rows][32 floats] unpadded, and the bank spread comes from an XOR swizzle of the 16-byte chunk index
 // with the row (chunk c of row r sits at position c ^ (r & 7)), applied on the SOURCE address by the loader and on the
 // read address by the matrix waves.  Needs N % BN == 0 (an LDS-DMA cannot zero-fill).
-template <int BN, bool BDMA, class Epilogue>
+// ADMA (needs BDMA; only when the strip carries no BatchNorm+ReLU transform: data gradients and the convolutions that
+// read a pooled activation): the activation strip goes by LDS-DMA as well, a third of it per sub-stage, into the same
+// swizzled lane-linear image [130 rows][32 floats].  A DMA cannot zero-fill, so rows outside the tensor are fetched from
+// a clamped address and the matrix waves zero the lanes whose tap leaves the image vertically (okt / okb), as they
+// already do horizontally - a tap that leaves the tensor always leaves the image one way or the other.
+template <int BN, bool BDMA, bool ADMA, class Epilogue>
 __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<true, BN / 32> bl, int M, int N, int C,
                                               int W, int block_m, int block_n, const Epilogue& ep,
-                                              ConvSmem<BN, BDMA>& sm) {
+                                              ConvSmem<BN, BDMA, ADMA>& sm) {
+  static_assert(!ADMA || BDMA, "the strip DMA shares the weight panels' wait");
+  constexpr int NAI = (CV_ROWS + 7) / 8;   // 8-row DMA instructions per strip (17), 6 per sub-stage
   // Matrix wavefronts 2 x 2: (64-row half, BN/2-column half).  KSPLIT = the second index splits the 32-channel K-step
   // instead, every wave a 64 x 64 tile with fewer LDS fragment reads per MFMA, halves added through LDS before the
   // epilogue; measured for BN = 64: 1353 -> 1390 us, i.e. that kernel is not bound by LDS reads (nor by occupancy: three
@@ -327,9 +334,28 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     // An LDS-DMA is ordered for the readers only by the issuing wave's vmcnt wait followed by a barrier; hipcc places
     // that wait in front of __syncthreads() by itself, the explicit one keeps the kernel independent of that.
     auto dma_wait = [&]() { if (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-    al.issue(0, 0, pa);
+    // third `part` of the strip of group grp: strip row r <-> pixel row0 - 1 + r at vertical offset dy
+    auto fetch_a = [&](int buf, int grp, int part) {
+      const int dyi = grp / nchunk, chunk = grp - dyi * nchunk;
+      const int lw = lt >> 6, l = lt & 63;
+      const int sw = (l & 7) ^ (l >> 3);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = part * 6 + lw + 4 * j;
+        const int r = k * 8 + (l >> 3);
+        long q = (long)row0 - 1 + r + (long)(dyi - 1) * W;
+        q = q < 0 ? 0 : (q > (long)M - 1 ? (long)M - 1 : q);
+        const float* src = al.X + q * C + chunk * BK + sw * 4;
+        if (lw + 4 * j < 6 && k < NAI && r < CV_ROWS) __builtin_amdgcn_global_load_lds(src, &sm.a[buf][k * 8 * BK], 16, 0, 0);
+      }
+    };
+    if (ADMA) {
+      fetch_a(0, 0, 0); fetch_a(0, 0, 1); fetch_a(0, 0, 2);
+    } else {
+      al.issue(0, 0, pa);
+    }
     fetch_b(0, kstep_of(0, 0));
-    put_a(0);
+    if (!ADMA) put_a(0);
     put_b(0);
     dma_wait();
     __syncthreads();
@@ -338,7 +364,9 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
       for (int dxi = 0; dxi < 3; ++dxi) {
         const int s = grp * 3 + dxi;
         const int g1 = grp + 1;
-        if (dxi == 0 && g1 < ngrp) {           // the next strip's loads fly for three sub-stages
+        if (ADMA) {
+          if (g1 < ngrp) fetch_a(g1 & 1, g1, dxi);   // the buffer's last readers (group grp - 1) are through
+        } else if (dxi == 0 && g1 < ngrp) {      // the next strip's loads fly for three sub-stages
           const int dyi = g1 / nchunk;
           al.issue(dyi, g1 - dyi * nchunk, pa);
         }
@@ -347,7 +375,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
           put_b((s + 1) & 1);
         } else if (g1 < ngrp) {
           fetch_b((s + 1) & 1, kstep_of(g1, 0));
-          put_a(g1 & 1);
+          if (!ADMA) put_a(g1 & 1);
           put_b((s + 1) & 1);
         }
         dma_wait();
@@ -357,21 +385,31 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
   } else {
     // ------------------------------------------------------------------ matrix wavefronts
     // border masks of this lane's two tile rows: pixel p = row0 + wm*64 + i*32 + li
-    bool okl[2], okr[2];
+    bool okl[2], okr[2], okt[2], okb[2];
     // 16-byte chunk of this lane's first weight fragment in the swizzled panel row: (K-half, k pair) ^ (row & 7); the
     // group index g * 2 occupies other bits than (4 * K-half + lh), so it can be xor-ed in
     const int bsw = ((KSPLIT ? 4 * wn : 0) + lh) ^ (li & 7);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int w = (row0 + wm * 64 + i * 32 + li) % W;
+      const int px = row0 + wm * 64 + i * 32 + li;
+      const int w = px % W, h = (px / W) % al.H;
       okl[i] = w > 0; okr[i] = w < W - 1;
+      okt[i] = h > 0; okb[i] = h < al.H - 1;
     }
     __syncthreads();
     for (int grp = 0; grp < ngrp; ++grp) {
-      const float* Ag = sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh + (KSPLIT ? wn * (BK / 2) : 0);
+      const float* Ag = ADMA ? sm.a[grp & 1] + (wm * 64 + li) * BK
+                             : sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh + (KSPLIT ? wn * (BK / 2) : 0);
+      bool vok[2] = {true, true};
+      if (ADMA) {
+        const int dyi = grp / nchunk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vok[i] = dyi == 0 ? okt[i] : (dyi == 2 ? okb[i] : true);
+      }
 #pragma unroll
       for (int dxi = 0; dxi < 3; ++dxi) {
-        const float* As = Ag + dxi * LDS_LD;           // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
+        const float* As = Ag + dxi * (ADMA ? BK : LDS_LD);   // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
+        const int asw = (lh ^ ((li + dxi) & 7)) << 2;       // ADMA: swizzled chunk of this lane's first fragment
         const float* Bs = sm.b[(grp * 3 + dxi) & 1] + ((KSPLIT ? 0 : wn * (BN / 2)) + li) * (BDMA ? BK : LDS_LD) +
                           (BDMA ? 0 : 4 * lh + (KSPLIT ? wn * (BK / 2) : 0));
 #pragma unroll
@@ -379,9 +417,11 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
           float4 af[2], bf[NTN];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            af[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
+            af[i] = ADMA ? *reinterpret_cast<const float4*>(As + i * 32 * BK + ((g << 3) ^ asw))
+                         : *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
             if (dxi == 0 && !okl[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (dxi == 2 && !okr[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ADMA && !vok[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int j = 0; j < NTN; ++j)
@@ -428,16 +468,16 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
   ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], matrix_wave);
 }
 
-template <int BN, bool BDMA>
+template <int BN, bool BDMA, bool ADMA = false>
 __global__ __launch_bounds__(nt_threads<CV_BMT>(), 2) void conv_igemm3_kernel(ConvStripLoader al,
                                                                               const float* __restrict__ Wp,
                                                                               ConvStatsEpilogue ep, int M, int Cout,
                                                                               int K) {
-  __shared__ ConvSmem<BN, BDMA> sm;
+  __shared__ ConvSmem<BN, BDMA, ADMA> sm;
   PlainLoader<true, BN / 32> bl{Wp, K, Cout, K};
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  conv_nt_block<BN, BDMA>(al, bl, M, Cout, al.C, al.W, bm, bn, ep, sm);
+  conv_nt_block<BN, BDMA, ADMA>(al, bl, M, Cout, al.C, al.W, bm, bn, ep, sm);
 }
 
 // BMT x BN tile; the A operand (im2col rows) carries the previous layer's BatchNorm+ReLU when al.scale != nullptr.
@@ -1240,19 +1280,25 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
   if (!aligned16(X) || !aligned16(Wp) || !aligned16(Y)) return ACVAE_EALIGN;
   const int M = N * H * W, K = 9 * Cin;
   ConvStatsEpilogue ep{Y, partials, Cout};
-  // A/B switch: 0 = one tap per stage (conv_igemm_kernel), 1 = strip kernel, 2 = strip kernel + weight panels by LDS-DMA
+  // A/B switch: 0 = one tap per stage (conv_igemm_kernel), 1 = strip kernel, 2 = strip kernel + weight panels by LDS-DMA,
+  // 3 = + the activation strip by LDS-DMA where it carries no transform (measured neutral: 10 of the 14 launches
+  // qualify, each within 1 % of its register-path time, encoder backward 16.55 vs 16.54 ms - the loader waves have the
+  // slack, what bounds the kernel is the L2 -> LDS operand stream itself; not the default)
   static const int strip = getenv("ACVAE_CONV_STRIP") ? atoi(getenv("ACVAE_CONV_STRIP")) : 2;
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
   if (strip) {
     ConvStripLoader al{X, scale, shift, H, W, Cin, M};
     const int bn = Cout <= 64 ? 64 : 128;
     const dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, bn)), block(nt_threads<CV_BMT>());
-    const bool dma = strip == 2 && Cout % bn == 0;
+    const bool dma = strip >= 2 && Cout % bn == 0;
+    const bool adma = dma && strip >= 3 && !scale;
     if (bn == 64) {
-      if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<64, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+      if (adma) hipLaunchKernelGGL((conv_igemm3_kernel<64, true, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+      else if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<64, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
       else hipLaunchKernelGGL((conv_igemm3_kernel<64, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
     } else {
-      if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<128, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+      if (adma) hipLaunchKernelGGL((conv_igemm3_kernel<128, true, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+      else if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<128, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
       else hipLaunchKernelGGL((conv_igemm3_kernel<128, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
     }
   } else {
