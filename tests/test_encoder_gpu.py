@@ -222,3 +222,18 @@ def test_cnn14_backward_vs_oracle():
     for seed in (9, 1, 6):
         errs = cnn14_grad_errors(4, 128, seed)
         assert max(errs.values()) <= 0.15, max(errs.items(), key=lambda kv: kv[1])
+
+
+@pytest.mark.parametrize("env", [dict(ACVAE_CONV_STRIP="3"), dict(ACVAE_CONV_STRIP="1", ACVAE_WGRAD_STRIP="0"),
+                                 dict(ACVAE_CONV_STRIP="0", ACVAE_WGRAD_STRIP="3")])
+def test_alternate_conv_kernels_keep_parity(env):
+    """The kernels behind the A/B switches (activation strip by LDS-DMA; register-path panels with the one-tap-per-tile
+    weight gradient; the one-tap-per-stage implicit GEMM) must pass the same forward golden and backward-vs-oracle
+    checks as the defaults.  The switches are read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "g4 or encoder_backward_vs_oracle"], env=dict(os.environ, **env), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
