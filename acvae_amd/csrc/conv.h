@@ -53,5 +53,9 @@ int relu_dropout(float* x, int total, DropoutSpec drop, hipStream_t st);
 int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1, const float* A2,
                        int64_t lda2, const float* B2, int64_t ldb2, int K2, const float* bias, float* C, int64_t ldc,
                        int M, int N, int accumulate, hipStream_t st, float* skws = nullptr);
+// two independent products C0 = A0 . B0^T (+ bias0), C1 = A1 . B1^T (+ bias1) of M <= 64 rows in one launch
+int acvae_gemm_nt_pair(const float* A0, int64_t lda0, const float* B0, int64_t ldb0, int K0, const float* bias0, float* C0,
+                       int64_t ldc0, int N0, int acc0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1,
+                       const float* bias1, float* C1, int64_t ldc1, int N1, int acc1, int M, hipStream_t st);
 long acvae_skinny_ws_floats();
 int acvae_skinny_ws_reset(float* ws, hipStream_t st);

@@ -465,16 +465,26 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
   };
   float* gru_save = sv + L.gru_save;
   float* hprev_d = sv + L.hprev_d;
+  static const bool pair_env = !(getenv("ACVAE_SKINNY_PAIR") && atoi(getenv("ACVAE_SKINNY_PAIR")) == 0);
+  const bool pair_ok = pair_env && N <= 64;
   auto dec_step = [&](int t) -> int {
     const float* hprev = t ? outputs + (long)(t - 1) * H : zeros;
     const long ldh = t ? (long)Tc * H : H;
-    ACVAE_TRY(gemm(hprev, ldh, P(TP_DEC_ATT_W), E + H, nullptr, qd + (long)t * A, (long)Tc * A, N, A, H, 0, st));
+    // Both products of h_{t-1} (attention query, hidden-to-hidden gates) in one launch.  The kernels of this chain run
+    // back to back and each is bound by its own load latency (7-20 us for microseconds of work), so what shortens a step
+    // is one kernel fewer on the chain, not fewer launches as such: decode forward 1.33 -> 1.16 ms.
+    if (pair_ok) {
+      ACVAE_TRY(acvae_gemm_nt_pair(hprev, ldh, P(TP_DEC_ATT_W), E + H, H, nullptr, qd + (long)t * A, (long)Tc * A, A, 0,
+                                   hprev, ldh, P(TP_DEC_WHH), H, H, P(TP_DEC_BHH), gh_d, 3 * H, 3 * H, 0, N, st));
+    } else {
+      ACVAE_TRY(gemm(hprev, ldh, P(TP_DEC_ATT_W), E + H, nullptr, qd + (long)t * A, (long)Tc * A, N, A, H, 0, st));
+      ACVAE_TRY(gemm(hprev, ldh, P(TP_DEC_WHH), H, P(TP_DEC_BHH), gh_d, 3 * H, N, 3 * H, H, 0, st));
+    }
     ACVAE_TRY(acvae_attn_fwd(qd + (long)t * A, (long)Tc * A, A, encproj_d, mem, mem_lens, P(TP_DEC_ATT_V),
                              rnn_d + (long)t * 3 * E + E, ld3E, 3 * E, attn_w + (long)t * S, (long)Tc * S, S, N, 1, S, A,
                              E, st));
     ACVAE_TRY(gemm(rnn_d + (long)t * 3 * E + E, ld3E, P(TP_DEC_WIH) + E, 3 * E, nullptr, gi_d + (long)t * 3 * H,
                    (long)Tc * 3 * H, N, 3 * H, E, 1, st));
-    ACVAE_TRY(gemm(hprev, ldh, P(TP_DEC_WHH), H, P(TP_DEC_BHH), gh_d, 3 * H, N, 3 * H, H, 0, st));
     ACVAE_TRY(acvae::gru_fwd(gi_d + (long)t * 3 * H, (long)Tc * 3 * H, gh_d, 3 * H, hprev, ldh, outputs + (long)t * H,
                              (long)Tc * H, nullptr, 0, gru_save + (long)t * 4 * H, (long)Tc * 4 * H,
                              hprev_d + (long)t * H, (long)Tc * H, nullptr, t, N, H, st));

@@ -149,6 +149,65 @@ int acvae_skinny_ws_reset(float* ws, hipStream_t st) {   // zero the ticket coun
   return hipMemsetAsync(ws, 0, SK_MAX_TILES * sizeof(unsigned), st) == hipSuccess ? ACVAE_OK : (int)hipGetLastError();
 }
 
+namespace {
+// Two independent skinny products in ONE launch (no split-K): the x-tiles of the first, then those of the second.  For
+// the serial decode steps, where two short-K products hang off the same input (h . W_att^T and h . W_hh^T in the decoder
+// step): each kernel on such a chain lasts 7-20 us - its own load latency, not its work - so running the two side by
+// side takes one kernel's time instead of two.  Each tile runs exactly the arithmetic of gemm_skinny_kernel with
+// gridDim.z = 1 (long-K products gain more from the split-K path and stay separate).
+struct SkProblem {
+  const float* A; long lda;
+  const float* B; long ldb;
+  int K;
+  const float* bias;
+  float* C; long ldc;
+  int N, accumulate;
+};
+template <bool VEC4>
+__global__ __launch_bounds__(SK_THREADS) void gemm_skinny_pair_kernel(SkProblem p0, SkProblem p1, int nx0, int M) {
+  __shared__ float red[SK_WAVES][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const bool second = (int)blockIdx.x >= nx0;
+  const SkProblem& p = second ? p1 : p0;
+  const int n0 = ((int)blockIdx.x - (second ? nx0 : 0)) * 32, m0 = blockIdx.y * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  sk_accumulate<VEC4>(acc, p.A, p.lda, p.B, p.ldb, M, p.N, p.K, m0, n0, wave, SK_WAVES, li, lh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += SK_THREADS) {
+    const int mm = e >> 5, nn = e & 31;
+    const int m = m0 + mm, n = n0 + nn;
+    if (m < M && n < p.N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) v += red[w][mm][nn];
+      if (p.bias) v += p.bias[n];
+      float* o = p.C + (long)m * p.ldc + n;
+      if (p.accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+}  // namespace
+
+int acvae_gemm_nt_pair(const float* A0, int64_t lda0, const float* B0, int64_t ldb0, int K0, const float* bias0, float* C0,
+                       int64_t ldc0, int N0, int acc0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1,
+                       const float* bias1, float* C1, int64_t ldc1, int N1, int acc1, int M, hipStream_t st) {
+  if (!A0 || !B0 || !C0 || !A1 || !B1 || !C1 || M <= 0 || M > 64 || N0 <= 0 || N1 <= 0 || K0 <= 0 || K1 <= 0)
+    return ACVAE_EINVAL;
+  const bool vec = vec_ok(A0, lda0, K0) && vec_ok(B0, ldb0, K0) && vec_ok(A1, lda1, K1) && vec_ok(B1, ldb1, K1);
+  const SkProblem p0{A0, lda0, B0, ldb0, K0, bias0, C0, ldc0, N0, acc0}, p1{A1, lda1, B1, ldb1, K1, bias1, C1, ldc1, N1, acc1};
+  const int nx0 = cdiv(N0, 32);
+  dim3 grid(nx0 + cdiv(N1, 32), cdiv(M, 32));
+  if (vec) hipLaunchKernelGGL(gemm_skinny_pair_kernel<true>, grid, dim3(SK_THREADS), 0, st, p0, p1, nx0, M);
+  else hipLaunchKernelGGL(gemm_skinny_pair_kernel<false>, grid, dim3(SK_THREADS), 0, st, p0, p1, nx0, M);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
 int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1, const float* A2,
                        int64_t lda2, const float* B2, int64_t ldb2, int K2, const float* bias, float* C, int64_t ldc,
                        int M, int N, int accumulate, hipStream_t st, float* skws) {
