@@ -24,3 +24,36 @@ def test_bad_arguments_are_reported_not_thrown():
     assert lib.acvae_reparam_fwd(None, 0, None, 0, None, None, None, 0, None, 0, 4, 4, None) == -1
     assert lib.acvae_gemm_nt(None, 0, None, 0, None, None, 0, 4, 4, 4, 0, None) == -1
     assert lib.acvae_attn_fwd(None, 0, 0, None, None, None, None, None, 0, 0, None, 0, 0, 1, 1, 1, 1, 1, None) == -1
+
+
+def test_product_never_reaches_into_the_oracle():
+    """oracle/ is test infrastructure: nothing under acvae_amd/ may import, load or execute it (only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg may), and the product has no CPU code path to fall back to."""
+    import ast
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    banned = {"acvae_oracle", "host_oracle", "ref_shim", "make_golden", "oracle"}
+    for path in sorted((root / "acvae_amd").rglob("*.py")):
+        src = path.read_text()
+        for node in ast.walk(ast.parse(src)):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n.split(".")[0] in banned for n in names), f"{path} imports {names}"
+        assert "oracle" not in src.lower().replace("the oracle", "").replace("oracle's", ""), f"{path} mentions oracle/"
+    for path in sorted((root / "acvae_amd" / "csrc").glob("*")):
+        if path.suffix in (".hip", ".h"):
+            assert "oracle" not in path.read_text().lower(), f"{path} mentions the oracle"
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: the host-side mirrors fail loudly when handed CPU tensors instead of computing on the host."""
+    import numpy as np
+    import pytest
+    import torch
+    from acvae_amd.encoder import Cnn10
+    enc = Cnn10(64, 512)
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X|cuda|GPU"):
+        enc(torch.zeros(1, 64, 64), np.array([64]))
