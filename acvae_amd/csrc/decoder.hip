@@ -643,7 +643,15 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     }
     return ACVAE_OK;
   };
-  if (!defer) ACVAE_TRY(heads_params(st, tn, dpart));
+  // They feed nothing downstream.  With a second stream they go there, in front of the prior's BPTT: the two serial
+  // chains leave most of the GPU idle, so the 75 us of these products cost the first stream nothing.
+  static const bool heads_aux = !(getenv("ACVAE_HEADS_AUX") && atoi(getenv("ACVAE_HEADS_AUX")) == 0);
+  const bool heads_on_aux = heads_aux && fork.on() && !defer;
+  if (heads_on_aux) {
+    ACVAE_TRY(heads_params(sp, tn_p, dpart_p));   // aux is behind fork.begin(): the upstream gradients are in place
+  } else if (!defer) {
+    ACVAE_TRY(heads_params(st, tn, dpart));
+  }
 
   // ---- decoder BPTT
   float* dgi = sc + L.dgi;
