@@ -129,10 +129,13 @@ def test_inference_n5_samples_config5():
             assert bool((r[int(idx[0]):] == 2).all())
 
 
-def test_loss_vs_oracle_at_config2_full_size():
-    """BASELINE configs[1] itself (B=32, T=1000, V=5000, E=512, 22-token captions): one forward + loss on the HIP path
-    against the oracle on the same weights, batch, dropout masks and noise — north_star's bar, |loss diff| <= 1e-4,
-    plus token ids exact; the gradient norm (through the whole backward) within 2e-4."""
+@pytest.mark.parametrize("B,T", [(32, 1000), (5, 999), (9, 517), (3, 1601)])
+def test_loss_vs_oracle_at_config2_full_size(B, T):
+    """BASELINE configs[1] itself (B=32, T=1000, V=5000, E=512, 22-token captions), and the same model on batch sizes /
+    frame counts that are no multiple of any tile (ragged caption and feature lengths): one forward + loss on the HIP
+    path against the oracle on the same weights, batch, dropout masks and noise — north_star's bar, |loss diff| <= 1e-4,
+    plus token ids exact; the gradient norm (through the whole backward) within 2e-4 (5e-4 for the small odd batches,
+    where one ReLU-boundary flip weighs more)."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import acvae_oracle as O
@@ -140,7 +143,7 @@ def test_loss_vs_oracle_at_config2_full_size():
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     model = build(5).train()
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    feats, caps, fl, cl = O.synthetic_batch(32, 1000, V, L, seed=4, ragged=True)
+    feats, caps, fl, cl = O.synthetic_batch(B, T, V, L, seed=4, ragged=True)
     rec = {}
     torch.manual_seed(9); random.seed(9)
     ores = O.OracleTrainer(state, V).step(feats, fl.copy(), caps, cl, 1.0, 0, record=rec, apply_update=False)
@@ -159,7 +162,8 @@ def test_loss_vs_oracle_at_config2_full_size():
     assert torch.equal(out["seqs"].cpu(), ores["out"]["seqs"])
     loss.backward()
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
-    assert abs(float(gn) - float(ores["grad_norm"])) <= 2e-4 * float(ores["grad_norm"]), (float(gn), float(ores["grad_norm"]))
+    tol = 2e-4 if B >= 32 else 5e-4
+    assert abs(float(gn) - float(ores["grad_norm"])) <= tol * float(ores["grad_norm"]), (float(gn), float(ores["grad_norm"]))
 
 
 def test_training_steps_do_not_leak_device_memory():
