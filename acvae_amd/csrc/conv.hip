@@ -271,14 +271,13 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
                                               ConvSmem<BN, BDMA, ADMA>& sm) {
   static_assert(!ADMA || BDMA, "the strip DMA shares the weight panels' wait");
   constexpr int NAI = (CV_ROWS + 7) / 8;   // 8-row DMA instructions per strip (17), 6 per sub-stage
-  // Matrix wavefronts 2 x 2: (64-row half, BN/2-column half).  KSPLIT = the second index splits the 32-channel K-step
-  // instead, every wave a 64 x 64 tile with fewer LDS fragment reads per MFMA, halves added through LDS before the
-  // epilogue; measured for BN = 64: 1353 -> 1390 us, i.e. that kernel is not bound by LDS reads (nor by occupancy: three
+  // Matrix wavefronts 2 x 2: (64-row half, BN/2-column half).  For BN = 64 a variant whose second index split the
+  // 32-channel K-step instead (every wave a 64 x 64 tile, fewer LDS fragment reads per MFMA, halves added through LDS
+  // before the epilogue) measured 1353 -> 1390 us: that kernel is not bound by LDS reads (nor by occupancy: three
   // workgroups per CU instead of two changed nothing either) but by its strip fetches - K = 9 * 64 is only 18 stages
-  // per tile and every tile reads its image rows three times.  Off.
-  constexpr bool KSPLIT = false;
-  constexpr int NTN = KSPLIT ? 2 : BN / 64;   // MFMA tiles per matrix wave along N
-  constexpr int NG = KSPLIT ? BK / 16 : BK / 8;   // 8-channel groups per wave and K-step
+  // per tile and every tile reads its image rows three times.
+  constexpr int NTN = BN / 64;     // MFMA tiles per matrix wave along N
+  constexpr int NG = BK / 8;       // 8-channel groups per K-step
   constexpr int NMW = CV_BMT / 32;
   constexpr int BR = BN / RPP;     // B rows per loader thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -386,9 +385,9 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     // ------------------------------------------------------------------ matrix wavefronts
     // border masks of this lane's two tile rows: pixel p = row0 + wm*64 + i*32 + li
     bool okl[2], okr[2], okt[2], okb[2];
-    // 16-byte chunk of this lane's first weight fragment in the swizzled panel row: (K-half, k pair) ^ (row & 7); the
-    // group index g * 2 occupies other bits than (4 * K-half + lh), so it can be xor-ed in
-    const int bsw = ((KSPLIT ? 4 * wn : 0) + lh) ^ (li & 7);
+    // 16-byte chunk of this lane's first weight fragment in the swizzled panel row: k pair ^ (row & 7); the group index
+    // g * 2 occupies other bits than lh, so it can be xor-ed in
+    const int bsw = lh ^ (li & 7);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int px = row0 + wm * 64 + i * 32 + li;
@@ -399,7 +398,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     __syncthreads();
     for (int grp = 0; grp < ngrp; ++grp) {
       const float* Ag = ADMA ? sm.a[grp & 1] + (wm * 64 + li) * BK
-                             : sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh + (KSPLIT ? wn * (BK / 2) : 0);
+                             : sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh;
       bool vok[2] = {true, true};
       if (ADMA) {
         const int dyi = grp / nchunk;
@@ -410,8 +409,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
       for (int dxi = 0; dxi < 3; ++dxi) {
         const float* As = Ag + dxi * (ADMA ? BK : LDS_LD);   // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
         const int asw = (lh ^ ((li + dxi) & 7)) << 2;       // ADMA: swizzled chunk of this lane's first fragment
-        const float* Bs = sm.b[(grp * 3 + dxi) & 1] + ((KSPLIT ? 0 : wn * (BN / 2)) + li) * (BDMA ? BK : LDS_LD) +
-                          (BDMA ? 0 : 4 * lh + (KSPLIT ? wn * (BK / 2) : 0));
+        const float* Bs = sm.b[(grp * 3 + dxi) & 1] + (wn * (BN / 2) + li) * (BDMA ? BK : LDS_LD) + (BDMA ? 0 : 4 * lh);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           float4 af[2], bf[NTN];
@@ -442,29 +440,6 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     }
   }
   // every wave is past the last LDS access (barrier above): LDS is free for the epilogue
-  if (KSPLIT) {
-    float* red = &sm.a[0][0];       // 2 row halves x 4 tiles x 16 registers x 64 lanes = 32 KB of the 37 KB strip ring
-    if (matrix_wave && wn == 1) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NTN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[(((wm * 2 + i) * NTN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (matrix_wave && wn == 0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NTN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((wm * 2 + i) * NTN + j) * 16 + r) * 64 + lane];
-    }
-    __syncthreads();
-    ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, 0, li, lh, M, N, &sm.a[0][0], matrix_wave && wn == 0);
-    return;
-  }
   ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], matrix_wave);
 }
 
