@@ -542,14 +542,14 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad3_kernel(const float* __rest
   const int row0 = bx * TM;
   const int nk = (k_end - k_begin + BKT - 1) / BKT;
 
-  // per-wave column tiles: 96 columns = 3 MFMA tiles, each inside one horizontal tap
-  int dxj[3], cbj[3];
+  // Every wave holds 64 rows x 96 columns (paired LDS reads need two row tiles and two channel tiles per wave).  EM = 2:
+  // the waves split the 128 rows.  EM = 1 (64 output channels): there are no second 64 rows to give to wm, and one row
+  // tile per wave costs 6 LDS reads per 3 MFMAs, which saturates the LDS (measured 101 TFLOP/s); instead wm splits the
+  // K-step - wave (wm, wn) takes the pixel pairs kk = wm, wm + 2, ... - and the two halves go to two slabs of their own
+  // (the slabs of this layer are 147 KB each), summed by wgrad_reduce_kernel like any other pair of slices.
+  f32x16 acc[2][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { const int col = wn * 96 + j * 32; dxj[j] = col >> 6; cbj[j] = col & 63; }
-
-  f32x16 acc[EM][3];
-#pragma unroll
-  for (int i = 0; i < EM; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -616,16 +616,17 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad3_kernel(const float* __rest
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < nk) issue(k_begin + (ks + 1) * BKT);
-    if (EM == 2) {
+    {
       // paired reads (as in tn_block): one ds_read_b64 gives two adjacent output rows / two adjacent channels, so MFMA tile
       // e of the A side covers rows 2*rho + e and the two tiles of the wave's full tap (dx = 0 for wn = 0, dx = 2 for
       // wn = 1) cover channels 2*li + e; the third tile is the wave's half of the centre tap (channels wn*32 + li)
-      const float* As = sm.a[cur] + lh * TM + wm * 64 + 2 * li;
+      const float* As = sm.a[cur] + lh * TM + (EM == 2 ? wm * 64 : 0) + 2 * li;
       const float* Sp = sm.s[cur] + (lh + 2 * wn) * 64 + 2 * li;      // strip row k + dx, dx = 2*wn
       const float* Sc = sm.s[cur] + (lh + 1) * 64 + wn * 32 + li;     // centre tap
       const float* Mk = sm.mk[cur] + wn * BKT + lh;
 #pragma unroll
-      for (int kk = 0; kk < BKT / 2; ++kk) {
+      for (int kq = 0; kq < BKT / 2 / (EM == 2 ? 1 : 2); ++kq) {
+        const int kk = EM == 2 ? kq : 2 * kq + wm;
         const float2 af = *reinterpret_cast<const float2*>(As + kk * 2 * TM);
         float2 bp = *reinterpret_cast<const float2*>(Sp + kk * 2 * 64);
         const float bc = Sc[kk * 2 * 64];
@@ -634,59 +635,27 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad3_kernel(const float* __rest
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bp.x, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bp.y, acc[0][1], 0, 0, 0);
         acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bc, acc[0][2], 0, 0, 0);
-        acc[EM - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bp.x, acc[EM - 1][0], 0, 0, 0);
-        acc[EM - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bp.y, acc[EM - 1][1], 0, 0, 0);
-        acc[EM - 1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bc, acc[EM - 1][2], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bp.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bp.y, acc[1][1], 0, 0, 0);
+        acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bc, acc[1][2], 0, 0, 0);
       }
-    } else {
-    const float* As = sm.a[cur] + lh * TM + wm * EM * 32 + li;
-    const float* Ss = sm.s[cur] + lh * 64 + li;
-    const float* Mk = sm.mk[cur] + lh;
-#pragma unroll
-    for (int kk = 0; kk < BKT / 2; ++kk) {
-      float af[EM], bf[3];
-#pragma unroll
-      for (int i = 0; i < EM; ++i) af[i] = As[kk * 2 * TM + i * 32];
-      const float mL = Mk[kk * 2], mR = Mk[BKT + kk * 2];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float v = Ss[(kk * 2 + dxj[j]) * 64 + cbj[j]];
-        bf[j] = dxj[j] == 0 ? v * mL : (dxj[j] == 2 ? v * mR : v);
-      }
-#pragma unroll
-      for (int i = 0; i < EM; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
     }
     if (ks + 1 < nk) stash(cur ^ 1);
     __syncthreads();
   }
-  // slab[co][(dy*3 + dx)*C + c]
-  if (EM == 2) {
+  // slab[co][(dy*3 + dx)*C + c]; EM = 1: the K-halves of the two wave rows go to slabs 2z and 2z + 1
+  float* Cw = EM == 2 ? Cs : slab + (long)(2 * z + wm) * Cout * NC;
 #pragma unroll
-    for (int em = 0; em < 2; ++em)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = row0 + wm * 64 + 2 * rho + em;
-        if (m >= Cout) continue;
-        float* out = Cs + (long)m * NC + dyi * 3 * C + c0;
-        out[2 * wn * C + 2 * li + 0] = acc[em == 0 ? 0 : EM - 1][0][r];
-        out[2 * wn * C + 2 * li + 1] = acc[em == 0 ? 0 : EM - 1][1][r];
-        out[C + wn * 32 + li] = acc[em == 0 ? 0 : EM - 1][2][r];
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < EM; ++i)
+  for (int em = 0; em < 2; ++em)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = row0 + wm * EM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = row0 + (EM == 2 ? wm * 64 : 0) + 2 * rho + em;
       if (m >= Cout) continue;
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        Cs[(long)m * NC + (dyi * 3 + dxj[j]) * C + c0 + cbj[j] + li] = acc[i][j][r];
+      float* out = Cw + (long)m * NC + dyi * 3 * C + c0;
+      out[2 * wn * C + 2 * li + 0] = acc[em][0][r];
+      out[2 * wn * C + 2 * li + 1] = acc[em][1][r];
+      out[C + wn * 32 + li] = acc[em][2][r];
     }
 }
 
@@ -1301,6 +1270,8 @@ static bool wgrad_strip(int NC, int Cout) {
   static const int mode = getenv("ACVAE_WGRAD_STRIP") ? atoi(getenv("ACVAE_WGRAD_STRIP")) : 1;
   return NC % 576 == 0 && (mode == 1 || mode == 2 || (mode == 3 && Cout <= 64));
 }
+// slabs per pixel slice: the 64-row strip kernel writes the two K-halves of its wave rows separately
+static int wgrad_slabs_per_slice(int NC, int Cout) { return wgrad_strip(NC, Cout) && Cout <= 64 ? 2 : 1; }
 static int wgrad_splits(int M, int Cout, int NC) {
   const bool narrow = Cout <= 64, w192 = wgrad_use192(NC) || wgrad_strip(NC, Cout);
   const long tiles = w192 ? (long)cdiv(Cout, narrow ? 64 : 128) * (NC / 192)
@@ -1310,10 +1281,11 @@ static int wgrad_splits(int M, int Cout, int NC) {
   // blocks over a round boundary cost a whole extra round (1040 blocks ran 18 % slower than 2030).  The slice count is a
   // multiple of 8 (one group of pixel slices per XCD, conv_wgrad_kernel); every slice adds one slab of Cout x NC floats
   // that is written and then read by the reduce, so: minimise (MFMA time / fill of the last round) + slab traffic.
-  const long slots = 256L * ((w192 ? !narrow : narrow) ? 3 : 4);
+  const long slots = 256L * (wgrad_strip(NC, Cout) ? 3 : ((w192 ? !narrow : narrow) ? 3 : 4));   // strip kernels: 161 / 168 VGPRs
   const int maxs = cdiv(M, 16 * BKT) & ~7;
   const double t_mfma = 2.0 * (double)M * Cout * NC / 1.1e14;
-  const double t_slab = 2.0 * (double)Cout * NC * 4.0 / 0.67e12;   // measured: a slab costs ~6x its bytes / HBM rate
+  // measured: a slab costs ~6x its bytes / HBM rate
+  const double t_slab = 2.0 * (double)Cout * NC * 4.0 / 0.67e12 * wgrad_slabs_per_slice(NC, Cout);
   int best = 8;
   double best_t = 1e30;
   for (int k = 8; k <= (maxs < 8 ? 8 : maxs) && tiles * k <= 5 * slots; k += 8) {
@@ -1326,7 +1298,7 @@ static int wgrad_splits(int M, int Cout, int NC) {
   return best;
 }
 long conv3x3_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout) {
-  return (long)wgrad_splits(N * H * W, Cout, 9 * Cin) * Cout * 9 * Cin;
+  return (long)wgrad_splits(N * H * W, Cout, 9 * Cin) * wgrad_slabs_per_slice(9 * Cin, Cout) * Cout * 9 * Cin;
 }
 int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
                   int N, int H, int W, int Cin, int Cout, hipStream_t st) {
@@ -1365,8 +1337,8 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
     hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
   }
   prof_end(ACVAE_PROF_CONV_WGRAD, st);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((long)Cout * NC)), dim3(256), 0, st, slab, s, dW_oihw, Cout,
-                     Cin);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((long)Cout * NC)), dim3(256), 0, st, slab,
+                     s * wgrad_slabs_per_slice(NC, Cout), dW_oihw, Cout, Cin);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
