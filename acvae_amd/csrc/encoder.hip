@@ -207,10 +207,10 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
   return ACVAE_OK;
 }
 
-extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
+extern "C" int acvae_encoder_bwd_hooked(const void* const* params, void* const* grads, const float* feats,
                                  const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
                                  int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
-                                 const uint8_t* const* masks, void* stream) {
+                                 const uint8_t* const* masks, void* stream, void* block_done, void* user) {
   EncLayout L;
   ACVAE_TRY(make_layout(arch, N, T, F, L));
   if (!params || !grads || !feats || !d_audio_embeds || !saved_v || !scratch_v) return ACVAE_EINVAL;
@@ -258,6 +258,14 @@ extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, 
                                        scratch + L.s_c1w, scratch + L.s_c1b, G(p_conv(1, 1)), G(p_bn0(0)), G(p_bn0(1)),
                                        dpart, N, T, F, st));
     }
+    if (block_done) ((void (*)(int, void*))block_done)(b, user);
   }
   return ACVAE_OK;
+}
+
+extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
+                                 const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
+                                 int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
+                                 const uint8_t* const* masks, void* stream) {
+  return acvae_encoder_bwd_hooked(params, grads, feats, d_audio_embeds, saved_v, saved_bytes, scratch_v, scratch_bytes, arch, N, T, F, p_block, seed, masks, stream, nullptr, nullptr);
 }

@@ -15,6 +15,7 @@ import torch.nn as nn
 from . import _lib
 
 _SCRATCH = {}
+_BLOCK_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)   # acvae_encoder_bwd_hooked's block_done
 
 
 def scratch_buffer(nbytes, device, tag=None):
@@ -111,9 +112,21 @@ class _Cnn10Fn(torch.autograd.Function):
         scratch_b = _lib.call("acvae_encoder_scratch_bytes", mod.ARCH, N, T, F)
         scratch = scratch_buffer(scratch_b, feats.device)
         mt = ptr_table(ctx.masks) if ctx.masks is not None else None
-        _lib.call("acvae_encoder_bwd", ptr_table(tensors), ptr_table(grads), feats, d_ae, ctx.saved,
+        hook, failed = None, []
+        if mod._grad_ready_cb is not None:
+            # host callback after each ConvBlock's gradient kernels are queued: the data-parallel exchange starts the
+            # all-reduce of the deepest block's bucket while the shallower blocks still run
+            def block_done(block, _user):
+                try:
+                    mod._grad_ready_cb(("encoder_block", int(block)))
+                except BaseException as exc:          # an exception cannot cross the C frame: re-raised below
+                    failed.append(exc)
+            hook = _BLOCK_HOOK(block_done)
+        _lib.call("acvae_encoder_bwd_hooked", ptr_table(tensors), ptr_table(grads), feats, d_ae, ctx.saved,
                   ctx.saved.numel(), scratch, scratch_b, mod.ARCH, N, T, F, float(mod.p_block), ctx.seed, mt,
-                  _lib.current_stream())
+                  _lib.current_stream(), ctypes.cast(hook, ctypes.c_void_p) if hook is not None else None, None)
+        if failed:
+            raise failed[0]
         ctx.saved = None
         if mod._grad_ready_cb is not None:
             mod._grad_ready_cb("encoder")

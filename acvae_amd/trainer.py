@@ -4,9 +4,10 @@ backward, ``clip_grad_norm_(max_grad_norm)``, ``Adam.step`` — with the MI355X-
 
   * all parameters live in ONE flat fp32 buffer and all gradients in another (the backward kernels write
     straight into it), so the global-norm clip is one reduction and Adam is one fused pass
-    (acvae_grad_norm / acvae_adam_step), and the data-parallel exchange is two large RCCL all-reduces
-    (text-side bucket, launched as soon as its gradients exist and overlapped with the encoder backward,
-    then the encoder bucket) instead of ~60 per-tensor buckets;
+    (acvae_grad_norm / acvae_adam_step), and the data-parallel exchange is three large RCCL all-reduces
+    (text-side bucket and the encoder's last ConvBlock, each launched from inside the backward as soon as its
+    gradients are queued and overlapped with the rest of the encoder backward, then the remaining 5 MB of the
+    encoder) instead of ~60 per-tensor buckets;
   * one process per GPU over ``torch.distributed`` (backend "nccl" = RCCL over xGMI); gradients are
     averaged like torch DDP does (reference :204-207); BatchNorm statistics stay local per rank (the
     reference uses plain BatchNorm2d) and rank 0's running buffers are broadcast before each forward
@@ -96,7 +97,10 @@ class TrainStep:
         self.max_steps_in_flight = int(os.environ.get("ACVAE_STEPS_IN_FLIGHT", "2"))
         self._in_flight = []
         self._flatten()
-        self.exchange = FlatGradExchange(self.flat_g, [self.n_text, self.n_enc], process_group)
+        # buckets in flat order: text side | encoder up to the last ConvBlock | last ConvBlock (72 % of Cnn10's encoder
+        # gradients, finished first in the backward and all-reduced while the shallower blocks run)
+        self.exchange = FlatGradExchange(self.flat_g, [self.n_text, self.n_enc - self.n_enc_deep, self.n_enc_deep],
+                                         process_group)
         model._grad_ready_cb = self._on_grads_ready
         model.encoder._grad_ready_cb = self._on_grads_ready
         if self._dist():
@@ -116,6 +120,9 @@ class TrainStep:
         params = [p for p in model.parameters() if p.requires_grad]
         text = [p for p in params if p not in enc_params]
         enc = [p for p in params if p in enc_params and p not in never]
+        deep = set(getattr(model.encoder, f"conv_block{model.encoder.N_BLOCKS}").parameters())
+        enc = [p for p in enc if p not in deep] + [p for p in enc if p in deep]
+        n_deep = sum(1 for p in enc if p in deep)
         tail = [p for p in params if p in never]
         order = text + enc + tail
         dev = order[0].device
@@ -135,6 +142,7 @@ class TrainStep:
             off += sz
         self.n_text = sum(sizes[:len(text)])
         self.n_enc = sum(sizes[len(text):len(text) + len(enc)])
+        self.n_enc_deep = sum(sizes[len(text) + len(enc) - n_deep:len(text) + len(enc)])
         self.n_active = self.n_text + self.n_enc
         self.order, self.views = order, views
         model._set_grad_views(views)
@@ -153,7 +161,16 @@ class TrainStep:
 
     # ------------------------------------------------------------------ gradient exchange
     def _on_grads_ready(self, tag):
-        self.exchange.ready(0 if tag == "text" else 1)
+        """Called from inside the backward: "text" after the posterior backward (all text-side gradients are queued),
+        ("encoder_block", b) from acvae_encoder_bwd_hooked after ConvBlock b, "encoder" when the encoder is through."""
+        if tag == "text":
+            self.exchange.ready(0)
+        elif isinstance(tag, tuple):
+            if tag[1] == self.model.encoder.N_BLOCKS:
+                self.exchange.ready(2)
+        else:
+            self.exchange.ready(2)
+            self.exchange.ready(1)
 
     # ------------------------------------------------------------------ one optimiser step
     def forward_loss(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):

@@ -141,6 +141,14 @@ int acvae_encoder_bwd(const void* const* params, void* const* grads, const float
                       const float* d_audio_embeds, void* saved, int64_t saved_bytes, void* scratch,
                       int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
                       const uint8_t* const* masks, void* stream);
+/* The same with a host callback: `block_done`, if not NULL, is a `void (*)(int block, void* user)` (passed as void*)
+ * that is called on the calling thread right after the kernels producing ALL parameter gradients of ConvBlock `block`
+ * (conv1 / conv2 / bn1 / bn2; blocks run nb .. 1) have been queued on `stream`: a data-parallel caller starts the
+ * all-reduce of that block's gradient bucket there, behind `stream`, while the shallower blocks still run. */
+int acvae_encoder_bwd_hooked(const void* const* params, void* const* grads, const float* feats,
+                             const float* d_audio_embeds, void* saved, int64_t saved_bytes, void* scratch,
+                             int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
+                             const uint8_t* const* masks, void* stream, void* block_done, void* user);
 
 /* ---------------------------------------------------------------------------------------------
  * Text side of the path.  `params` / `grads` are pointer tables in the reference's state-dict order

@@ -47,11 +47,13 @@ def _worker(rank, world, port, q):
     model = _model()
     model.encoder.p_block = model.encoder.p_fc = 0.0
     ts = TrainStep(model, V)
+    announced, ready = [], ts.exchange.ready
+    ts.exchange.ready = lambda i: (announced.append(i), ready(i))[1]
     feats, caps, fl, cl = _batch(10 + rank)             # each rank its own shard
     torch.manual_seed(1); random.seed(1)
     parts = ts.step(feats.cuda(), fl.copy(), caps, cl, 1.0, 0, 0.5)
     torch.cuda.synchronize()
-    q.put((rank, ts.flat_p.cpu().numpy().copy(), float(parts["loss"])))
+    q.put((rank, ts.flat_p.cpu().numpy().copy(), float(parts["loss"]), announced))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,12 +65,16 @@ def test_two_rank_train_step_on_one_gpu():
     ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
-    res = dict((r, (w, l)) for r, w, l in (q.get(timeout=300) for _ in range(world)))
+    res = dict((r, (w, l, a)) for r, w, l, a in (q.get(timeout=300) for _ in range(world)))
     for p in ps:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert np.array_equal(res[0][0], res[1][0]), "ranks diverged after the averaged step"
     assert res[0][1] != res[1][1]                        # different shards -> different local losses
+    for r in range(world):                               # buckets: 0 text, 1 encoder blocks 1-3 (+bn0), 2 last ConvBlock
+        seq = res[r][2]
+        assert set(seq) == {0, 1, 2}, seq
+        assert seq.index(2) < seq.index(1), seq          # the deepest block's gradients go on the wire before the rest
     # single-process run of rank 0's shard without exchange must differ (the exchange really happened)
     import random
     from acvae_amd.trainer import TrainStep
