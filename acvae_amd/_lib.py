@@ -117,8 +117,16 @@ class _PinnedRing:
             self.head = 0
         s, e = self.head, self.head + span
         self.head = e
-        while self.live and self.live[0][0] < e and self.live[0][1] > s:
-            self.live.pop(0)[2].synchronize()
+        # every live entry that overlaps the slot must have been copied out (not only the oldest one: after a wrap an
+        # old tail entry the new lap never reaches can sit in front of newer ones that do overlap); entries whose copy
+        # has already passed are dropped on the way so the list stays short
+        keep = []
+        for (ls, le, ev) in self.live:
+            if ls < e and le > s:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((ls, le, ev))
+        self.live = keep
         return s, e
 
     def _send(self, slot, s, e, dev):

@@ -42,7 +42,7 @@ int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* 
 int bn_bwd_blocks(int N, int H, int W);
 int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
-           int W, int C, DropoutSpec drop, hipStream_t st);
+           int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats = true);
 int freq_mean(const float* P, float* out, long rows, int Fp, int C, hipStream_t st);
 int freq_mean_bwd(const float* dae, float* dP, long rows, int Fp, int C, hipStream_t st);
 int time_pool(const float* ae, float* out, int N, int S, int C, DropoutSpec drop, hipStream_t st);

@@ -1118,10 +1118,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ Y, const float* __
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ sum_g, const float* __restrict__ sum_gy,
-                                    float* __restrict__ dYout, int N, int H, int W, int C, DropoutSpec drop) {
+                                    float* __restrict__ dYout, int N, int H, int W, int C, DropoutSpec drop,
+                                    int batch_stats) {
   const int C4 = C / 4;
   const long total = (long)N * H * W * C4;
-  const float invn = 1.0f / (float)((long)N * H * W);
+  // evaluation-mode BatchNorm normalises with the running statistics, which do not depend on the batch: dY = scale * g
+  const float invn = batch_stats ? 1.0f / (float)((long)N * H * W) : 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     const long p = i / C4;
@@ -1424,7 +1426,7 @@ constexpr int BNB_PIX = 512;
 int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, BNB_PIX); }
 int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
-           int W, int C, DropoutSpec drop, hipStream_t st) {
+           int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats) {
   const int Cc = C < 1024 ? C : 1024;
   if (C % 4 != 0 || 1024 % Cc != 0 || C % Cc != 0) return ACVAE_EUNSUPPORTED;
   const dim3 rgrid(bn_bwd_blocks(N, H, W), C / Cc);
@@ -1436,7 +1438,7 @@ int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, co
                      N, H, W, C, BNB_PIX, drop);                                                                       \
   ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st)); /* sum_g (= dbeta) | sum_gy (= dgamma) */        \
   hipLaunchKernelGGL(bn_bwd_apply_kernel<UP_>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,       \
-                     invstd, sum_g, sum_gy, dY, N, H, W, C, drop)
+                     invstd, sum_g, sum_gy, dY, N, H, W, C, drop, batch_stats ? 1 : 0)
   if (upstream == UP_POOL) { BN_BWD_LAUNCH(UP_POOL); }
   else if (upstream == UP_DROP) { BN_BWD_LAUNCH(UP_DROP); }
   else { BN_BWD_LAUNCH(UP_PLAIN); }

@@ -60,13 +60,22 @@ struct Fork {
   hipStream_t main_s, aux;
   bool on() const { return aux != main_s; }
   // Events come from a small ring that is never destroyed: hipEventDestroy on an event that has not completed yet may
-  // hold the host until it has, which would serialise the host with the GPU at every fork.
+  // hold the host until it has, which would serialise the host with the GPU at every fork.  The ring belongs to the
+  // CALLING THREAD and to its current device (thread_local, re-made when the thread switches devices), so concurrent
+  // calls from several host threads - the autograd thread beside the main thread, SURVEY §8(b) - share nothing; an
+  // event re-recorded while an older wait on it is still queued is legal (a wait captures the record that precedes it).
   static int edge(hipStream_t from, hipStream_t to) {
     constexpr int RING = 64;
-    static hipEvent_t ring[RING];
-    static int next = 0;
-    hipEvent_t& e = ring[next];
-    next = (next + 1) % RING;
+    struct Ring { hipEvent_t ev[RING]; int next; int dev; };
+    static thread_local Ring ring = {{}, 0, -1};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    if (dev != ring.dev) {                      // first use on this thread, or the thread moved to another device
+      for (int i = 0; i < RING; ++i) ring.ev[i] = nullptr;   // the old device's events are left to its context
+      ring.next = 0; ring.dev = dev;
+    }
+    hipEvent_t& e = ring.ev[ring.next];
+    ring.next = (ring.next + 1) % RING;
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
     hipError_t r = hipEventRecord(e, from);
     if (r == hipSuccess) r = hipStreamWaitEvent(to, e, 0);

@@ -209,8 +209,9 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
 
 extern "C" int acvae_encoder_bwd_hooked(const void* const* params, void* const* grads, const float* feats,
                                  const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
-                                 int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
-                                 const uint8_t* const* masks, void* stream, void* block_done, void* user) {
+                                 int64_t scratch_bytes, int arch, int N, int T, int F, int training, float p_block,
+                                 uint64_t seed, const uint8_t* const* masks, void* stream, void* block_done,
+                                 void* user) {
   EncLayout L;
   ACVAE_TRY(make_layout(arch, N, T, F, L));
   if (!params || !grads || !feats || !d_audio_embeds || !saved_v || !scratch_v) return ACVAE_EINVAL;
@@ -238,14 +239,15 @@ extern "C" int acvae_encoder_bwd_hooked(const void* const* params, void* const* 
     BnPtrs n1 = bn_at(saved, L, 1 + 2 * (b - 1)), n2 = bn_at(saved, L, 2 + 2 * (b - 1));
     // conv2 / bn2 / pool / dropout
     ACVAE_TRY(acvae::bn_bwd(Y2, dp_cur, L.pool[b] ? UP_POOL : UP_DROP, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
-                            G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, 1), st));
+                            G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, training), st,
+                            training != 0));
     ACVAE_TRY(acvae::conv3x3_wgrad(dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
     ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), nullptr, wd, C, C, st));
     ACVAE_TRY(acvae::conv3x3_igemm(dya, nullptr, nullptr, wd, dyb, nullptr, N, H, W, C, C, st));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
     ACVAE_TRY(acvae::bn_bwd(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
-                            G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st));
+                            G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st, training != 0));
     if (b > 1) {
       ACVAE_TRY(acvae::conv3x3_wgrad(dya, saved + L.p[b - 1], nullptr, nullptr, G(p_conv(b, 1)), slab, N, H, W, Cin, C,
                                      st));
@@ -265,7 +267,8 @@ extern "C" int acvae_encoder_bwd_hooked(const void* const* params, void* const* 
 
 extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
                                  const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
-                                 int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
-                                 const uint8_t* const* masks, void* stream) {
-  return acvae_encoder_bwd_hooked(params, grads, feats, d_audio_embeds, saved_v, saved_bytes, scratch_v, scratch_bytes, arch, N, T, F, p_block, seed, masks, stream, nullptr, nullptr);
+                                 int64_t scratch_bytes, int arch, int N, int T, int F, int training, float p_block,
+                                 uint64_t seed, const uint8_t* const* masks, void* stream) {
+  return acvae_encoder_bwd_hooked(params, grads, feats, d_audio_embeds, saved_v, saved_bytes, scratch_v, scratch_bytes,
+                                  arch, N, T, F, training, p_block, seed, masks, stream, nullptr, nullptr);
 }

@@ -94,7 +94,7 @@ class _Cnn10Fn(torch.autograd.Function):
         mt = ptr_table(masks) if masks is not None else None
         _lib.call("acvae_encoder_fwd", ptr_table(tensors), feats, ae, pooled, saved, saved_b, scratch, scratch_b, arch,
                   N, T, F, int(training), float(mod.p_block), float(mod.p_fc), seed, mt, _lib.current_stream())
-        ctx.mod, ctx.feats, ctx.saved, ctx.masks, ctx.seed = mod, feats, saved, masks, seed
+        ctx.mod, ctx.feats, ctx.saved, ctx.masks, ctx.seed, ctx.training = mod, feats, saved, masks, seed, training
         ctx.mark_non_differentiable(pooled)
         return ae, pooled
 
@@ -123,7 +123,7 @@ class _Cnn10Fn(torch.autograd.Function):
                     failed.append(exc)
             hook = _BLOCK_HOOK(block_done)
         _lib.call("acvae_encoder_bwd_hooked", ptr_table(tensors), ptr_table(grads), feats, d_ae, ctx.saved,
-                  ctx.saved.numel(), scratch, scratch_b, mod.ARCH, N, T, F, float(mod.p_block), ctx.seed, mt,
+                  ctx.saved.numel(), scratch, scratch_b, mod.ARCH, N, T, F, int(ctx.training), float(mod.p_block), ctx.seed, mt,
                   _lib.current_stream(), ctypes.cast(hook, ctypes.c_void_p) if hook is not None else None, None)
         if failed:
             raise failed[0]

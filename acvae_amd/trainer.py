@@ -27,31 +27,50 @@ from .train_util import LabelSmoothingLoss, MSELoss, Normal_kl_loss
 class FlatGradExchange:
     """Data-parallel gradient exchange over one flat buffer split into ordered buckets.
 
-    ``ready(i)`` launches the asynchronous SUM all-reduce of bucket i (called from the backward as soon as the
-    bucket's gradients are written, so it overlaps with the rest of the backward); ``finish()`` waits for all of
-    them and returns the factor 1/world that the consumer folds into its next kernel (norm / Adam), which
-    makes it an average like torch DDP's.  Device-agnostic (RCCL on MI355X, gloo in the CPU tests)."""
+    ``ready(i, after=...)`` launches the asynchronous SUM all-reduce of bucket i (called from the backward as soon as
+    the bucket's gradients are queued, so it overlaps with the rest of the backward); ``finish()`` waits for all of
+    them and returns the factor 1/world that the consumer folds into its next kernel (norm / Adam), which makes it an
+    average like torch DDP's.  Device-agnostic (RCCL on MI355X, gloo in the CPU tests).
 
-    def __init__(self, flat, bucket_sizes, group=None):
+    Stream contract (RCCL): a collective is ordered behind the stream that is CURRENT when it is issued, nothing else.
+    A bucket whose gradients were produced on more than one stream therefore names the other producers explicitly:
+    ``after`` is a list of events (recorded behind the last kernel that writes into the bucket on those streams) that
+    the issuing stream waits for first.  ``finish()`` orders the collectives in front of the caller's current stream.
+    A bucket larger than ``max_chunk`` elements goes on the wire as several collectives (first byte sooner; the ring
+    pipelines them).  ``issued`` records the (bucket, chunk) sequence: it must be identical on every rank."""
+
+    def __init__(self, flat, bucket_sizes, group=None, max_chunk=8 << 20):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.max_chunk = int(max_chunk)
         self.slices, off = [], 0
         for n in bucket_sizes:
             self.slices.append((off, off + n))
             off += n
         assert off <= flat.numel()
-        self._works, self._done = [], set()
+        self._works, self._done, self.issued = [], set(), []
 
     def begin(self):
-        self._works, self._done = [], set()
+        self._works, self._done, self.issued = [], set(), []
 
-    def ready(self, i):
+    def ready(self, i, after=()):
         if self.world == 1 or i in self._done:
             return
         self._done.add(i)
         a, b = self.slices[i]
-        if b > a:
-            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if b <= a:
+            return
+        if self.flat.is_cuda:
+            cur = torch.cuda.current_stream(self.flat.device)
+            for ev in after:
+                if ev is not None:
+                    cur.wait_event(ev)
+        k = 0
+        while a < b:
+            e = min(b, a + self.max_chunk)
+            self._works.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.issued.append((i, k))
+            a, k = e, k + 1
 
     def finish(self):
         for i in range(len(self.slices)):
@@ -78,7 +97,7 @@ def kl_weight_for(epoch, epochs, beta):
 class TrainStep:
     def __init__(self, model, vocab_size, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
                  label_smoothing=True, smoothing=0.1, alpha=1.0, global_loss="MSE", process_group=None,
-                 broadcast_buffers=True):
+                 broadcast_buffers=True, data_parallel=True):
         self.model = model
         self.vocab = vocab_size
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -91,25 +110,37 @@ class TrainStep:
         self.kl_loss = Normal_kl_loss()
         self.mse_loss = MSELoss()
         self.pg = process_group
+        self.data_parallel = data_parallel          # False: a purely local step inside an initialised process group
         self.world = dist.get_world_size(process_group) if self._dist() else 1
         self.broadcast_buffers = broadcast_buffers
         self.step_count = 0
         self.max_steps_in_flight = int(os.environ.get("ACVAE_STEPS_IN_FLIGHT", "2"))
         self._in_flight = []
         self._flatten()
-        # buckets in flat order: text side | encoder up to the last ConvBlock | last ConvBlock (72 % of Cnn10's encoder
-        # gradients, finished first in the backward and all-reduced while the shallower blocks run)
-        self.exchange = FlatGradExchange(self.flat_g, [self.n_text, self.n_enc - self.n_enc_deep, self.n_enc_deep],
-                                         process_group)
-        model._grad_ready_cb = self._on_grads_ready
-        model.encoder._grad_ready_cb = self._on_grads_ready
+        # Buckets in flat order, each announced from inside the backward as soon as its gradients are queued:
+        #   0 decoder + prior + heads (everything acvae_decode_bwd writes, 76 MB at V=5000): behind the decode backward,
+        #     i.e. before the encoder backward has even started;
+        #   1 posterior (20 MB): behind the posterior backward, which runs on the side stream beside the encoder's;
+        #   2 encoder up to the last ConvBlock (5 MB): at the end of the encoder backward - the only exposed part;
+        #   3 the last ConvBlock (72 % of Cnn10's encoder gradients, 14 MB): from acvae_encoder_bwd_hooked's callback
+        #     right after that block's kernels are queued, while the shallower blocks still run.
+        # Buckets over 32 MB go out in 32 MB pieces.
+        self.exchange = FlatGradExchange(self.flat_g, [self.n_text_dec, self.n_text - self.n_text_dec,
+                                                       self.n_enc - self.n_enc_deep, self.n_enc_deep], process_group)
+        if self.world == 1:
+            self.exchange.world = 1
+        if self.world > 1:                         # single process: no exchange, no callbacks out of the backward
+            model._grad_ready_cb = self._on_grads_ready
+            model.encoder._grad_ready_cb = self._on_grads_ready
+        self._buf_work = None
         if self._dist():
             dist.broadcast(self.flat_p, src=0, group=self.pg)
             if self.flat_buf is not None:
                 dist.broadcast(self.flat_buf, src=0, group=self.pg)
 
     def _dist(self):
-        return dist.is_available() and dist.is_initialized() and (self.pg is not None or dist.get_world_size() > 1)
+        return self.data_parallel and dist.is_available() and dist.is_initialized() and \
+            (self.pg is not None or dist.get_world_size() > 1)
 
     # ------------------------------------------------------------------ flat parameter / gradient storage
     def _flatten(self):
@@ -118,7 +149,10 @@ class TrainStep:
         head = model.encoder._head()                                # embed_pooled / fc1: no gradient on this path
         never = {head.weight, head.bias}
         params = [p for p in model.parameters() if p.requires_grad]
+        qset = set(model.qnet.parameters())
         text = [p for p in params if p not in enc_params]
+        text = [p for p in text if p not in qset] + [p for p in text if p in qset]   # decode-written first, posterior last
+        n_q = sum(1 for p in text if p in qset)
         enc = [p for p in params if p in enc_params and p not in never]
         deep = set(getattr(model.encoder, f"conv_block{model.encoder.N_BLOCKS}").parameters())
         enc = [p for p in enc if p not in deep] + [p for p in enc if p in deep]
@@ -141,10 +175,11 @@ class TrainStep:
             views[p] = self.flat_g[off:off + p.numel()].view_as(p)
             off += sz
         self.n_text = sum(sizes[:len(text)])
+        self.n_text_dec = sum(sizes[:len(text) - n_q])
         self.n_enc = sum(sizes[len(text):len(text) + len(enc)])
         self.n_enc_deep = sum(sizes[len(text) + len(enc) - n_deep:len(text) + len(enc)])
         self.n_active = self.n_text + self.n_enc
-        self.order, self.views = order, views
+        self.order, self.views, self.never = order, views, never
         model._set_grad_views(views)
         # BatchNorm running statistics in one buffer (for the DDP-style broadcast)
         bufs = [b for n, b in model.named_buffers() if b.dtype.is_floating_point]
@@ -160,17 +195,28 @@ class TrainStep:
         self.total_norm = torch.zeros(1, device=dev)
 
     # ------------------------------------------------------------------ gradient exchange
-    def _on_grads_ready(self, tag):
-        """Called from inside the backward: "text" after the posterior backward (all text-side gradients are queued),
-        ("encoder_block", b) from acvae_encoder_bwd_hooked after ConvBlock b, "encoder" when the encoder is through."""
-        if tag == "text":
+    def _on_grads_ready(self, tag, event=None):
+        """Called from inside the backward, on the thread and with the stream of the autograd node that just queued
+        its kernels: ("decode", event) after acvae_decode_bwd unless it left gradients trailing on the side stream
+        (`event` = recorded behind its last kernel), "text" after the posterior backward (every text-side gradient is
+        queued now), ("encoder_block", b) from acvae_encoder_bwd_hooked after ConvBlock b, "encoder" when the encoder
+        is through.  The order of these calls is fixed by the autograd graph, hence identical on every rank."""
+        if tag == "decode":
+            self._decode_event = event
             self.exchange.ready(0)
+        elif tag == "decode_deferred":
+            self._decode_event = event           # announced at "text", behind the side stream's trailing work
+        elif tag == "text":
+            # decode-written gradients not announced yet (trailing-gradient mode): they were queued on this (side)
+            # stream or on the main stream behind `_decode_event`
+            self.exchange.ready(0, after=(getattr(self, "_decode_event", None),))
+            self.exchange.ready(1)
         elif isinstance(tag, tuple):
             if tag[1] == self.model.encoder.N_BLOCKS:
-                self.exchange.ready(2)
+                self.exchange.ready(3)
         else:
+            self.exchange.ready(3)
             self.exchange.ready(2)
-            self.exchange.ready(1)
 
     # ------------------------------------------------------------------ one optimiser step
     def forward_loss(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):
@@ -192,9 +238,8 @@ class TrainStep:
         return loss, {"ce": ce.detach(), "kl": kl.detach(), "mse": None if mse is None else mse.detach()}, out
 
     def step(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):
-        model = self.model
-        if self.world > 1 and self.broadcast_buffers and self.flat_buf is not None:
-            dist.broadcast(self.flat_buf, src=0, group=self.pg)
+        self.sync_buffers()
+        self._decode_event = None
         for p in self.order:
             p.grad = None                                             # optimizer.zero_grad(set_to_none=True)
         loss, parts, _ = self.forward_loss(feats, feat_lens, caps, cap_lens, ss_ratio, dis_ratio, kl_weight)
@@ -214,6 +259,11 @@ class TrainStep:
                   float(self.max_grad_norm or 0.0), tn, st)
         parts["loss"] = loss.detach()
         parts["grad_norm"] = self.total_norm
+        # DDP's broadcast_buffers: rank 0's BatchNorm running statistics reach the other ranks before the next forward
+        # touches them.  Issued here, behind this step's kernels and off the next step's critical path; joined by
+        # sync_buffers() at the start of the next step (or by the caller before an evaluation pass).
+        if self.world > 1 and self.broadcast_buffers and self.flat_buf is not None:
+            self._buf_work = dist.broadcast(self.flat_buf, src=0, group=self.pg, async_op=True)
         # Bound how far the host may run ahead of the GPU.  Unbounded, the first steps of a run queue several steps'
         # worth of launches, the runtime grows its queues / kernel-argument / signal pools while the GPU is working and
         # those steps run 31-36 ms instead of 28.7 (tools/step_times.py); two steps of slack hide every host hiccup.
@@ -224,6 +274,12 @@ class TrainStep:
             if len(self._in_flight) > self.max_steps_in_flight:
                 self._in_flight.pop(0).synchronize()
         return parts
+
+    def sync_buffers(self):
+        """Join the asynchronous BatchNorm-buffer broadcast of the previous step (a stream dependency under RCCL)."""
+        if self._buf_work is not None:
+            self._buf_work.wait()
+            self._buf_work = None
 
     def _check_grad_aliasing(self):
         """The backward kernels write into the flat gradient buffer and autograd is expected to adopt those
@@ -253,10 +309,12 @@ class TrainStep:
         ``{"model": model.state_dict(), "optimizer": ts.optimizer_state_dict()}`` is the checkpoint the reference writes
         (``:380-388``) and a ``torch.optim.Adam`` over a reference model loads it."""
         table = self._offsets()
-        params = [p for p in self.model.parameters() if p.requires_grad]
+        params = list(self.model.parameters())     # the reference builds Adam over ALL model.parameters() (:233-236)
         state = {}
         for i, p in enumerate(params):
-            if self.step_count == 0:
+            # torch.optim.Adam holds no state for a parameter that never had a gradient (frozen ones, and the pooled
+            # head embed_pooled / fc1 whose output this path does not consume): no entry, like a reference checkpoint
+            if self.step_count == 0 or p not in table or p in self.never:
                 continue
             o = table[p]
             state[i] = {"step": torch.tensor(float(self.step_count)),
@@ -271,7 +329,7 @@ class TrainStep:
         """Inverse of ``optimizer_state_dict`` (also accepts the state dict of a ``torch.optim.Adam`` built over the
         same model): resume training where the checkpoint left off."""
         table = self._offsets()
-        params = [p for p in self.model.parameters() if p.requires_grad]
+        params = list(self.model.parameters())
         group = sd["param_groups"][0]
         self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
         self.weight_decay = group.get("weight_decay", 0.0)
@@ -279,10 +337,15 @@ class TrainStep:
         self.exp_avg.zero_(); self.exp_avg_sq.zero_()
         for i, st in sd["state"].items():
             p = params[int(i)]
+            if p not in table:
+                continue                                   # frozen here: nothing to resume
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} does not match parameter "
+                                 f"{tuple(p.shape)} (state indexed over a different parameter list?)")
             o = table[p]
             self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError("per-parameter step counts differ: this optimiser keeps one step counter")
-        self.step_count = steps.pop() if steps else 0
+        # one step counter for the flat buffer: per-parameter counts that differ (legal under DDP's
+        # find_unused_parameters) resume at the largest, which is exact for every parameter that was never skipped
+        self.step_count = max(steps) if steps else 0

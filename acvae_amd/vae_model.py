@@ -86,7 +86,15 @@ class _DecodeFn(torch.autograd.Function):
         _lib.call("acvae_decode_bwd", ptr_table(params), ptr_table(grads), mem, mem_lens_d, lens1_d, eps_p, ctx.dis_arr,
                   outputs, attw, pl, *ups, d_mem, d_qz, ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, main,
                   aux)
-        if _lib.lib().acvae_decode_bwd_defers(ctx.dis_arr, Tc, main, aux):      # a yes / no answer, not a status
+        defers = bool(_lib.lib().acvae_decode_bwd_defers(ctx.dis_arr, Tc, main, aux))   # a yes / no answer, not a status
+        if model._grad_ready_cb is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            if not defers:                       # every gradient this call writes is ordered on the current stream
+                model._grad_ready_cb("decode", ev)
+            else:
+                model._grad_ready_cb("decode_deferred", ev)
+        if defers:
             # The parameter gradients and d_q_z are still being computed on the side stream (beside the encoder backward
             # that starts now).  Their consumers: the posterior backward (same stream: ordered), the gradient exchange
             # announced from there, and whoever reads .grad after backward() - joined here at the end of the pass.

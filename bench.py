@@ -100,11 +100,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU, torch.distributed.run
+        # over 127.0.0.1) before this process has made any GPU call, and leave with their exit code.  Nothing is
+        # re-executed in place: a process that has initialised the GPU must never exec.
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+               "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) "
+                         "or run `python bench.py --gpus N` without a launcher; refusing to report a mislabelled number")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     # test hooks (one-GPU rehearsal of the multi-rank path): every rank on device 0 over gloo
@@ -123,12 +143,13 @@ def main():
 
     model = build_model().cuda().train()
     ts = TrainStep(model, V, lr=5e-4, max_grad_norm=1.0, smoothing=0.1, alpha=1.0)
-    feats, caps, feat_lens, cap_lens = synthetic(1 + rank)
-    feats = feats.cuda()
+    feats_host, caps, feat_lens, cap_lens = synthetic(1 + rank)
+    feats = feats_host.cuda()
 
-    def step():
+    def step(x=None):
         random.seed(0)   # scheduled-sampling draws (ss_ratio = 1: always teacher forcing, as in epoch 1 of the reference)
-        return ts.step(feats, feat_lens.copy(), caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5)
+        return ts.step(feats if x is None else x, feat_lens.copy(), caps, cap_lens, ss_ratio=1.0, dis_ratio=0,
+                       kl_weight=0.5)
 
     for _ in range(args.warmup):
         parts = step()
@@ -162,6 +183,18 @@ def main():
     wgrad_ms, wgrad_n = ms.value, cnt.value
     _lib.lib().acvae_prof_enable(0)
     loss = float(parts["loss"])
+    # PCIe-inclusive rate, reported beside `value` and never as it: the 8.2 MB feature batch is handed over as a
+    # page-locked HOST buffer and uploaded inside every step, as Runner._forward does (runners/pytorch_runner_vae.py:80)
+    pinned = feats_host.pin_memory()
+    for _ in range(2):
+        step(pinned.cuda(non_blocking=True))
+    torch.cuda.synchronize()
+    PCIE_STEPS = 8
+    t1 = time.perf_counter()
+    for _ in range(PCIE_STEPS):
+        step(pinned.cuda(non_blocking=True))
+    torch.cuda.synchronize()
+    pcie_ms = max_over_ranks((time.perf_counter() - t1) / PCIE_STEPS * 1e3, device="cuda")
 
     if rank == 0:
         n_gpus = world
@@ -191,7 +224,9 @@ def main():
                                    "(fwd + CE/KL/MSE loss + bwd + global-norm clip + Adam), ss_ratio=1, dis_ratio=0",
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}" if n_gpus > 1 else "single",
                        "frames_per_s": frames_per_s, "audio_s_per_s": frames_per_s * HOP_S, "hop_s_assumed": HOP_S,
-                       "loss_last_step": loss},
+                       "loss_last_step": loss, "pcie_inclusive_ms_per_step": pcie_ms,
+                       "pcie_inclusive_note": f"{PCIE_STEPS} extra steps after the timed region with the feature batch "
+                                              "uploaded from page-locked host memory inside each step"},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm3_kernel (conv3x3 implicit GEMM fwd+dgrad with horizontal-tap reuse, fp32 MFMA)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,

@@ -9,7 +9,10 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless its name ends in _host.
  *   - the caller owns every buffer, workspaces included; the library never allocates or frees device
- *     memory and keeps no mutable global state (except the opt-in timing ring, acvae_prof_*).
+ *     memory.  Mutable state inside the library, all of it: (1) a per-THREAD, per-device pool of 64 HIP events used
+ *     for the fork / join edges of the two-stream calls (thread_local: concurrent calls from different host threads
+ *     share nothing, so every entry point is re-entrant across threads and streams); (2) the opt-in timing ring
+ *     (acvae_prof_*, mutex-guarded, empty unless enabled).  Run-time switches are read once from the environment.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises.
  *   - return 0 on success, a negative ACVAE_E* code for bad arguments, or a positive hipError_t.
  *   - fp32 everywhere ("dtype f32"), token ids / lengths int64 (as torch.long).
@@ -22,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ACVAE_ABI_VERSION 1
+#define ACVAE_ABI_VERSION 2
 int acvae_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -137,9 +140,12 @@ int acvae_encoder_fwd(const void* const* params, const float* feats, float* audi
                       void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int arch, int N, int T,
                       int F, int training, float p_block, float p_fc, uint64_t seed, const uint8_t* const* masks,
                       void* stream);
+/* `training` must be the value the forward that filled `saved` was called with: 0 = evaluation-mode BatchNorm
+ * (running statistics, no dropout; dY = scale * g, fine-tuning with frozen statistics and the data-parallel
+ * equivalence test), != 0 = batch statistics. */
 int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,
                       const float* d_audio_embeds, void* saved, int64_t saved_bytes, void* scratch,
-                      int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
+                      int64_t scratch_bytes, int arch, int N, int T, int F, int training, float p_block, uint64_t seed,
                       const uint8_t* const* masks, void* stream);
 /* The same with a host callback: `block_done`, if not NULL, is a `void (*)(int block, void* user)` (passed as void*)
  * that is called on the calling thread right after the kernels producing ALL parameter gradients of ConvBlock `block`
@@ -147,8 +153,8 @@ int acvae_encoder_bwd(const void* const* params, void* const* grads, const float
  * all-reduce of that block's gradient bucket there, behind `stream`, while the shallower blocks still run. */
 int acvae_encoder_bwd_hooked(const void* const* params, void* const* grads, const float* feats,
                              const float* d_audio_embeds, void* saved, int64_t saved_bytes, void* scratch,
-                             int64_t scratch_bytes, int arch, int N, int T, int F, float p_block, uint64_t seed,
-                             const uint8_t* const* masks, void* stream, void* block_done, void* user);
+                             int64_t scratch_bytes, int arch, int N, int T, int F, int training, float p_block,
+                             uint64_t seed, const uint8_t* const* masks, void* stream, void* block_done, void* user);
 
 /* ---------------------------------------------------------------------------------------------
  * Text side of the path.  `params` / `grads` are pointer tables in the reference's state-dict order

@@ -82,9 +82,8 @@ def g2_reparam_kl(ref):
 
 def g3_ce(ref):
     """G3: LabelSmoothingLoss (utils/train_util.py:243-251) on packed rows and torch CrossEntropyLoss
-    (runner :222-227); ragged cap_lens.  The masked [bs,max_len,C] forms of losses/loss.py:18-70 cannot
-    be imported here (ignite absent) - their expected values below come from stock torch ops following
-    that source text and are flagged 'restated'."""
+    (runner :222-227); ragged cap_lens.  The masked [bs,max_len,C] forms of losses/loss.py:18-70 are pinned
+    by the reference itself in G3b (g3b_masked_losses)."""
     g = torch.Generator().manual_seed(103)
     N, T, V = 6, 9, 257
     logits = 3 * torch.randn(N, T, V, generator=g)
@@ -95,10 +94,31 @@ def g3_ce(ref):
     ls = ref.train_util.LabelSmoothingLoss(V, smoothing=0.1, device="cpu")(pk, tg)
     ls0 = ref.train_util.LabelSmoothingLoss(V, smoothing=0.0, device="cpu")(pk, tg)
     ce = torch.nn.CrossEntropyLoss()(pk, tg.long())
-    restated_mean = O.masked_ce(logits, targets, lens1, 0.1, "mean")
-    restated_none = O.masked_ce(logits, targets, lens1, 0.0, "none")
-    save("g3_ce", logits=logits, targets=targets, lens1=lens1, ls_packed=ls, ls0_packed=ls0, ce_packed=ce,
-         restated_masked_ls_mean=restated_mean, restated_masked_ce_none=restated_none)
+    save("g3_ce", logits=logits, targets=targets, lens1=lens1, ls_packed=ls, ls0_packed=ls0, ce_packed=ce)
+
+
+def g3b_masked_losses():
+    """G3b: the reference's own ``losses/loss.py`` classes - CrossEntropyLoss (:12-37) and
+    LabelSmoothingLoss (:39-70) on the dict ``{"logits" [bs,max_len,C], "targets" [bs,max_len], "lens" [bs]}`` - for
+    reduction none / mean / sum, ragged lens.  Values AND input gradients (d loss / d logits of the mean and sum
+    forms) are the reference's."""
+    L = ref_shim.load_losses()
+    g = torch.Generator().manual_seed(113)
+    N, T, V = 6, 9, 257
+    logits = 3 * torch.randn(N, T, V, generator=g)
+    lens = torch.tensor([9, 9, 7, 4, 2, 1])
+    targets = torch.randint(0, V, (N, T), generator=g)
+    out = dict(logits=logits, targets=targets, lens=lens)
+    for name, mk in (("ce", lambda red: L.CrossEntropyLoss(reduction=red)),
+                     ("ls", lambda red: L.LabelSmoothingLoss(smoothing=0.1, reduction=red))):
+        for red in ("none", "mean", "sum"):
+            x = logits.clone().requires_grad_(True)
+            val = mk(red)({"logits": x, "targets": targets, "lens": lens})
+            out[f"{name}_{red}"] = val.detach().clone()
+            if red != "none":
+                val.backward()
+                out[f"{name}_{red}_dlogits"] = x.grad.clone()
+    save("g3b_masked_losses", **out)
 
 
 def g4_encoder(ref):
@@ -392,6 +412,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "host":          # only the host-side fixture
         g10_host()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "losses":        # only the losses/loss.py fixture
+        g3b_masked_losses()
+        return
     ref = ref_shim.load()
     if len(sys.argv) > 1 and sys.argv[1] == "dbs":
         g11_dbs(ref)
@@ -405,7 +428,7 @@ def main():
     g11_dbs(ref)
     g12_cnn14(ref)
     train_fixture(ref, "g13_train_step_cnn14", 2, 64, 40, 64, 6, True, 0, seed=36, keep_tensors=False, encoder="Cnn14_16k")
-    g1_attention(ref); g2_reparam_kl(ref); g3_ce(ref); g4_encoder(ref); g5_rnn(ref)
+    g1_attention(ref); g2_reparam_kl(ref); g3_ce(ref); g3b_masked_losses(); g4_encoder(ref); g5_rnn(ref)
     train_fixture(ref, "g6_train_step", 4, 64, 50, 64, 8, True, 0, seed=6)
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)
     train_fixture(ref, "g6c_train_step_e512", 2, 64, 300, 512, 7, False, 0, seed=26, keep_tensors=False)

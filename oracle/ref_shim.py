@@ -67,6 +67,26 @@ def load_host_side():
     return types.SimpleNamespace(caption_dataset=cd, build_vocab=bv, base_runner=br)
 
 
+def load_losses():
+    """``losses/loss.py`` (the masked CrossEntropyLoss :12-37 and LabelSmoothingLoss :39-70).  It imports
+    ``ignite.metrics`` and ``ignite.engine.engine.Engine`` at module level for a metric class the two loss classes
+    never touch; ignite is absent here, so empty stand-in modules are registered for those two names only (as
+    ``load_host_side`` does for the runner).  ``utils.score_util`` and ``models.utils`` are the reference's own files
+    and import for real."""
+    load()
+    for name in ("ignite", "ignite.metrics", "ignite.engine", "ignite.engine.engine"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["ignite.engine.engine"], "Engine"):
+        sys.modules["ignite.engine.engine"].Engine = type("Engine", (), {})
+    sys.modules["ignite"].metrics = sys.modules["ignite.metrics"]
+    for cls in ("Metric", "Loss"):                 # base classes of the metric wrappers at the end of the file
+        if not hasattr(sys.modules["ignite.metrics"], cls):
+            setattr(sys.modules["ignite.metrics"], cls, type(cls, (), {}))
+    import losses.loss as loss
+    return loss
+
+
 def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None, encoder="Cnn10"):
     """Hybrid_VAEModel(Cnn10, VAERNNBahdanauAttnDecoder, PosteriorRNN_hybrid, PriorRNN): the
     self-consistent combination of SURVEY F6, built the way runners/pytorch_runner_vae.py:33-73 does."""

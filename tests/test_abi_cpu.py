@@ -15,7 +15,7 @@ def test_build_and_symbols():
     so = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(so, name), f"{name} declared in include/acvae_hip.h but not exported"
-    assert _lib.lib().acvae_abi_version() == 1
+    assert _lib.lib().acvae_abi_version() == 2
 
 
 def test_bad_arguments_are_reported_not_thrown():

@@ -1,0 +1,150 @@
+"""GPU: the data-parallel train step over the REAL collective backend.
+
+Two ranks, one process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI) - the transport of
+``runners/pytorch_runner_vae.py:155-161,204-207`` - skipped unless two GPUs are visible.  The same body also runs with
+both ranks on GPU 0 over gloo (RCCL refuses two ranks on one device), so every assertion below is exercised on a
+one-GPU box as well; only the backend string and the device index differ.
+
+Checked on every rank:
+  1. the (bucket, piece) sequence of collectives issued from inside the backward is identical on all ranks and is
+     decode-written text gradients -> posterior / last ConvBlock -> rest of the encoder;
+  2. after the step the flat parameter buffer is BITWISE equal on all ranks;
+  3. it is BITWISE equal to the result of one un-bucketed all-reduce of the whole gradient buffer issued after the
+     backward (two operands: a + b == b + a bit for bit, whatever the bucket / piece structure);
+  4. with BatchNorm in evaluation mode (clips independent) the averaged gradient equals the
+     gradient of ONE process on the concatenated batch.
+"""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+V, E, L, NB, T = 60, 64, 8, 3, 64
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _model():
+    from acvae_amd.decoder import VAERNNBahdanauAttnDecoder
+    from acvae_amd.encoder import Cnn10
+    from acvae_amd.vae_model import Hybrid_VAEModel
+    torch.manual_seed(5)
+    dec = VAERNNBahdanauAttnDecoder(vocab_size=V, enc_mem_size=E, embed_size=E, hidden_size=E, attn_size=E)
+    m = Hybrid_VAEModel(Cnn10(64, 512), dec, posterior_model="PosteriorRNN_hybrid", posterior_args={"hidden_size": E},
+                        prior_model="PriorRNN", prior_args={"hidden_size": E}).cuda().train()
+    m.encoder.p_block = m.encoder.p_fc = 0.0
+    return m
+
+
+def _shard(rank):
+    g = torch.Generator().manual_seed(10 + rank)
+    feats = torch.randn(NB, T, 64, generator=g)
+    caps = torch.zeros(NB, L); caps[:, 0] = 1; caps[:, -1] = 2
+    caps[:, 1:-1] = torch.randint(4, V, (NB, L - 2), generator=g).float()
+    eps_q = torch.randn(NB, L - 1, E, generator=g)
+    eps_p = torch.randn(L - 1, NB, E, generator=g)
+    return feats, caps, np.full(NB, T), np.full(NB, L), eps_q, eps_p
+
+
+def _step(ts, model, shard):
+    feats, caps, fl, cl, eps_q, eps_p = shard
+    model.noise = dict(eps_q=eps_q, eps_p=eps_p)
+    random.seed(1)
+    parts = ts.step(feats.cuda(), fl.copy(), caps, cl, 1.0, 0, 0.5)
+    torch.cuda.synchronize()
+    return parts
+
+
+def _worker(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from acvae_amd.trainer import FlatGradExchange, TrainStep
+    shard = _shard(rank)
+
+    # (1)-(3): training-mode BatchNorm, bucketed exchange announced from inside the backward
+    model = _model()
+    ts = TrainStep(model, V)
+    parts = _step(ts, model, shard)
+    issued = list(ts.exchange.issued)
+    flat_bucketed = ts.flat_p.cpu().numpy().copy()
+    grads_avg = (ts.flat_g[:ts.n_active] * (1.0 / world)).cpu().numpy().copy()
+
+    # the same step with ONE all-reduce of the whole active gradient range, issued after the backward
+    model2 = _model()
+    ts2 = TrainStep(model2, V)
+    ts2.exchange = FlatGradExchange(ts2.flat_g, [ts2.n_active], None, max_chunk=1 << 40)
+    model2._grad_ready_cb = model2.encoder._grad_ready_cb = None
+    _step(ts2, model2, shard)
+    flat_single = ts2.flat_p.cpu().numpy().copy()
+
+    # (4): evaluation-mode BatchNorm in the encoder -> clips independent -> DP average == concatenated batch
+    model3 = _model()
+    model3.encoder.eval()
+    ts3 = TrainStep(model3, V)
+    _step(ts3, model3, shard)
+    g_eval = (ts3.flat_g[:ts3.n_active] * (1.0 / world)).cpu().numpy().copy()
+    g_cat = None
+    if rank == 0:
+        model4 = _model()
+        model4.encoder.eval()
+        ts4 = TrainStep(model4, V, data_parallel=False)
+        shards = [_shard(r) for r in range(world)]
+        cat = (torch.cat([s[0] for s in shards]), torch.cat([s[1] for s in shards]),
+               np.concatenate([s[2] for s in shards]), np.concatenate([s[3] for s in shards]),
+               torch.cat([s[4] for s in shards]), torch.cat([s[5] for s in shards], dim=1))
+        _step(ts4, model4, cat)
+        g_cat = ts4.flat_g[:ts4.n_active].cpu().numpy().copy()
+    q.put((rank, issued, flat_bucketed, flat_single, float(parts["loss"]), grads_avg, g_eval, g_cat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(backend):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=600)
+        res[r[0]] = r[1:]
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    issued0, flat0, single0, loss0, gavg0, geval0, gcat = res[0]
+    issued1, flat1, single1, loss1, gavg1, geval1, _ = res[1]
+    # 1. same collective sequence everywhere; decode-written bucket first, shallow encoder bucket last
+    assert issued0 == issued1, (issued0, issued1)
+    buckets = [b for b, _ in issued0]
+    assert set(buckets) == {0, 1, 2, 3} and buckets[0] == 0 and buckets[-1] == 2, issued0
+    assert buckets.index(3) < buckets.index(2)
+    # 2. ranks agree bit for bit; 3. and with the un-bucketed exchange
+    assert np.array_equal(flat0, flat1), "ranks diverged after the averaged step"
+    assert np.array_equal(flat0, single0) and np.array_equal(flat1, single1), "bucketed != single all-reduce"
+    assert np.array_equal(gavg0, gavg1) and loss0 != loss1
+    # 4. evaluation-mode BatchNorm: averaged shards == concatenated batch
+    assert np.array_equal(geval0, geval1)
+    scale = max(float(np.abs(gcat).max()), 1e-6)
+    err = float(np.abs(geval0 - gcat).max())
+    assert err <= 2e-5 * scale + 1e-7, (err, scale)
+
+
+def test_two_ranks_one_gpu_gloo():
+    _run("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: two GPUs")
+def test_two_ranks_rccl():
+    _run("nccl")

@@ -372,6 +372,47 @@ def test_edge_shapes_vs_oracle(B, Tt, L, lens, flens):
     assert len(loose) <= 3, loose
 
 
+def test_g6_trainstep_against_the_reference_adam_step():
+    """TrainStep.step (forward, loss, backward, clip_grad_norm_(1.0), Adam lr 5e-4) on the g6 batch against the state
+    the REFERENCE model held after its own optimiser step (golden post_*: three parameters, two BatchNorm running
+    buffers).  Adam's first step moves an element by lr * g / (|g| + 1e-8) ~ lr * sign(g): elements whose clipped
+    gradient is at rounding-noise level (< 1e-5 here) may land anywhere within 2 lr; every other element must agree
+    to 2e-6, the running statistics to rtol 1e-5."""
+    from acvae_amd.trainer import TrainStep
+    g = load_golden("g6_train_step")
+    B, Tt, V, E, L = (int(x) for x in g["dims"])
+    seed = int(g["seed"])
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, Tt, V, L, seed=seed, ragged=bool(int(g["ragged"])))
+    model = build_model(V, E, state).train()
+    model.encoder.dropout_masks = unpack_masks(g)
+    model.noise = dict(eps_q=T(g["noise_eps_q"]), eps_p=T(g["noise_eps_p"]))
+    ts = TrainStep(model, V, lr=5e-4, max_grad_norm=1.0, smoothing=0.1, alpha=1.0)
+    random.seed(seed)
+    parts = ts.step(feats.cuda(), feat_lens.copy(), caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5)
+    assert abs(float(parts["loss"]) - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert abs(float(parts["grad_norm"]) - float(g["grad_norm"])) <= 1e-3 * float(g["grad_norm"])
+    coef = min(1.0, 1.0 / (float(parts["grad_norm"]) + 1e-6))
+    sd = model.state_dict()
+    named = dict(model.named_parameters())
+    checked = 0
+    for k in [k for k in g if k.startswith("post_")]:
+        name, ref = k[5:], T(g[k]).double()
+        got = sd[name].detach().cpu().double()
+        if name in named:
+            gr = named[name].grad.detach().cpu().double().abs() * coef
+            err = (got - ref).abs()
+            firm = gr >= 1e-5
+            assert float(firm.double().mean()) > 0.9, (name, float(firm.double().mean()))
+            assert float(err[firm].max()) <= 2e-6, (name, float(err[firm].max()))
+            assert float(err.max()) <= 2.1 * ts.lr, (name, float(err.max()))
+            assert float((got - state[name].double()).abs().max()) > 0.5 * ts.lr      # the step was taken at all
+        else:
+            close(got, ref, 1e-5, 1e-7, what=name)
+        checked += 1
+    assert checked == 5
+
+
 def test_checkpoint_round_trip_and_torch_adam_compat():
     """{"model", "optimizer"} checkpoint in the reference's format: resuming from it continues bit for bit, and a
     torch.optim.Adam over the same parameters accepts the optimiser part (it takes the same second step)."""

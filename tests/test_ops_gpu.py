@@ -192,17 +192,41 @@ def test_g3_ce_golden_and_backward():
     for smooth, key in ((0.1, "ls_packed"), (0.0, "ce_packed")):
         _lib.call("acvae_ls_ce_fwd", lg, Tt * V, V, tg, Tt, l1, lse, smooth, 1, rows, out, N, Tt, V, S())
         close(out[0], g[key], 1e-6, 1e-5)
-    _lib.call("acvae_ls_ce_fwd", lg, Tt * V, V, tg, Tt, l1, lse, 0.0, 0, rows, None, N, Tt, V, S())
-    close(rows, g["restated_masked_ce_none"], 1e-5, 1e-5)
     _lib.call("acvae_ls_ce_fwd", lg, Tt * V, V, tg, Tt, l1, lse, 0.1, 1, rows, out, N, Tt, V, S())
-    close(out[0], g["restated_masked_ls_mean"], 1e-6, 1e-5)
+    close(out[0], g["ls_packed"], 1e-6, 1e-5)       # masked mean == packed mean (A13 vs A8)
     lr = logits.clone().requires_grad_(True)
     (O.masked_ce(lr, targets, g["lens1"], 0.1, "mean") * 1.7).backward()
     dl = torch.empty(N, Tt, V, device="cuda")
     _lib.call("acvae_ls_ce_bwd", lg, Tt * V, V, tg, Tt, l1, lse, 0.1, 1, torch.tensor([1.7], device="cuda"), None, dl,
               N, Tt, V, S())
     close(dl, lr.grad, 1e-4, 1e-7)
-    # MSE
+    mse_check(out)
+
+
+def test_g3b_masked_losses_of_losses_py_golden():
+    """A13 (losses/loss.py:12-70): MaskedCrossEntropyLoss / MaskedLabelSmoothingLoss on the HIP path against the
+    reference's own classes (golden g3b: values for none / mean / sum and d loss / d logits for mean / sum)."""
+    from acvae_amd.train_util import MaskedCrossEntropyLoss, MaskedLabelSmoothingLoss
+    g = load_golden("g3b_masked_losses")
+    targets, lens = dev(g["targets"]), g["lens"]
+    for name, mk in (("ce", lambda red: MaskedCrossEntropyLoss(reduction=red)),
+                     ("ls", lambda red: MaskedLabelSmoothingLoss(smoothing=0.1, reduction=red))):
+        for red in ("none", "mean", "sum"):
+            x = dev(g["logits"]).requires_grad_(True)
+            val = mk(red)({"logits": x, "targets": targets, "lens": lens})
+            close(val, g[f"{name}_{red}"], 1e-5, 1e-5)
+            if red != "none":
+                val.backward()
+                close(x.grad, g[f"{name}_{red}_dlogits"], 1e-4, 1e-7)
+            else:                                            # row-wise upstream gradient through reduction="none"
+                w = torch.linspace(0.5, 1.5, val.numel()).reshape(val.shape)
+                (val * w.cuda()).sum().backward()
+                xr = T(g["logits"]).clone().requires_grad_(True)
+                (O.masked_ce(xr, T(g["targets"]), lens, 0.0 if name == "ce" else 0.1, "none") * w).sum().backward()
+                close(x.grad, xr.grad, 1e-4, 1e-7)
+
+
+def mse_check(out):
     a, b = torch.randn(33, 70), torch.randn(33, 70)
     part = torch.empty(_lib.call("acvae_kl_partials", a.numel()), device="cuda")
     _lib.call("acvae_mse_fwd", dev(a), dev(b), part, out, a.numel(), S())

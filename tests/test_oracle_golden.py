@@ -46,6 +46,21 @@ def test_g3_ce():
     close(O.masked_ce(logits, targets, lens1, 0.1, "mean"), g["ls_packed"], 1e-6, 1e-6)
 
 
+def test_g3b_masked_losses_of_losses_py():
+    """A13: the oracle's masked CE / label-smoothed CE against the values the reference's own losses/loss.py classes
+    produced (oracle/make_golden.py:g3b_masked_losses), all three reductions."""
+    g = load_golden("g3b_masked_losses")
+    logits, targets, lens = T(g["logits"]), T(g["targets"]), g["lens"]
+    for name, sm in (("ce", 0.0), ("ls", 0.1)):
+        for red in ("none", "mean", "sum"):
+            x = logits.clone().requires_grad_(True)
+            val = O.masked_ce(x, targets, lens, sm, red)
+            close(val, g[f"{name}_{red}"], 1e-6, 1e-6)
+            if red != "none":
+                val.backward()
+                close(x.grad, g[f"{name}_{red}_dlogits"], 1e-5, 1e-8)
+
+
 def test_g4_encoder():
     g = load_golden("g4_encoder")
     full = O.closed_form_state(O.state_shapes(10))
