@@ -359,6 +359,26 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
                                 float* cp_final, void* saved_v, int64_t saved_bytes, void* scratch_v,
                                 int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc,
                                 int start_idx, int end_idx, void* stream, void* aux_stream) {
+  return acvae_decode_fwd_sampled(params, mem_in, mem_lens, caps, ld_caps, lens1, q_z, eps_p, ss_flags_host,
+                                  dis_flags_host, logits, outputs, seqs, sampled_logprobs, attn_w, p_means, p_logs, p_z,
+                                  p_means_utt, h_final, hp_final, cp_final, saved_v, saved_bytes, scratch_v,
+                                  scratch_bytes, N, Tc, S, E, H, A, V, Eenc, start_idx, end_idx, stream, aux_stream,
+                                  ACVAE_SAMPLE_GREEDY, 1.f, nullptr);
+}
+
+extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, const int64_t* mem_lens,
+                                        const int64_t* caps, int64_t ld_caps, const int64_t* lens1, const float* q_z,
+                                        const float* eps_p, const int* ss_flags_host, const int* dis_flags_host,
+                                        float* logits, float* outputs, int64_t* seqs, float* sampled_logprobs,
+                                        float* attn_w, float* p_means, float* p_logs, float* p_z, float* p_means_utt,
+                                        float* h_final, float* hp_final, float* cp_final, void* saved_v,
+                                        int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S,
+                                        int E, int H, int A, int V, int Eenc, int start_idx, int end_idx, void* stream,
+                                        void* aux_stream, int sample_method, float temp, const float* sample_noise) {
+  if (sample_method != ACVAE_SAMPLE_GREEDY &&
+      ((sample_method != ACVAE_SAMPLE_GUMBEL && sample_method != ACVAE_SAMPLE_MULTINOMIAL) || !sample_noise ||
+       !(temp > 0.f)))
+    return ACVAE_EINVAL;
   DecLayout L;
   ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
   if (!params || !mem_in || !mem_lens || !eps_p || !logits || !outputs || !seqs || !sampled_logprobs || !attn_w ||
@@ -506,6 +526,10 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
                    ldof(cnt, V), M, V, H, 0, st));
     ACVAE_TRY(acvae_row_logsoftmax_argmax(logits + (long)t0 * V, (long)Tc * V, V, seqs + t0, sampled_logprobs + t0,
                                           lse + t0, Tc, 1, N, cnt, V, st));
+    if (sample_method != ACVAE_SAMPLE_GREEDY)      // word_model.py:188-203 overwrite the greedy choice
+      ACVAE_TRY(acvae_sample_next_word(logits + (long)t0 * V, (long)Tc * V, V, sample_noise + (long)t0 * N * V, V,
+                                       (long)N * V, sample_method, temp, seqs + t0, sampled_logprobs + t0, Tc, 1, N, cnt,
+                                       V, st));
     return ACVAE_OK;
   };
 

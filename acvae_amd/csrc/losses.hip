@@ -169,6 +169,60 @@ __global__ __launch_bounds__(EW_THREADS) void row_stats_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------------------ sample_next_word, non-greedy branches
+// models/word_model.py:188-203.  logprobs = log_softmax(logits) as torch evaluates it, (x - max) - log(sum exp(x - max));
+//   method 1 "gumbel"  (:188-197): w = argmax_c (logprobs_c + g_c) / temp,  g = -log(-log(U + 1e-20) + 1e-20) drawn by the
+//                      caller (U = torch.rand on the CPU generator); the reference takes the argmax of
+//                      log_softmax((logprobs + g) / temp), a monotone map of the same scores;
+//   method 2 "sample"  (:198-203): w = torch.multinomial(exp(logprobs / temp), 1), which ATen evaluates as
+//                      argmax_c exp(logprobs_c / temp) / q_c with q ~ Exp(1) drawn as one [N,V] tensor
+//                      (aten/src/ATen/native/Distributions.cpp, multinomial_out, n_sample == 1): the caller draws q.
+// First maximum wins, as torch.max / argmax do.  Writes w and logprobs[w] (the reference's sampled_logprobs).
+__global__ __launch_bounds__(EW_THREADS) void sample_rows_kernel(const float* __restrict__ logits, long ld_n, long ld_t,
+                                                                 const float* __restrict__ noise, long nz_sn, long nz_st,
+                                                                 int method, float temp, int64_t* __restrict__ w_out,
+                                                                 float* __restrict__ lp_out, long o_sn, long o_st, int T,
+                                                                 int V) {
+  __shared__ float red[16];
+  __shared__ int redi[16];
+  const int n = blockIdx.x / T, t = blockIdx.x % T;
+  const float* x = logits + n * ld_n + t * ld_t;
+  const float* z = noise + n * nz_sn + t * nz_st;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < V; c += EW_THREADS) m = fmaxf(m, x[c]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += EW_THREADS) s += expf(x[c] - m);
+  s = block_sum(s, red);
+  const float ls = logf(s);
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = threadIdx.x; c < V; c += EW_THREADS) {
+    const float lp = (x[c] - m) - ls;
+    const float sc = method == 1 ? (lp + z[c]) / temp : expf(lp / temp) / z[c];
+    if (sc > best || bi == 0x7fffffff) { best = sc; bi = c; }   // strict '>': first maximum within the stride
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  __syncthreads();
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w] = best; redi[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = red[0]; bi = redi[0];
+    for (int i = 1; i < EW_THREADS / 64; ++i)
+      if (red[i] > best || (red[i] == best && redi[i] < bi)) { best = red[i]; bi = redi[i]; }
+    if (bi < 0 || bi >= V) bi = 0;                      // every score NaN: torch returns index 0 as well
+    const long o = n * o_sn + t * o_st;
+    w_out[o] = bi;
+    if (lp_out) lp_out[o] = (x[bi] - m) - ls;
+  }
+}
+
 // ------------------------------------------------------------------ label-smoothed CE
 // loss_row = -[(1-s) * lp_tgt + s/(V-1) * (sum_c lp_c - lp_tgt)],  lp_c = x_c - lse.
 __global__ __launch_bounds__(EW_THREADS) void ce_rows_kernel(const float* __restrict__ logits, long ld_n, long ld_t,
@@ -420,6 +474,17 @@ extern "C" int acvae_row_logsoftmax_argmax(const float* logits, int64_t ld_n, in
   if (!logits || N <= 0 || T <= 0 || V <= 0) return ACVAE_EINVAL;
   hipLaunchKernelGGL(row_stats_kernel, dim3(N * T), dim3(EW_THREADS), 0, (hipStream_t)stream, logits, ld_n, ld_t,
                      argmax, max_logprob, lse, o_sn, o_st, T, V);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_sample_next_word(const float* logits, int64_t ld_n, int64_t ld_t, const float* noise,
+                                      int64_t nz_sn, int64_t nz_st, int method, float temp, int64_t* w_out,
+                                      float* logprob_out, int64_t o_sn, int64_t o_st, int N, int T, int V, void* stream) {
+  if (!logits || !noise || !w_out || N <= 0 || T <= 0 || V <= 0) return ACVAE_EINVAL;
+  if ((method != ACVAE_SAMPLE_GUMBEL && method != ACVAE_SAMPLE_MULTINOMIAL) || !(temp > 0.f)) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(N * T), dim3(EW_THREADS), 0, (hipStream_t)stream, logits, ld_n, ld_t, noise,
+                     nz_sn, nz_st, method, temp, w_out, logprob_out, o_sn, o_st, T, V);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

@@ -26,7 +26,7 @@ from .word_model import CaptionModel
 
 class _DecodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, mem, mem_lens_d, caps_d, lens1_d, q_z, eps_p, ss_flags, dis_flags, Tc, *weights):
+    def forward(ctx, model, mem, mem_lens_d, caps_d, lens1_d, q_z, eps_p, ss_flags, dis_flags, Tc, sampling, *weights):
         N, S, Eenc = mem.shape
         dec = model.decoder
         E, H, A, V = dec.embed_size, dec.model.hidden_size, dec.attn.attn_size, dec.vocab_size
@@ -51,10 +51,11 @@ class _DecodeFn(torch.autograd.Function):
         ss_arr = IntArr(*[int(bool(x)) for x in ss_flags]) if train else None
         dis_arr = IntArr(*[int(bool(x)) for x in dis_flags]) if train else IntArr(*([1] * Tc))
         mem = mem.contiguous()
-        _lib.call("acvae_decode_fwd", ptr_table(params), mem, mem_lens_d, caps_d, caps_d.stride(0) if train else 0,
-                  lens1_d, q_z, eps_p, ss_arr, dis_arr, logits, outputs, seqs, slp, attw, pm, pl, pz, putt, hfin, hp, cp,
-                  saved, saved_b, scratch, scratch_b, *dims, model.start_idx, model.end_idx, _lib.current_stream(),
-                  model._aux_stream())
+        method, temp, noise = sampling if sampling is not None else (0, 1.0, None)
+        _lib.call("acvae_decode_fwd_sampled", ptr_table(params), mem, mem_lens_d, caps_d,
+                  caps_d.stride(0) if train else 0, lens1_d, q_z, eps_p, ss_arr, dis_arr, logits, outputs, seqs, slp,
+                  attw, pm, pl, pz, putt, hfin, hp, cp, saved, saved_b, scratch, scratch_b, *dims, model.start_idx,
+                  model.end_idx, _lib.current_stream(), model._aux_stream(), int(method), float(temp), noise)
         ctx.model, ctx.saved, ctx.dims, ctx.dis_arr = model, saved, dims, dis_arr
         # outputs kept as plain ctx attributes would form tensor -> grad_fn -> ctx -> tensor cycles that are never collected
         ctx.save_for_backward(mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl)
@@ -107,7 +108,7 @@ class _DecodeFn(torch.autograd.Function):
                 torch.autograd.Variable._execution_engine.queue_callback(lambda: cur.wait_stream(side))
         ctx.saved = None
         outs = [next((g for p, g in zip(params, grads) if p is w), None) for w in model._decode_weights()]
-        return (None, d_mem, None, None, None, d_qz, None, None, None, None, *outs)
+        return (None, d_mem, None, None, None, d_qz, None, None, None, None, None, *outs)
 
 
 class Hybrid_VAEModel(CaptionModel):
@@ -331,11 +332,7 @@ class Hybrid_VAEModel(CaptionModel):
             return self.diverse_beam_search(encoded, max_length, kwargs.get("beam_size", 5), kwargs.get("group_size", 5),
                                             kwargs.get("diversity_lambda", 0.5), kwargs.get("temperature", 1.0),
                                             kwargs.get("group_nbest", True))
-        if method != "greedy":
-            raise NotImplementedError(f"inference method {method!r}: the HIP path implements greedy decoding with "
-                                      "z ~ prior, beam search and diverse beam search (gumbel / multinomial sampling "
-                                      "are not on SURVEY §8's path)")
-        return self.stepwise_forward(encoded, None, None, **kwargs)
+        return self.stepwise_forward(encoded, None, None, **kwargs)     # greedy / "gumbel" / anything else = multinomial
 
     def forward(self, *input, **kwargs):
         """models/vae_model.py:732-760"""
@@ -389,6 +386,17 @@ class Hybrid_VAEModel(CaptionModel):
         self.noise = None
         ss_flags, dis_flags = [], []
         draw = replay is None or replay.get("eps_p") is None
+        # sample_next_word's method (models/word_model.py:173-207): "greedy", "gumbel", anything else = multinomial
+        # sampling with `temp`.  The non-greedy branches draw one [N,V] tensor per step on the CPU generator right after
+        # the step's prior noise (and dis_ratio coin): torch.rand for the Gumbel noise (:189-191), and - inside
+        # torch.multinomial(., 1) - empty(N,V).exponential_(1).  Both are drawn here in that order and uploaded once.
+        method = kwargs.get("method", "greedy")
+        temp = float(kwargs.get("temp", 1))
+        V = self.vocab_size
+        code = 0 if method == "greedy" else (1 if method == "gumbel" else 2)
+        sample_noise = None
+        if code and (replay is None or replay.get("sample_noise") is None):
+            sample_noise = torch.empty(Tc, N, V)
 
         def host_draws(eps):            # eps: [Tc, N, E] staging slot (None when the noise is replayed)
             for t in range(Tc):
@@ -398,6 +406,12 @@ class Hybrid_VAEModel(CaptionModel):
                     torch.randn(N, E, out=eps[t])                                    # text_encoder.py:259 (CPU, F9)
                 if train:
                     dis_flags.append(bool(dis_ratio != 0 and torch.rand(1) <= dis_ratio))   # :802-806
+                if sample_noise is not None:
+                    if code == 1:
+                        U = torch.rand(N, V)                                          # word_model.py:189-191
+                        torch.neg(torch.log(-torch.log(U + 1e-20) + 1e-20), out=sample_noise[t])
+                    else:
+                        sample_noise[t].exponential_(1)                               # torch.multinomial(prob, 1)
 
         if draw:
             eps_p = _lib.h2d_fill((Tc, N, E), torch.float32, dev, host_draws)
@@ -408,8 +422,13 @@ class Hybrid_VAEModel(CaptionModel):
         if train:
             caps_d = _lib.h2d(caps, dev, torch.long).contiguous()
             lens1_d = _lib.h2d(lens1, dev, torch.long)
+        sampling = None
+        if code:
+            if sample_noise is None:
+                sample_noise = torch.as_tensor(replay["sample_noise"])[:Tc]
+            sampling = (code, temp, _lib.h2d(sample_noise, dev, torch.float32).contiguous())
         return {"Tc": Tc, "ss_flags": ss_flags, "dis_flags": dis_flags, "eps_p": eps_p, "caps_d": caps_d,
-                "lens1_d": lens1_d}
+                "lens1_d": lens1_d, "sampling": sampling}
 
     def stepwise_forward(self, encoded, caps, cap_lens, **kwargs):
         """models/vae_model.py:700-730 with decode_step (:792-816), prepare_decoder_input (:818-848) and
@@ -428,7 +447,7 @@ class Hybrid_VAEModel(CaptionModel):
         q_z = encoded["q_z"] if train else None
         self.staged = {"caps_d": caps_d, "lens1_d": lens1_d}           # device copies the loss can reuse
         outs = _DecodeFn.apply(self, mem, mem_lens_d, caps_d, lens1_d, q_z, eps_p, ss_flags, dis_flags, Tc,
-                               *self._decode_weights())
+                               prep.get("sampling"), *self._decode_weights())
         logits, outputs, seqs, slp, attw, pm, pl, pz, putt, hfin, hp, cp = outs
         output = {"seqs": seqs, "logits": logits, "outputs": outputs, "sampled_logprobs": slp,
                   "attn_weights": attw.transpose(1, 2), "p_means": pm, "p_logs": pl, "p_z": pz,

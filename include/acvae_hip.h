@@ -97,6 +97,20 @@ int acvae_gauss_kl_bwd(const float* mu1, const float* lv1, const float* mu2, con
  * ------------------------------------------------------------------------------------------- */
 int acvae_row_logsoftmax_argmax(const float* logits, int64_t ld_n, int64_t ld_t, int64_t* argmax, float* max_logprob,
                                 float* lse, int64_t o_sn, int64_t o_st, int N, int T, int V, void* stream);
+/* The non-greedy branches of sample_next_word (models/word_model.py:188-203) for rows (n,t) of logits as above.
+ *   ACVAE_SAMPLE_GUMBEL      w = argmax_c (log_softmax(logits)_c + g_c) / temp, g = -log(-log(U+1e-20)+1e-20) with
+ *                            U = torch.rand(N,V) drawn by the caller on the CPU generator (:189-191);
+ *   ACVAE_SAMPLE_MULTINOMIAL w = torch.multinomial(exp(log_softmax(logits) / temp), 1) = argmax_c p_c / q_c with
+ *                            q = empty(N,V).exponential_(1), which is how ATen draws one sample per row; the caller
+ *                            draws q the same way.
+ * noise row (n,t) at noise + n*nz_sn + t*nz_st (V floats: g or q).  Writes w (int64) and log_softmax(logits)[w]
+ * (the reference's "probs") at w_out / logprob_out + n*o_sn + t*o_st.  First maximum wins (torch.max). */
+#define ACVAE_SAMPLE_GREEDY 0
+#define ACVAE_SAMPLE_GUMBEL 1
+#define ACVAE_SAMPLE_MULTINOMIAL 2
+int acvae_sample_next_word(const float* logits, int64_t ld_n, int64_t ld_t, const float* noise, int64_t nz_sn,
+                           int64_t nz_st, int method, float temp, int64_t* w_out, float* logprob_out, int64_t o_sn,
+                           int64_t o_st, int N, int T, int V, void* stream);
 /* reduction: 0 none (writes loss_rows only), 1 mean over valid rows, 2 sum.  loss_rows [N,T] (0 at invalid rows). */
 int acvae_ls_ce_fwd(const float* logits, int64_t ld_n, int64_t ld_t, const int64_t* targets, int64_t tg_sn,
                     const int64_t* lens1, const float* lse, float smoothing, int reduction, float* loss_rows,
@@ -157,6 +171,71 @@ int acvae_encoder_bwd_hooked(const void* const* params, void* const* grads, cons
                              uint64_t seed, const uint8_t* const* masks, void* stream, void* block_done, void* user);
 
 /* ---------------------------------------------------------------------------------------------
+ * The encoder's kernels one by one (conv3x3[_bn], bn_mel, bn pieces): the same launchers
+ * acvae_encoder_fwd / _bwd sequence, each callable - and tested - alone.  Activations are NHWC
+ * [N][H][W][C] fp32 (the reference is NCHW: torch.nn.Conv2d(.., (3,3), (1,1), (1,1), bias=False),
+ * models/encoder.py:612-622, 633-649), weights OIHW as in the state dict.  `ws`: scratch of
+ * acvae_conv3x3_workspace_bytes / acvae_bn_workspace_bytes for the same dims, 16-byte aligned.
+ *   acvae_conv3x3_fwd   Y = conv3x3(act(X), W), act = relu(x * in_scale[ci] + in_shift[ci]) (the PREVIOUS layer's fused
+ *                       BatchNorm+ReLU) or the identity when in_scale == NULL.  If bn_out != NULL it also returns THIS
+ *                       layer's BatchNorm as [4][Cout] = scale | shift | mean | invstd (y_bn = Y*scale + shift) from the
+ *                       batch statistics (training != 0: running buffers updated, momentum 0.1, unbiased variance) or
+ *                       from the running buffers (training == 0).  Cin == 1 is the stack's first convolution:
+ *                       in_scale / in_shift are then bn0's per-MEL affine [W] (required), W = 64, Cout = 64.
+ *   acvae_conv3x3_dgrad dX = conv3x3(dY, flipped / transposed W)           (Cin >= 32)
+ *   acvae_conv3x3_wgrad dW[co][ci][tap] = sum_p dY[p][co] * act(X)[p + tap][ci]      (Cin >= 4; Cin == 1: below)
+ *   acvae_conv1_first_bwd  first convolution: dW1 [64][1][3][3] and bn0's dgamma / dbeta [64] (x [N,T,64] features,
+ *                       bn0 = [4][64] from acvae_bn_mel_fwd).
+ *   acvae_bn_mel_fwd    bn0 (BatchNorm2d(64) over the MEL axis, models/encoder.py:655, 679-681) statistics of x [rows,64]
+ *                       -> bn_out [4][64]; the normalised tensor is never written: the first convolution applies it.
+ *   acvae_bn_relu_pool_fwd  P = dropout(avg_pool2x2(relu(Y*scale + shift)))  (pool != 0) or dropout(relu(..)) (pool == 0:
+ *                       ConvBlock pool_size (1,1)); bn = [4][C] as above; dropout p_drop with Philox(seed, site) or an
+ *                       explicit keep mask (NCHW order), p_drop = 0 disables.
+ *   acvae_bn_relu_bwd   backward of relu(bn(Y)) for upstream dO: upstream 0 = dO [N,H,W,C] as is, 1 = dO [N,H/2,W/2,C]
+ *                       through dropout + 2x2 average pool, 2 = through dropout only.  Writes dgamma, dbeta [C] and dY.
+ *                       training == 0: evaluation-mode BatchNorm (dY = scale * g).
+ * ------------------------------------------------------------------------------------------- */
+int64_t acvae_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int acvae_conv3x3_fwd(const float* X, const float* W_oihw, const float* in_scale, const float* in_shift, float* Y,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, int training, float* bn_out, void* ws, int64_t ws_bytes, int N, int H,
+                      int W, int Cin, int Cout, void* stream);
+int acvae_conv3x3_dgrad(const float* dY, const float* W_oihw, float* dX, void* ws, int64_t ws_bytes, int N, int H, int W,
+                        int Cin, int Cout, void* stream);
+int acvae_conv3x3_wgrad(const float* dY, const float* X, const float* in_scale, const float* in_shift, float* dW_oihw,
+                        void* ws, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
+int acvae_conv1_first_bwd(const float* x, const float* bn0, const float* W1_oihw, const float* dY, float* dW1,
+                          float* dgamma0, float* dbeta0, void* ws, int64_t ws_bytes, int N, int T, int F, void* stream);
+int64_t acvae_bn_workspace_bytes(int N, int H, int W, int C);
+int acvae_bn_mel_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, int training, float* bn_out, void* ws, int64_t ws_bytes, int64_t rows,
+                     int F, void* stream);
+int acvae_bn_relu_pool_fwd(const float* Y, const float* bn, float* P, int N, int H, int W, int C, int pool, float p_drop,
+                           uint64_t seed, int site, const uint8_t* keep_mask, void* stream);
+int acvae_bn_relu_bwd(const float* Y, const float* dO, int upstream, const float* bn, float* dgamma, float* dbeta,
+                      float* dY, void* ws, int64_t ws_bytes, int N, int H, int W, int C, int training, float p_drop,
+                      uint64_t seed, int site, const uint8_t* keep_mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The recurrent cells one by one (gru_step, lstm_step, bigru_seq), torch.nn.GRU / LSTM
+ * semantics and weight layout (gate order r|z|n and i|f|g|o):
+ *   acvae_gru_step   one step of the decoder's GRU, models/decoder.py:39-44, 190: x [N,I], h [N,H] -> h_out [N,H]
+ *   acvae_lstm_step  one step of the prior's LSTM, models/text_encoder.py:229-235, 254: (h, c) -> (h_out, c_out)
+ *   acvae_bigru_seq  the posterior's packed bidirectional GRU, models/text_encoder.py:189-191: X [N,Tc,E] (batch-major),
+ *                    lens [N] int64 (rows stop at their length; padded outputs are zero, pad_packed_sequence),
+ *                    w = {w_ih, w_hh, b_ih, b_hh, then the same four of the reverse direction}, hidden [N,Tc,2H].
+ * `ws`: scratch of acvae_rnn_workspace_bytes(N, Tc (1 for the single steps), I, H).
+ * ------------------------------------------------------------------------------------------- */
+int64_t acvae_rnn_workspace_bytes(int N, int Tc, int I, int H);
+int acvae_gru_step(const float* x, const float* h, const float* w_ih, const float* w_hh, const float* b_ih,
+                   const float* b_hh, float* h_out, void* ws, int64_t ws_bytes, int N, int I, int H, void* stream);
+int acvae_lstm_step(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
+                    const float* b_ih, const float* b_hh, float* h_out, float* c_out, void* ws, int64_t ws_bytes, int N,
+                    int I, int H, void* stream);
+int acvae_bigru_seq(const float* X, const int64_t* lens, const void* const* w, float* hidden, void* ws, int64_t ws_bytes,
+                    int N, int Tc, int E, int H, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Text side of the path.  `params` / `grads` are pointer tables in the reference's state-dict order
  * after the encoder (ACVAE_TEXT_NPARAMS entries; ln.* may be NULL when absent):
  *   decoder.{word_embeddings.weight, model.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0},
@@ -211,6 +290,18 @@ int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64
                      float* p_means_utt, float* h_final, float* hp_final, float* cp_final, void* saved,
                      int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int Tc, int S, int E, int H,
                      int A, int V, int Eenc, int start_idx, int end_idx, void* stream, void* aux_stream);
+/* The same with sample_next_word's method (models/word_model.py:173-207) chosen by the caller: ACVAE_SAMPLE_GREEDY
+ * (= acvae_decode_fwd), or GUMBEL / MULTINOMIAL with `temp` and `sample_noise` [Tc,N,V] (see acvae_sample_next_word; the
+ * per-step draws of the reference in step order).  seqs / sampled_logprobs then hold the sampled words; with
+ * scheduled sampling or in inference the sampled word of step t-1 is the input of step t (vae_model.py:829-832). */
+int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, const int64_t* mem_lens,
+                             const int64_t* caps, int64_t ld_caps, const int64_t* lens1, const float* q_z,
+                             const float* eps_p, const int* ss_flags_host, const int* dis_flags_host, float* logits,
+                             float* outputs, int64_t* seqs, float* sampled_logprobs, float* attn_w, float* p_means,
+                             float* p_logs, float* p_z, float* p_means_utt, float* h_final, float* hp_final,
+                             float* cp_final, void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes,
+                             int N, int Tc, int S, int E, int H, int A, int V, int Eenc, int start_idx, int end_idx,
+                             void* stream, void* aux_stream, int sample_method, float temp, const float* sample_noise);
 /* Backward for upstream gradients of logits / outputs / p_means / p_logs / p_z / p_means_utt (each may be
  * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E].
  * Stream contract: d_mem_in is ordered on `stream` when the call returns.  When acvae_decode_bwd_defers() says 1 for the

@@ -336,8 +336,31 @@ def decoder_step(state, word, h, enc_mem, enc_mem_lens, z, prefix="decoder"):
 # ----------------------------------------------------------------------------
 # A6/A7/A12  Hybrid_VAEModel   models/vae_model.py:700-894 ; word_model.py:173-207
 # ----------------------------------------------------------------------------
+def sample_next_word(logits, method="greedy", temp=1, noise=None):
+    """CaptionModel.sample_next_word, models/word_model.py:173-207.  `noise` (optional) replays the branch's draw:
+    the Gumbel noise g [N,V] (:189-191) or, for the multinomial branch, the Exp(1) tensor q [N,V] that
+    torch.multinomial(prob, 1) draws internally (argmax of prob / q: ATen's one-sample path).  Returns
+    (w_t, logprob of w_t, the noise used)."""
+    logprobs = torch.log_softmax(logits, dim=1)
+    if method == "greedy":
+        lp, w_t = torch.max(logprobs, 1)
+        return w_t.detach().long(), lp, None
+    if method == "gumbel":
+        if noise is None:
+            U = torch.rand(logprobs.size())
+            noise = -torch.log(-torch.log(U + 1e-20) + 1e-20)
+        _logprob = torch.log_softmax((logprobs + noise) / temp, dim=-1)
+        _, w_t = torch.max(_logprob.data, 1)
+        return w_t.detach().long(), logprobs.gather(1, w_t.unsqueeze(-1)).squeeze(1), noise
+    prob_prev = torch.exp(logprobs / temp)
+    if noise is None:
+        noise = torch.empty_like(prob_prev).exponential_(1)
+    w_t = torch.argmax(prob_prev / noise, dim=-1, keepdim=True)           # == torch.multinomial(prob_prev, 1)
+    return w_t.view(-1).detach().long(), logprobs.gather(1, w_t).squeeze(1), noise
+
+
 def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_ratio=1.0, dis_ratio=0,
-                   training=True, method="greedy", max_length=MAX_LENGTH, noise=None, record=None,
+                   training=True, method="greedy", temp=1, max_length=MAX_LENGTH, noise=None, record=None,
                    mutate_lens=True):
     """4-input form = train_forward, 2-input form = inference_forward(greedy).
     `noise` (optional): dict(dropout=[masks...], eps_q=[N,Tc,E], eps_p=[Tc,N,E]) to replay; else drawn
@@ -361,7 +384,7 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         steps = max_length
     seqs = torch.full((N, steps), END_IDX, dtype=torch.long)                  # prepare_output :762-790
     logits, outputs, slp, attw = [], [], [], []
-    p_means, p_logs, p_z, eps_p = [], [], [], []
+    p_means, p_logs, p_z, eps_p, sample_noise = [], [], [], [], []
     h = mem.new_zeros(N, H)
     hc = (mem.new_zeros(N, E), mem.new_zeros(N, E))                           # PriorRNN.init_hidden :240-245
     last_z = mem.new_zeros(N, E)
@@ -383,9 +406,11 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         else:
             z = pr["z"]
         d = decoder_step(state, word.unsqueeze(1), h, mem, mem_lens, z)
-        logprobs = torch.log_softmax(d["logits"], dim=1)                      # sample_next_word greedy
-        lp, w_t = torch.max(logprobs, 1)
-        seqs[:, t] = w_t.detach()
+        sn = None if noise is None or noise.get("sample_noise") is None else noise["sample_noise"][t]
+        w_t, lp, sn_used = sample_next_word(d["logits"], method, temp, sn)     # word_model.py:173-207
+        if sn_used is not None:
+            sample_noise.append(sn_used)
+        seqs[:, t] = w_t
         logits.append(d["logits"]); outputs.append(d["output"]); slp.append(lp); attw.append(d["weights"])
         p_means.append(pr["mean"]); p_logs.append(pr["log"]); p_z.append(pr["z"])
         h, hc, last_z = d["state"], pr["hiddens_state"], pr["z"]
@@ -412,6 +437,7 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         record["dropout"] = rec_masks
         record["eps_q"] = q["_eps"] if train else None
         record["eps_p"] = torch.stack(eps_p, 0)
+        record["sample_noise"] = torch.stack(sample_noise, 0) if sample_noise else None
     return out
 
 

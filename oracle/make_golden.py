@@ -265,6 +265,47 @@ def g7_decode(ref):
     save("g7_decode", **d)
 
 
+def g14_sampling(ref):
+    """G14: the non-greedy branches of sample_next_word (models/word_model.py:188-203) through the
+    reference's inference path (models/vae_model.py:880-894): method="sample" (multinomial, several temperatures,
+    3 clips at once) and method="gumbel" (the reference's branch only runs with ONE clip per call: with more its
+    sampled_logprobs assignment raises, word_model.py:197 / :165 - so one clip per call here).  The fixture keeps the
+    reference's token ids and log-probabilities, and the noise the run drew: the prior's eps per step and the [N,V]
+    Gumbel / Exp(1) tensor per step (re-drawn here from the same seed in the same order; the oracle replaying them
+    must return the reference's tokens, asserted)."""
+    V, E = 50, 64
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    model = ref_shim.build_reference_model(ref, V, E, E)
+    load_state_into(model, state)
+    model.eval()
+    feats, _, feat_lens, _ = O.synthetic_batch(3, 96, V, 8, seed=14, ragged=True)
+    d = dict(dims=np.array([3, 96, V, E]), feats=feats, feat_lens=feat_lens)
+    cases = [("sample_t1", "sample", 1.0, slice(0, 3)), ("sample_t07", "sample", 0.7, slice(0, 3)),
+             ("sample_t15", "sample", 1.5, slice(0, 3)), ("gumbel_t1_c0", "gumbel", 1.0, slice(0, 1)),
+             ("gumbel_t05_c1", "gumbel", 0.5, slice(1, 2)), ("gumbel_t2_c2", "gumbel", 2.0, slice(2, 3))]
+    for ci, (tag, method, temp, sl) in enumerate(cases):
+        l_ = feat_lens[sl].copy()
+        f = feats[sl][:, :int(l_.max())]                   # a batch is padded to ITS longest clip (collate_fn)
+        torch.manual_seed(140 + ci)
+        with torch.no_grad():
+            ro = model(f, l_.copy(), method=method, temp=temp)
+        rec = {}
+        torch.manual_seed(140 + ci)
+        with torch.no_grad():
+            oo = O.hybrid_forward({k: v.clone() for k, v in state.items()}, f, l_.copy(), training=False, method=method,
+                                  temp=temp, record=rec)
+        assert torch.equal(ro["seqs"], oo["seqs"]), (tag, ro["seqs"], oo["seqs"])
+        n, steps = f.shape[0], rec["eps_p"].shape[0]
+        eps = torch.zeros(O.MAX_LENGTH, n, E); eps[:steps] = rec["eps_p"]
+        sn = torch.ones(O.MAX_LENGTH, n, V); sn[:steps] = rec["sample_noise"]
+        d[tag + "_seqs"] = ro["seqs"]; d[tag + "_logprobs"] = ro["sampled_logprobs"][:, :steps]
+        d[tag + "_steps_run"] = np.array(steps); d[tag + "_temp"] = np.array(temp)
+        d[tag + "_noise_eps_p"] = eps; d[tag + "_sample_noise"] = sn
+        d[tag + "_clips"] = np.array([sl.start, sl.stop])
+    d["cases"] = np.array([c[0] for c in cases]); d["methods"] = np.array([c[1] for c in cases])
+    save("g14_sampling", **d)
+
+
 def g9_beam(ref):
     """G9: validation beam search, beam_size=3 (models/vae_model.py:896-995), eval mode."""
     V, E, beam = 50, 64, 3
@@ -419,6 +460,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dbs":
         g11_dbs(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "sampling":
+        g14_sampling(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cnn14":
         g12_cnn14(ref)
         train_fixture(ref, "g13_train_step_cnn14", 2, 64, 40, 64, 6, True, 0, seed=36, keep_tensors=False,
@@ -433,6 +477,7 @@ def main():
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)
     train_fixture(ref, "g6c_train_step_e512", 2, 64, 300, 512, 7, False, 0, seed=26, keep_tensors=False)
     g7_decode(ref)
+    g14_sampling(ref)
     g9_beam(ref)
     # G8: BASELINE config 1 shape; scalars only, noise re-drawn in the test from the stored seed.
     train_fixture(ref, "g8_config1_scalars", 8, 500, 5000, 512, 22, False, 0, seed=8, keep_tensors=False,

@@ -179,6 +179,63 @@ def test_g7_greedy_decode_token_exact():
         close(o["logits"][:, 0], g[tag + "_logits0"], 1e-4, 2e-5, what=tag + " logits0")
 
 
+def test_g14_sampling_methods_token_exact():
+    """A6: method="sample" (multinomial with temp) and method="gumbel" of sample_next_word (models/word_model.py:188-203)
+    through Hybrid_VAEModel.forward(feats, feat_lens, method=, temp=) against the REFERENCE's own token ids and
+    log-probabilities (golden g14), replaying the noise that run drew."""
+    g = load_golden("g14_sampling")
+    _, _, V, E = (int(x) for x in g["dims"])
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    model = build_model(V, E, state)
+    model.eval()
+    for tag, method in zip(g["cases"], g["methods"]):
+        a, b = (int(x) for x in g[tag + "_clips"])
+        lens = g["feat_lens"][a:b].copy()
+        f = T(g["feats"])[a:b, :int(lens.max())].contiguous().cuda()
+        model.noise = dict(eps_p=T(g[tag + "_noise_eps_p"]), sample_noise=T(g[tag + "_sample_noise"]))
+        with torch.no_grad():
+            o = model(f, lens, method=str(method), temp=float(g[tag + "_temp"]))
+        assert np.array_equal(o["seqs"].cpu().numpy(), g[tag + "_seqs"]), tag
+        steps = int(g[tag + "_steps_run"])
+        close(o["sampled_logprobs"][:, :steps], g[tag + "_logprobs"], 1e-4, 2e-5, what=tag)
+
+
+def test_sampling_draws_follow_the_reference_generator_order():
+    """Without replayed noise the host draws eps and the per-step [N,V] sampling noise on the CPU generator in the
+    reference's order (prior randn, then torch.rand / exponential_ of sample_next_word): same seed -> the oracle's
+    tokens, for inference and for a scheduled-sampling training forward with method="sample"."""
+    V, E = 40, 64
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    feats, caps, feat_lens, cap_lens = O.synthetic_batch(3, 96, V, 6, seed=5, ragged=False)
+    model = build_model(V, E, state)
+    model.eval()
+    for method, temp in (("sample", 0.8), ("gumbel", 1.3)):
+        torch.manual_seed(21)
+        with torch.no_grad():
+            oo = O.hybrid_forward({k: v.clone() for k, v in state.items()}, feats, feat_lens.copy(), training=False,
+                                  method=method, temp=temp)
+        torch.manual_seed(21)
+        with torch.no_grad():
+            o = model(feats.cuda(), feat_lens.copy(), method=method, temp=temp)
+        n = oo["_steps_run"]
+        assert np.array_equal(o["seqs"].cpu().numpy()[:, :n], oo["seqs"].numpy()[:, :n]), method
+    # training forward, ss_ratio < 1: the sampled word of step t-1 is fed at step t when the coin says so
+    rec = {}
+    torch.manual_seed(22); random.seed(22)
+    with torch.no_grad():
+        oo = O.hybrid_forward({k: v.clone() for k, v in state.items()}, feats, feat_lens.copy(), caps, cap_lens,
+                              ss_ratio=0.5, dis_ratio=0, method="sample", temp=0.9, record=rec)
+    model.train()
+    model.encoder.dropout_masks = rec["dropout"]
+    torch.manual_seed(22); random.seed(22)
+    for m_ in rec["dropout"]:                       # the oracle drew its dropout masks first: keep the generator aligned
+        torch.empty(m_.shape, dtype=torch.bool).bernoulli_(0.5)
+    with torch.no_grad():
+        out = model(feats.cuda(), feat_lens.copy(), caps, cap_lens, ss_ratio=0.5, dis_ratio=0, method="sample", temp=0.9)
+    assert np.array_equal(out["seqs"].cpu().numpy(), oo["seqs"].numpy())
+    close(out["sampled_logprobs"], oo["sampled_logprobs"], 1e-4, 2e-5, what="sampled_logprobs")
+
+
 def test_scheduled_sampling_forward_vs_oracle():
     # ss_ratio < 1: the word fed at step t may be the previous argmax (device-side select, no host sync)
     V, E, B, Tt, L = 40, 64, 3, 96, 6
@@ -411,6 +468,50 @@ def test_g6_trainstep_against_the_reference_adam_step():
             close(got, ref, 1e-5, 1e-7, what=name)
         checked += 1
     assert checked == 5
+
+
+def test_two_host_threads_two_streams_share_nothing():
+    """Re-entrancy of the two-stream calls (include/acvae_hip.h, "Mutable state"): two host threads, each with its own
+    model, its own pair of HIP streams and its own batch, run teacher-forced training forwards (acvae_decode_fwd forks
+    the prior chain onto the side stream and joins it with events from the per-thread pool) at the same time; each
+    must reproduce, bit for bit, what it computes alone."""
+    import threading
+    V, E = 40, 64
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    jobs = []
+    for i in range(2):
+        feats, caps, fl, cl = O.synthetic_batch(3, 64, V, 7, seed=30 + i, ragged=True)
+        m = build_model(V, E, state).train()
+        m.encoder.p_block = m.encoder.p_fc = 0.0
+        g = torch.Generator().manual_seed(40 + i)
+        noise = dict(eps_q=torch.randn(3, 6, E, generator=g), eps_p=torch.randn(6, 3, E, generator=g))
+        jobs.append((m, feats.cuda(), caps, fl, cl, noise, torch.cuda.Stream()))
+
+    def run(job, out, idx, reps):
+        m, feats, caps, fl, cl, noise, stream = job
+        res = []
+        with torch.cuda.stream(stream), torch.no_grad():
+            for _ in range(reps):
+                m.noise = dict(noise)
+                random.seed(1)
+                o = m(feats, fl.copy(), caps, cl, ss_ratio=1.0, dis_ratio=0)
+                res.append((o["logits"].clone(), o["p_z"].clone(), o["seqs"].clone()))
+        stream.synchronize()
+        out[idx] = res
+
+    alone = [None, None]
+    for i in range(2):
+        run(jobs[i], alone, i, 1)
+    both = [None, None]
+    ths = [threading.Thread(target=run, args=(jobs[i], both, i, 20)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(2):
+        for rep in both[i]:
+            for a, b in zip(rep, alone[i][0]):
+                assert torch.equal(a, b), f"thread {i}: result differs from its single-threaded run"
 
 
 def test_checkpoint_round_trip_and_torch_adam_compat():

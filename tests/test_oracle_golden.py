@@ -175,6 +175,24 @@ def test_g7_decode_token_exact():
         assert np.array_equal(o["seqs"].numpy(), g[tag + "_seqs"])
 
 
+def test_g14_sampling_token_exact():
+    """A6: the oracle's sample_next_word (gumbel / multinomial) replaying the noise the reference run drew."""
+    g = load_golden("g14_sampling")
+    _, _, V, E = (int(x) for x in g["dims"])
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    for tag, method in zip(g["cases"], g["methods"]):
+        a, b = (int(x) for x in g[tag + "_clips"])
+        lens = g["feat_lens"][a:b].copy()
+        f = T(g["feats"])[a:b, :int(lens.max())]
+        with torch.no_grad():
+            o = O.hybrid_forward({k: v.clone() for k, v in state.items()}, f, lens, training=False, method=str(method),
+                                 temp=float(g[tag + "_temp"]),
+                                 noise=dict(eps_p=T(g[tag + "_noise_eps_p"]), sample_noise=T(g[tag + "_sample_noise"])))
+        assert np.array_equal(o["seqs"].numpy(), g[tag + "_seqs"]), tag
+        steps = int(g[tag + "_steps_run"])
+        close(o["sampled_logprobs"][:, :steps], g[tag + "_logprobs"], 1e-5, 1e-6)
+
+
 def test_g9_beam_search_token_exact():
     g = load_golden("g9_beam")
     _, _, V, E, beam = (int(x) for x in g["dims"])
