@@ -56,6 +56,7 @@ PROTOS, ENUMS = parse_header()
 _defs = dict(re.findall(r"#define\s+(ACVAE_\w+)\s+(\d+)", open(HEADER).read()))
 ENUMS_TEXT_N = int(_defs["ACVAE_TEXT_NPARAMS"])
 ENC_NPARAMS = int(_defs["ACVAE_ENC_NPARAMS"])
+ENC_BF16 = int(_defs["ACVAE_ENC_BF16"])
 _lib = None
 
 

@@ -30,6 +30,32 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- bf16 storage (configs[2]: bf16 forward / fp32 loss).  Tensors are stored as bf16 and every kernel computes in fp32:
+// load4 / store4 move 4 consecutive elements of either storage type (16 B of float, 8 B of bf16; round-to-nearest-even
+// on the way out: hipcc emits v_cvt_pk_bf16_f32 for the cast).
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {     // a -> low half, b -> high half
+  union { bf16_t h[2]; unsigned u; } x;
+  x.h[0] = (bf16_t)a; x.h[1] = (bf16_t)b;
+  return x.u;
+}
+__device__ __forceinline__ float round_bf16(float a) { return (float)(bf16_t)a; }
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+}
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+__device__ __forceinline__ float load1(const bf16_t* p) { return (float)*p; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 struct DropoutSpec {
   float p;              // drop probability; 0 disables
@@ -18,10 +19,36 @@ namespace acvae {
 int conv3x3_igemm(const float* X, const float* scale, const float* shift, const float* Wp, float* Y, float* partials,
                   int N, int H, int W, int Cin, int Cout, hipStream_t st);
 int conv_partials_rows(int N, int H, int W);
+// bf16 storage (conv_bf16.hip): same contracts, X / Wp / Y in bf16, fp32 accumulation, statistics of the rounded output
+int conv3x3_igemm_bf16(const bf16_t* X, const float* scale, const float* shift, const bf16_t* Wp, bf16_t* Y,
+                       float* partials, int N, int H, int W, int Cin, int Cout, hipStream_t st);
+long conv3x3_wgrad_bf16_slab_floats(int N, int H, int W, int Cin, int Cout);
+int conv3x3_wgrad_bf16_splits(int N, int H, int W, int Cin, int Cout);
+int conv3x3_wgrad_bf16_launch(const bf16_t* dY, const bf16_t* X, const float* scale, const float* shift, float* slab, int N,
+                              int H, int W, int Cin, int Cout, hipStream_t st);
+// dW_oihw[co][ci][tap] = sum_z slab[z][co][tap*Cin + ci]  (fixed order)
+int wgrad_reduce(const float* slab, int nsplit, float* dW_oihw, int Cout, int Cin, hipStream_t st);
 long conv3x3_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout);
 int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
                   int N, int H, int W, int Cin, int Cout, hipStream_t st);
-int repack_weights(const float* W_oihw, float* Wf, float* Wd, int Cout, int Cin, hipStream_t st);
+// T = float or bf16_t (storage type of activations / repacked weights; arithmetic is fp32 either way)
+template <class T>
+int repack_weights(const float* W_oihw, T* Wf, T* Wd, int Cout, int Cin, hipStream_t st);
+// storage-type overloads so that the encoder driver is one template
+inline int conv3x3_igemm(const bf16_t* X, const float* scale, const float* shift, const bf16_t* Wp, bf16_t* Y,
+                         float* partials, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  return conv3x3_igemm_bf16(X, scale, shift, Wp, Y, partials, N, H, W, Cin, Cout, st);
+}
+inline int conv3x3_wgrad(const bf16_t* dY, const bf16_t* X, const float* scale, const float* shift, float* dW_oihw,
+                         float* slab, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  int r = conv3x3_wgrad_bf16_launch(dY, X, scale, shift, slab, N, H, W, Cin, Cout, st);
+  if (r != 0) return r;
+  return wgrad_reduce(slab, conv3x3_wgrad_bf16_splits(N, H, W, Cin, Cout), dW_oihw, Cout, Cin, st);
+}
+template <class T>
+inline long conv3x3_wgrad_slab_floats_t(int N, int H, int W, int Cin, int Cout) {
+  return sizeof(T) == 2 ? conv3x3_wgrad_bf16_slab_floats(N, H, W, Cin, Cout) : conv3x3_wgrad_slab_floats(N, H, W, Cin, Cout);
+}
 int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hipStream_t st);
 int bn0_partials_rows(long rows);
 int bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
@@ -31,20 +58,26 @@ long colsum_scratch_doubles(int width);
 // deterministic column sums of x[P][width] (ld == width): out[i] = sum_p x[p][i]; entries >= split (if > 0) go to out2
 int colsum2(const float* x, int P, int width, double* dpart, float* out, float* out2, int split, hipStream_t st);
 int conv1_first_blocks(int N, int T);
-int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, float* Y,
+template <class TY>
+int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, TY* Y,
                     float* partials, int N, int T, int F, hipStream_t st);
+template <class TY>
 int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
-                    const float* W1, const float* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
+                    const float* W1, const TY* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
                     float* dbeta0, double* dpart, int N, int T, int F, hipStream_t st);
 // pool: 2x2 average pool after BN+ReLU (ConvBlock pool_size (2,2)); !pool: pool_size (1,1) (Cnn14's last block)
-int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* P, int N, int H, int W, int C,
+template <class T>
+int bn_relu_pool(const T* Y, const float* scale, const float* shift, T* P, int N, int H, int W, int C,
                  DropoutSpec drop, hipStream_t st, bool pool = true);
 int bn_bwd_blocks(int N, int H, int W);
-int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, const float* shift, const float* mean,
-           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
+template <class T>
+int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const float* shift, const float* mean,
+           const float* invstd, float* partials, float* sum_g, float* sum_gy, T* dY, double* dpart, int N, int H,
            int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats = true);
-int freq_mean(const float* P, float* out, long rows, int Fp, int C, hipStream_t st);
-int freq_mean_bwd(const float* dae, float* dP, long rows, int Fp, int C, hipStream_t st);
+template <class T>
+int freq_mean(const T* P, float* out, long rows, int Fp, int C, hipStream_t st);
+template <class T>
+int freq_mean_bwd(const float* dae, T* dP, long rows, int Fp, int C, hipStream_t st);
 int time_pool(const float* ae, float* out, int N, int S, int C, DropoutSpec drop, hipStream_t st);
 int relu_dropout(float* x, int total, DropoutSpec drop, hipStream_t st);
 }  // namespace acvae

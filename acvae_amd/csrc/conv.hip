@@ -681,20 +681,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, 
 
 // ------------------------------------------------------------------ weight repacks
 // fwd:  Wf[co][tap*Cin + ci] = W[co][ci][tap];   dgrad: Wd[ci][tap'*Cout + co] = W[co][ci][8 - tap']
-__global__ void repack_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wf, int Cout, int Cin) {
+template <class T>
+__global__ void repack_fwd_kernel(const float* __restrict__ W, T* __restrict__ Wf, int Cout, int Cin) {
   const long total = (long)Cout * Cin * 9;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int co = (int)(i / (9 * Cin)), rem = (int)(i % (9 * Cin));
     const int tap = rem / Cin, ci = rem % Cin;
-    Wf[i] = W[((long)co * Cin + ci) * 9 + tap];
+    Wf[i] = (T)W[((long)co * Cin + ci) * 9 + tap];
   }
 }
-__global__ void repack_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Cin) {
+template <class T>
+__global__ void repack_dgrad_kernel(const float* __restrict__ W, T* __restrict__ Wd, int Cout, int Cin) {
   const long total = (long)Cout * Cin * 9;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i / (9 * Cout)), rem = (int)(i % (9 * Cout));
     const int tp = rem / Cout, co = rem % Cout;
-    Wd[i] = W[((long)co * Cin + ci) * 9 + (8 - tp)];
+    Wd[i] = (T)W[((long)co * Cin + ci) * 9 + (8 - tp)];
   }
 }
 
@@ -788,10 +790,11 @@ __global__ __launch_bounds__(64) void colsum_stage2_kernel(const double* __restr
 // Y[n,t,w,co] = sum_tap W1[co][tap] * xin(t+dy, w+dx),  xin = x*scale0[w] + shift0[w] inside the image.
 // Block = RB time rows of one clip; 256 threads = 16 pixels x 16 cout-quads per pass.
 constexpr int C1_RB = 8;
+template <class TY>
 __global__ __launch_bounds__(256) void conv1_first_fwd_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ scale0,
                                                               const float* __restrict__ shift0,
-                                                              const float* __restrict__ W1, float* __restrict__ Y,
+                                                              const float* __restrict__ W1, TY* __restrict__ Y,
                                                               float* __restrict__ partials, int T, int F) {
   __shared__ float wl[64 * 9];
   __shared__ float patch[(C1_RB + 2) * 66];
@@ -827,9 +830,11 @@ __global__ __launch_bounds__(256) void conv1_first_fwd_kernel(const float* __res
       float a = 0.f;
 #pragma unroll
       for (int k = 0; k < 9; ++k) a += wreg[c][k] * in[k];
+      // bf16 storage: the statistics describe the tensor as stored (rounded), so that BatchNorm is exact on it
+      if (!std::is_same<TY, float>::value) a = round_bf16(a);
       o[c] = a; s[c] += a; q[c] += a * a;
     }
-    *reinterpret_cast<float4*>(Y + (((long)n * T + t) * F + w) * 64 + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    store4(Y + (((long)n * T + t) * F + w) * 64 + cq * 4, make_float4(o[0], o[1], o[2], o[3]));
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) { red[0][pp][cq * 4 + c] = s[c]; red[1][pp][cq * 4 + c] = q[c]; }
@@ -845,13 +850,14 @@ __global__ __launch_bounds__(256) void conv1_first_fwd_kernel(const float* __res
 // Backward of the first conv: dW1 partials [blocks][64*9] and bn0 grad partials [blocks][2][64]
 // (sum over pixels of dxin and dxin*xhat per mel bin), dxin[q] = sum_tap D[q - tap][tap],
 // D[p][tap] = sum_co dY[p][co] * W1[co][tap].
+template <class TY>
 __global__ __launch_bounds__(256) void conv1_first_bwd_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ scale0,
                                                               const float* __restrict__ shift0,
                                                               const float* __restrict__ mean0,
                                                               const float* __restrict__ invstd0,
                                                               const float* __restrict__ W1,
-                                                              const float* __restrict__ dY,
+                                                              const TY* __restrict__ dY,
                                                               float* __restrict__ dw_part, float* __restrict__ bn_part,
                                                               int T, int F) {
   __shared__ float wl[64 * 9];
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(256) void conv1_first_bwd_kernel(const float* __res
     const int t = t0 + r - 1;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool inimg = (t >= 0 && t < T && w < F);
-    if (inimg) g = *reinterpret_cast<const float4*>(dY + (((long)n * T + t) * F + w) * 64 + cq * 4);
+    if (inimg) g = load4(dY + (((long)n * T + t) * F + w) * 64 + cq * 4);
     const float gv[4] = {g.x, g.y, g.z, g.w};
     float d[9];
 #pragma unroll
@@ -992,8 +998,9 @@ __device__ __forceinline__ float4 drop4(const DropoutSpec& d, long idx4, int n, 
                      (float)(r.z >> 8) * u >= d.p ? k : 0.f, (float)(r.w >> 8) * u >= d.p ? k : 0.f);
 }
 
-__global__ void bn_relu_pool_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, float* __restrict__ P, int N, int H, int W, int C,
+template <class T>
+__global__ void bn_relu_pool_kernel(const T* __restrict__ Y, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, T* __restrict__ P, int N, int H, int W, int C,
                                     DropoutSpec drop) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const long total = (long)N * Ho * Wo * C4;
@@ -1005,23 +1012,24 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ Y, const float* __
     const int n = (int)(r / Ho);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
     const float4 sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
-    const float* y = Y + ((((long)n * H + 2 * ho) * W + 2 * wo) * C + c4 * 4);
-    const float4 a = bnrelu4(*reinterpret_cast<const float4*>(y), sc, sh);
-    const float4 b = bnrelu4(*reinterpret_cast<const float4*>(y + C), sc, sh);
-    const float4 c = bnrelu4(*reinterpret_cast<const float4*>(y + (long)W * C), sc, sh);
-    const float4 d = bnrelu4(*reinterpret_cast<const float4*>(y + (long)W * C + C), sc, sh);
+    const T* y = Y + ((((long)n * H + 2 * ho) * W + 2 * wo) * C + c4 * 4);
+    const float4 a = bnrelu4(load4(y), sc, sh);
+    const float4 b = bnrelu4(load4(y + C), sc, sh);
+    const float4 c = bnrelu4(load4(y + (long)W * C), sc, sh);
+    const float4 d = bnrelu4(load4(y + (long)W * C + C), sc, sh);
     const float4 m = drop4(drop, i, n, ho, wo, c4 * 4, Ho, Wo, C);
     // F.avg_pool2d then F.dropout: (sum * 0.25) * mask * 1/(1-p)
     float4 o;
     o.x = ((a.x + b.x + c.x + d.x) * 0.25f) * m.x; o.y = ((a.y + b.y + c.y + d.y) * 0.25f) * m.y;
     o.z = ((a.z + b.z + c.z + d.z) * 0.25f) * m.z; o.w = ((a.w + b.w + c.w + d.w) * 0.25f) * m.w;
-    reinterpret_cast<float4*>(P)[i] = o;
+    store4(P + 4 * i, o);
   }
 }
 
 // pool_size (1,1): BN + ReLU + dropout at full resolution
-__global__ void bn_relu_drop_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, float* __restrict__ P, int N, int H, int W, int C,
+template <class T>
+__global__ void bn_relu_drop_kernel(const T* __restrict__ Y, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, T* __restrict__ P, int N, int H, int W, int C,
                                     DropoutSpec drop) {
   const int C4 = C / 4;
   const long total = (long)N * H * W * C4;
@@ -1033,21 +1041,21 @@ __global__ void bn_relu_drop_kernel(const float* __restrict__ Y, const float* __
     const int n = (int)(r / H);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4);
     const float4 sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
-    const float4 a = bnrelu4(reinterpret_cast<const float4*>(Y)[i], sc, sh);
+    const float4 a = bnrelu4(load4(Y + 4 * i), sc, sh);
     const float4 m = drop4(drop, i, n, h, w, c4 * 4, H, W, C);
-    reinterpret_cast<float4*>(P)[i] = make_float4(a.x * m.x, a.y * m.y, a.z * m.z, a.w * m.w);
+    store4(P + 4 * i, make_float4(a.x * m.x, a.y * m.y, a.z * m.z, a.w * m.w));
   }
 }
 
 // ------------------------------------------------------------------ BN backward
 // g = relu'(bn(Y)) * upstream;  UP_POOL: upstream = dP[n,h/2,w/2,c] * dropmask * 0.25 (0 for a trailing odd row/col)
-template <int UP>
-__device__ __forceinline__ float4 upstream4(const float* __restrict__ dO, const DropoutSpec& drop, int n, int h, int w,
+template <int UP, class T>
+__device__ __forceinline__ float4 upstream4(const T* __restrict__ dO, const DropoutSpec& drop, int n, int h, int w,
                                             int c, int H, int W, int C) {
-  if (UP == UP_PLAIN) return *reinterpret_cast<const float4*>(dO + ((((long)n * H + h) * W + w) * C + c));
+  if (UP == UP_PLAIN) return load4(dO + ((((long)n * H + h) * W + w) * C + c));
   if (UP == UP_DROP) {
     const long i4 = ((((long)n * H + h) * W + w) * C + c) >> 2;
-    float4 v = reinterpret_cast<const float4*>(dO)[i4];
+    float4 v = load4(dO + 4 * i4);
     const float4 m = drop4(drop, i4, n, h, w, c, H, W, C);
     v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
     return v;
@@ -1056,7 +1064,7 @@ __device__ __forceinline__ float4 upstream4(const float* __restrict__ dO, const 
   const int ho = h >> 1, wo = w >> 1;
   if (ho >= Ho || wo >= Wo) return make_float4(0.f, 0.f, 0.f, 0.f);
   const long i4 = ((((long)n * Ho + ho) * Wo + wo) * C + c) >> 2;
-  float4 v = reinterpret_cast<const float4*>(dO)[i4];
+  float4 v = load4(dO + 4 * i4);
   const float4 m = drop4(drop, i4, n, ho, wo, c, Ho, Wo, C);
   v.x *= m.x * 0.25f; v.y *= m.y * 0.25f; v.z *= m.z * 0.25f; v.w *= m.w * 0.25f;
   return v;
@@ -1064,8 +1072,8 @@ __device__ __forceinline__ float4 upstream4(const float* __restrict__ dO, const 
 
 // partials [blocks][2][C]: sum g | sum g*yhat.  Block = 256 threads = (Cc/4) channel-quads x (1024/Cc) pixels of the
 // channel chunk blockIdx.y (Cc = min(C, 1024) channels per chunk).
-template <int UP>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ Y, const float* __restrict__ dO,
+template <int UP, class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ Y, const T* __restrict__ dO,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
@@ -1087,7 +1095,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       const int w = (int)(p % W);
       const long t = p / W;
       const int h = (int)(t % H), n = (int)(t / H);
-      const float4 y = *reinterpret_cast<const float4*>(Y + p * C + c);
+      const float4 y = load4(Y + p * C + c);
       float4 g = upstream4<UP>(dO, drop, n, h, w, c, H, W, C);
       if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
       if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
@@ -1113,12 +1121,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // dY = scale * (g - sum_g/n - yhat * sum_gy/n)      (scale = gamma * invstd)
-template <int UP>
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ Y, const float* __restrict__ dO,
+template <int UP, class T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ Y, const T* __restrict__ dO,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ sum_g, const float* __restrict__ sum_gy,
-                                    float* __restrict__ dYout, int N, int H, int W, int C, DropoutSpec drop,
+                                    T* __restrict__ dYout, int N, int H, int W, int C, DropoutSpec drop,
                                     int batch_stats) {
   const int C4 = C / 4;
   const long total = (long)N * H * W * C4;
@@ -1133,7 +1141,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ Y, const float* __
     const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
     const float4 sg = *reinterpret_cast<const float4*>(sum_g + c), sgy = *reinterpret_cast<const float4*>(sum_gy + c);
-    const float4 y = reinterpret_cast<const float4*>(Y)[i];
+    const float4 y = load4(Y + 4 * i);
     float4 g = upstream4<UP>(dO, drop, n, h, w, c, H, W, C);
     if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
     if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
@@ -1144,30 +1152,32 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ Y, const float* __
     o.y = sc.y * (g.y - sg.y * invn - ((y.y - mu.y) * is.y) * (sgy.y * invn));
     o.z = sc.z * (g.z - sg.z * invn - ((y.z - mu.z) * is.z) * (sgy.z * invn));
     o.w = sc.w * (g.w - sg.w * invn - ((y.w - mu.w) * is.w) * (sgy.w * invn));
-    reinterpret_cast<float4*>(dYout)[i] = o;
+    store4(dYout + 4 * i, o);
   }
 }
 
 // ------------------------------------------------------------------ encoder tail
 // audio_embeds[n,s,c] = mean_f P4[n,s,f,c]  (torch.mean(x, dim=3), encoder.py:691)
-__global__ void freq_mean_kernel(const float* __restrict__ P, float* __restrict__ out, long rows, int Fp, int C) {
+template <class T>
+__global__ void freq_mean_kernel(const T* __restrict__ P, float* __restrict__ out, long rows, int Fp, int C) {
   const long total = rows * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / C;
     const int c = (int)(i % C);
     float a = 0.f;
-    for (int f = 0; f < Fp; ++f) a += P[(r * Fp + f) * C + c];
+    for (int f = 0; f < Fp; ++f) a += load1(P + (r * Fp + f) * C + c);
     out[i] = a / (float)Fp;
   }
 }
 // dP4[n,s,f,c] = d_ae[n,s,c] / Fp
-__global__ void freq_mean_bwd_kernel(const float* __restrict__ dae, float* __restrict__ dP, long rows, int Fp, int C) {
+template <class T>
+__global__ void freq_mean_bwd_kernel(const float* __restrict__ dae, T* __restrict__ dP, long rows, int Fp, int C) {
   const long total = rows * Fp * C;
   const float k = 1.0f / (float)Fp;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const long r = i / ((long)Fp * C);
-    dP[i] = dae[r * C + c] * k;
+    dP[i] = (T)(dae[r * C + c] * k);
   }
 }
 // pooled_in[n,c] = dropout(max_s ae + mean_s ae)   (encoder.py:693-696, unmasked over s)
@@ -1345,13 +1355,23 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
   return ACVAE_OK;
 }
 
-int repack_weights(const float* W_oihw, float* Wf, float* Wd, int Cout, int Cin, hipStream_t st) {
-  const long total = (long)Cout * Cin * 9;
-  if (Wf) hipLaunchKernelGGL(repack_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W_oihw, Wf, Cout, Cin);
-  if (Wd) hipLaunchKernelGGL(repack_dgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W_oihw, Wd, Cout, Cin);
+int wgrad_reduce(const float* slab, int nsplit, float* dW_oihw, int Cout, int Cin, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((long)Cout * 9 * Cin)), dim3(256), 0, st, slab, nsplit, dW_oihw, Cout,
+                     Cin);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
+
+template <class T>
+int repack_weights(const float* W_oihw, T* Wf, T* Wd, int Cout, int Cin, hipStream_t st) {
+  const long total = (long)Cout * Cin * 9;
+  if (Wf) hipLaunchKernelGGL(repack_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, st, W_oihw, Wf, Cout, Cin);
+  if (Wd) hipLaunchKernelGGL(repack_dgrad_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, st, W_oihw, Wd, Cout, Cin);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+template int repack_weights<float>(const float*, float*, float*, int, int, hipStream_t);
+template int repack_weights<bf16_t>(const float*, bf16_t*, bf16_t*, int, int, hipStream_t);
 
 int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hipStream_t st) {
   if (F > 64) return ACVAE_EUNSUPPORTED;
@@ -1389,43 +1409,53 @@ int bn_finalize(const float* partials, int P, int C, double count, const float* 
 }
 
 int conv1_first_blocks(int N, int T) { return N * cdiv(T, C1_RB); }
-int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, float* Y,
+template <class TY>
+int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, TY* Y,
                     float* partials, int N, int T, int F, hipStream_t st) {
   if (F != 64) return ACVAE_EUNSUPPORTED;
-  hipLaunchKernelGGL(conv1_first_fwd_kernel, dim3(conv1_first_blocks(N, T)), dim3(256), 0, st, x, scale0, shift0, W1, Y,
-                     partials, T, F);
+  hipLaunchKernelGGL(conv1_first_fwd_kernel<TY>, dim3(conv1_first_blocks(N, T)), dim3(256), 0, st, x, scale0, shift0, W1,
+                     Y, partials, T, F);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
+template int conv1_first_fwd<float>(const float*, const float*, const float*, const float*, float*, float*, int, int, int, hipStream_t);
+template int conv1_first_fwd<bf16_t>(const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, hipStream_t);
+template <class TY>
 int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
-                    const float* W1, const float* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
+                    const float* W1, const TY* dY, float* dw_part, float* bn_part, float* dW1, float* dgamma0,
                     float* dbeta0, double* dpart, int N, int T, int F, hipStream_t st) {
   if (F != 64) return ACVAE_EUNSUPPORTED;
   const int nb = conv1_first_blocks(N, T);
-  hipLaunchKernelGGL(conv1_first_bwd_kernel, dim3(nb), dim3(256), 0, st, x, scale0, shift0, mean0, invstd0, W1, dY,
+  hipLaunchKernelGGL(conv1_first_bwd_kernel<TY>, dim3(nb), dim3(256), 0, st, x, scale0, shift0, mean0, invstd0, W1, dY,
                      dw_part, bn_part, T, F);
   ACVAE_TRY(colsum2(dw_part, nb, 576, dpart, dW1, nullptr, 0, st));
   // bn0: y = xhat*gamma + beta with xin = scale0*x + shift0  ->  dbeta = sum dxin, dgamma = sum dxin*xhat
   ACVAE_TRY(colsum2(bn_part, nb, 128, dpart, dbeta0, dgamma0, 64, st));
   return ACVAE_OK;
 }
+template int conv1_first_bwd<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*, double*, int, int, int, hipStream_t);
+template int conv1_first_bwd<bf16_t>(const float*, const float*, const float*, const float*, const float*, const float*, const bf16_t*, float*, float*, float*, float*, float*, double*, int, int, int, hipStream_t);
 
-int bn_relu_pool(const float* Y, const float* scale, const float* shift, float* P, int N, int H, int W, int C,
+template <class T>
+int bn_relu_pool(const T* Y, const float* scale, const float* shift, T* P, int N, int H, int W, int C,
                  DropoutSpec drop, hipStream_t st, bool pool) {
   const long total = pool ? (long)N * (H / 2) * (W / 2) * (C / 4) : (long)N * H * W * (C / 4);
   if (total <= 0 || C % 4 != 0) return ACVAE_EINVAL;
   if (pool)
-    hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
+    hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
   else
-    hipLaunchKernelGGL(bn_relu_drop_kernel, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
+    hipLaunchKernelGGL(bn_relu_drop_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, st, Y, scale, shift, P, N, H, W, C, drop);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
+template int bn_relu_pool<float>(const float*, const float*, const float*, float*, int, int, int, int, DropoutSpec, hipStream_t, bool);
+template int bn_relu_pool<bf16_t>(const bf16_t*, const float*, const float*, bf16_t*, int, int, int, int, DropoutSpec, hipStream_t, bool);
 
 constexpr int BNB_PIX = 512;
 int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, BNB_PIX); }
-int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, const float* shift, const float* mean,
-           const float* invstd, float* partials, float* sum_g, float* sum_gy, float* dY, double* dpart, int N, int H,
+template <class T>
+int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const float* shift, const float* mean,
+           const float* invstd, float* partials, float* sum_g, float* sum_gy, T* dY, double* dpart, int N, int H,
            int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats) {
   const int Cc = C < 1024 ? C : 1024;
   if (C % 4 != 0 || 1024 % Cc != 0 || C % Cc != 0) return ACVAE_EUNSUPPORTED;
@@ -1434,10 +1464,10 @@ int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, co
   const size_t shm = 256 * 8 * sizeof(float);
   const long total = (long)N * H * W * (C / 4);
 #define BN_BWD_LAUNCH(UP_)                                                                                             \
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<UP_>, rgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials, \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<UP_, T>), rgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials, \
                      N, H, W, C, BNB_PIX, drop);                                                                       \
   ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st)); /* sum_g (= dbeta) | sum_gy (= dgamma) */        \
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<UP_>, dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,       \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<UP_, T>), dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,  \
                      invstd, sum_g, sum_gy, dY, N, H, W, C, drop, batch_stats ? 1 : 0)
   if (upstream == UP_POOL) { BN_BWD_LAUNCH(UP_POOL); }
   else if (upstream == UP_DROP) { BN_BWD_LAUNCH(UP_DROP); }
@@ -1446,17 +1476,25 @@ int bn_bwd(const float* Y, const float* dO, int upstream, const float* scale, co
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
+template int bn_bwd<float>(const float*, const float*, int, const float*, const float*, const float*, const float*, float*, float*, float*, float*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool);
+template int bn_bwd<bf16_t>(const bf16_t*, const bf16_t*, int, const float*, const float*, const float*, const float*, float*, float*, float*, bf16_t*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool);
 
-int freq_mean(const float* P, float* out, long rows, int Fp, int C, hipStream_t st) {
-  hipLaunchKernelGGL(freq_mean_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, st, P, out, rows, Fp, C);
+template <class T>
+int freq_mean(const T* P, float* out, long rows, int Fp, int C, hipStream_t st) {
+  hipLaunchKernelGGL(freq_mean_kernel<T>, dim3(ew_grid(rows * C)), dim3(256), 0, st, P, out, rows, Fp, C);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
-int freq_mean_bwd(const float* dae, float* dP, long rows, int Fp, int C, hipStream_t st) {
-  hipLaunchKernelGGL(freq_mean_bwd_kernel, dim3(ew_grid(rows * Fp * C)), dim3(256), 0, st, dae, dP, rows, Fp, C);
+template <class T>
+int freq_mean_bwd(const float* dae, T* dP, long rows, int Fp, int C, hipStream_t st) {
+  hipLaunchKernelGGL(freq_mean_bwd_kernel<T>, dim3(ew_grid(rows * Fp * C)), dim3(256), 0, st, dae, dP, rows, Fp, C);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
+template int freq_mean<float>(const float*, float*, long, int, int, hipStream_t);
+template int freq_mean<bf16_t>(const bf16_t*, float*, long, int, int, hipStream_t);
+template int freq_mean_bwd<float>(const float*, float*, long, int, int, hipStream_t);
+template int freq_mean_bwd<bf16_t>(const float*, bf16_t*, long, int, int, hipStream_t);
 int time_pool(const float* ae, float* out, int N, int S, int C, DropoutSpec drop, hipStream_t st) {
   hipLaunchKernelGGL(time_pool_kernel, dim3(ew_grid((long)N * C)), dim3(256), 0, st, ae, out, N, S, C, drop);
   ACVAE_LAUNCH_CHECK();

@@ -11,13 +11,16 @@ namespace {
 // arch 0: Cnn10 (models/encoder.py:651-707): 4 blocks, every block 2x2-pooled, 512-wide output, time / 16.
 // arch 1: Cnn14_16k (models/encoder.py:871-964): 6 blocks up to 2048 channels, block 6 pooled (1,1), time / 32.
 constexpr int kMaxBlocks = 6;
+constexpr int kArchMask = 0xff;          // low byte: encoder family; ACVAE_ENC_BF16 (0x100): bf16 activation storage
 constexpr int kChan[kMaxBlocks + 1] = {1, 64, 128, 256, 512, 1024, 2048};
 struct Arch { int blocks; bool pool_last; };
 inline bool arch_of(int arch, Arch& a) {
-  if (arch == ACVAE_ARCH_CNN10) { a = {4, true}; return true; }
-  if (arch == ACVAE_ARCH_CNN14_16K) { a = {6, false}; return true; }
+  if (arch & ~(kArchMask | ACVAE_ENC_BF16)) return false;
+  if ((arch & kArchMask) == ACVAE_ARCH_CNN10) { a = {4, true}; return true; }
+  if ((arch & kArchMask) == ACVAE_ARCH_CNN14_16K) { a = {6, false}; return true; }
   return false;
 }
+inline bool is_bf16(int arch) { return (arch & ACVAE_ENC_BF16) != 0; }
 
 struct EncLayout {
   int N, T, F;
@@ -35,9 +38,12 @@ struct EncLayout {
 
 long align4(long x) { return (x + 63) & ~63L; }
 
+// offsets are in 4-byte units; `esz` = bytes per activation / repacked-weight element (4: fp32, 2: bf16)
 int make_layout(int arch, int N, int T, int F, EncLayout& L) {
   Arch A;
   if (!arch_of(arch, A)) return ACVAE_EINVAL;
+  const long esz = is_bf16(arch) ? 2 : 4;
+  auto units = [esz](long n) { return (n * esz + 3) / 4; };
   const int div = 1 << (A.pool_last ? A.blocks : A.blocks - 1);
   if (N <= 0 || F != 64 || T < div) return ACVAE_EINVAL;
   L.N = N; L.T = T; L.F = F; L.nb = A.blocks; L.Cemb = kChan[A.blocks];
@@ -49,19 +55,21 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
     L.pool[b] = b < L.nb || A.pool_last;
     const long act = (long)N * h * w * kChan[b];
     const long pool = L.pool[b] ? (long)N * (h / 2) * (w / 2) * kChan[b] : act;
-    L.y1[b] = off; off = align4(off + act);
-    L.y2[b] = off; off = align4(off + act);
-    L.p[b] = off; off = align4(off + pool);
-    L.wf1[b] = off; off = align4(off + (long)kChan[b] * 9 * kChan[b - 1]);
-    L.wf2[b] = off; off = align4(off + (long)kChan[b] * 9 * kChan[b]);
+    L.y1[b] = off; off = align4(off + units(act));
+    L.y2[b] = off; off = align4(off + units(act));
+    L.p[b] = off; off = align4(off + units(pool));
+    L.wf1[b] = off; off = align4(off + units((long)kChan[b] * 9 * kChan[b - 1]));
+    L.wf2[b] = off; off = align4(off + units((long)kChan[b] * 9 * kChan[b]));
     if (act > max_act) max_act = act;
     if (pool > max_pool) max_pool = pool;
     const long part = (long)acvae::conv_partials_rows(N, h, w) * 2 * kChan[b];
     if (part > max_part) max_part = part;
-    long sl = acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b], kChan[b]);
+    long sl = esz == 2 ? acvae::conv3x3_wgrad_bf16_slab_floats(N, h, w, kChan[b], kChan[b])
+                       : acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b], kChan[b]);
     if (sl > max_slab) max_slab = sl;
     if (b > 1) {
-      sl = acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b - 1], kChan[b]);
+      sl = esz == 2 ? acvae::conv3x3_wgrad_bf16_slab_floats(N, h, w, kChan[b - 1], kChan[b])
+                    : acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b - 1], kChan[b]);
       if (sl > max_slab) max_slab = sl;
     }
     const long bp = (long)acvae::bn_bwd_blocks(N, h, w) * 2 * kChan[b];
@@ -84,14 +92,14 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
   L.s_dpart = s; s = align4(s + 2 * acvae::colsum_scratch_doubles(2 * L.Cemb > 1024 ? 2 * L.Cemb : 1024));
   L.s_partials = s; s = align4(s + max_part);
   L.s_bnpart = s; s = align4(s + max_bnpart);
-  L.s_wd = s; s = align4(s + (long)L.Cemb * 9 * L.Cemb);
+  L.s_wd = s; s = align4(s + units((long)L.Cemb * 9 * L.Cemb));
   L.s_slab = s; s = align4(s + max_slab);
   L.s_c1w = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 576);
   L.s_c1b = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 128);
-  L.s_dpa = s; s = align4(s + max_pool);
-  L.s_dpb = s; s = align4(s + max_pool);
-  L.s_dya = s; s = align4(s + max_act);
-  L.s_dyb = s; s = align4(s + max_act);
+  L.s_dpa = s; s = align4(s + units(max_pool));
+  L.s_dpb = s; s = align4(s + units(max_pool));
+  L.s_dya = s; s = align4(s + units(max_act));
+  L.s_dyb = s; s = align4(s + units(max_act));
   L.s_total = s;
   return ACVAE_OK;
 }
@@ -142,7 +150,9 @@ extern "C" int64_t acvae_encoder_scratch_bytes(int arch, int N, int T, int F) {
   return L.s_total * (int64_t)sizeof(float);
 }
 
-extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, float* audio_embeds, float* pooled,
+namespace {
+template <class TA>
+int encoder_fwd_t(const void* const* params, const float* feats, float* audio_embeds, float* pooled,
                                  void* saved_v, int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int arch,
                                  int N, int T, int F, int training, float p_block, float p_fc, uint64_t seed,
                                  const uint8_t* const* masks, void* stream) {
@@ -165,12 +175,12 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
   if (training) ACVAE_TRY(acvae::bn0_stats(feats, partials, (long)N * T, F, &nparts, st));
   ACVAE_TRY(acvae::bn_finalize(partials, nparts, 64, (double)N * T, P(p_bn0(0)), P(p_bn0(1)), P(p_bn0(2)), P(p_bn0(3)),
                                (int64_t*)params[p_bn0(4)], training, b0.scale, b0.shift, b0.mean, b0.invstd, dpart, st));
-  const float* x_in = nullptr;
+  const TA* x_in = nullptr;
   for (int b = 1; b <= L.nb; ++b) {
     const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
     const double cnt = (double)N * H * W;
-    float* Y1 = saved + L.y1[b];
-    float* Y2 = saved + L.y2[b];
+    TA* Y1 = (TA*)(saved + L.y1[b]);
+    TA* Y2 = (TA*)(saved + L.y2[b]);
     BnPtrs n1 = bn_at(saved, L, 1 + 2 * (b - 1)), n2 = bn_at(saved, L, 2 + 2 * (b - 1));
     int np1;
     if (b == 1) {
@@ -178,26 +188,26 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
                                        N, T, F, st));
       np1 = acvae::conv1_first_blocks(N, T);
     } else {
-      ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 1)), saved + L.wf1[b], nullptr, C, Cin, st));
-      ACVAE_TRY(acvae::conv3x3_igemm(x_in, nullptr, nullptr, saved + L.wf1[b], Y1, training ? partials : nullptr, N, H,
-                                     W, Cin, C, st));
+      ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 1)), (TA*)(saved + L.wf1[b]), nullptr, C, Cin, st));
+      ACVAE_TRY(acvae::conv3x3_igemm(x_in, nullptr, nullptr, (const TA*)(saved + L.wf1[b]), Y1,
+                                     training ? partials : nullptr, N, H, W, Cin, C, st));
       np1 = acvae::conv_partials_rows(N, H, W);
     }
     ACVAE_TRY(acvae::bn_finalize(partials, np1, C, cnt, P(p_bn(b, 1, 0)), P(p_bn(b, 1, 1)), P(p_bn(b, 1, 2)),
                                  P(p_bn(b, 1, 3)), (int64_t*)params[p_bn(b, 1, 4)], training, n1.scale, n1.shift,
                                  n1.mean, n1.invstd, dpart, st));
-    ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), saved + L.wf2[b], nullptr, C, C, st));
-    ACVAE_TRY(acvae::conv3x3_igemm(Y1, n1.scale, n1.shift, saved + L.wf2[b], Y2, training ? partials : nullptr, N, H,
-                                   W, C, C, st));
+    ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 2)), (TA*)(saved + L.wf2[b]), nullptr, C, C, st));
+    ACVAE_TRY(acvae::conv3x3_igemm((const TA*)Y1, n1.scale, n1.shift, (const TA*)(saved + L.wf2[b]), Y2,
+                                   training ? partials : nullptr, N, H, W, C, C, st));
     ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_partials_rows(N, H, W), C, cnt, P(p_bn(b, 2, 0)),
                                  P(p_bn(b, 2, 1)), P(p_bn(b, 2, 2)), P(p_bn(b, 2, 3)), (int64_t*)params[p_bn(b, 2, 4)],
                                  training, n2.scale, n2.shift, n2.mean, n2.invstd, dpart, st));
-    ACVAE_TRY(acvae::bn_relu_pool(Y2, n2.scale, n2.shift, saved + L.p[b], N, H, W, C,
-                                  dspec(p_block, masks, seed, b - 1, training), st, L.pool[b]));
-    x_in = saved + L.p[b];
+    ACVAE_TRY(acvae::bn_relu_pool<TA>(Y2, n2.scale, n2.shift, (TA*)(saved + L.p[b]), N, H, W, C,
+                                      dspec(p_block, masks, seed, b - 1, training), st, L.pool[b]));
+    x_in = (const TA*)(saved + L.p[b]);
   }
   const int S = L.H[0], Fp = L.W[0], Ce = L.Cemb;
-  ACVAE_TRY(acvae::freq_mean(saved + L.p[L.nb], audio_embeds, (long)N * S, Fp, Ce, st));
+  ACVAE_TRY(acvae::freq_mean<TA>((const TA*)(saved + L.p[L.nb]), audio_embeds, (long)N * S, Fp, Ce, st));
   // pooled branch (encoder.py:693-698 / :944-950): dropout sites nb, nb+1 after the nb block sites
   float* pin = saved + L.pooled_in;
   ACVAE_TRY(acvae::time_pool(audio_embeds, pin, N, S, Ce, dspec(p_fc, masks, seed, L.nb, training), st));
@@ -206,8 +216,22 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
   ACVAE_TRY(acvae::relu_dropout(pooled, N * Ce, dspec(p_fc, masks, seed, L.nb + 1, training), st));
   return ACVAE_OK;
 }
+}  // namespace
 
-extern "C" int acvae_encoder_bwd_hooked(const void* const* params, void* const* grads, const float* feats,
+extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, float* audio_embeds, float* pooled,
+                                 void* saved_v, int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int arch,
+                                 int N, int T, int F, int training, float p_block, float p_fc, uint64_t seed,
+                                 const uint8_t* const* masks, void* stream) {
+  if (is_bf16(arch))
+    return encoder_fwd_t<bf16_t>(params, feats, audio_embeds, pooled, saved_v, saved_bytes, scratch_v, scratch_bytes, arch,
+                                 N, T, F, training, p_block, p_fc, seed, masks, stream);
+  return encoder_fwd_t<float>(params, feats, audio_embeds, pooled, saved_v, saved_bytes, scratch_v, scratch_bytes, arch, N,
+                              T, F, training, p_block, p_fc, seed, masks, stream);
+}
+
+namespace {
+template <class TA>
+int encoder_bwd_t(const void* const* params, void* const* grads, const float* feats,
                                  const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
                                  int64_t scratch_bytes, int arch, int N, int T, int F, int training, float p_block,
                                  uint64_t seed, const uint8_t* const* masks, void* stream, void* block_done,
@@ -222,47 +246,60 @@ extern "C" int acvae_encoder_bwd_hooked(const void* const* params, void* const* 
   float* scratch = (float*)scratch_v;
   auto P = [&](int i) { return (float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
-  float* dya = scratch + L.s_dya;
-  float* dyb = scratch + L.s_dyb;
-  float* dp_cur = scratch + L.s_dpa;
-  float* dp_nxt = scratch + L.s_dpb;
-  float* wd = scratch + L.s_wd;
+  TA* dya = (TA*)(scratch + L.s_dya);
+  TA* dyb = (TA*)(scratch + L.s_dyb);
+  TA* dp_cur = (TA*)(scratch + L.s_dpa);
+  TA* dp_nxt = (TA*)(scratch + L.s_dpb);
+  TA* wd = (TA*)(scratch + L.s_wd);
   float* slab = scratch + L.s_slab;
   float* bnpart = scratch + L.s_bnpart;
   double* dpart = (double*)(scratch + L.s_dpart);
   const int S = L.H[0], Fp = L.W[0];
-  ACVAE_TRY(acvae::freq_mean_bwd(d_audio_embeds, dp_cur, (long)N * S, Fp, L.Cemb, st));
+  ACVAE_TRY(acvae::freq_mean_bwd<TA>(d_audio_embeds, dp_cur, (long)N * S, Fp, L.Cemb, st));
   for (int b = L.nb; b >= 1; --b) {
     const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
-    float* Y1 = saved + L.y1[b];
-    float* Y2 = saved + L.y2[b];
+    const TA* Y1 = (const TA*)(saved + L.y1[b]);
+    const TA* Y2 = (const TA*)(saved + L.y2[b]);
     BnPtrs n1 = bn_at(saved, L, 1 + 2 * (b - 1)), n2 = bn_at(saved, L, 2 + 2 * (b - 1));
     // conv2 / bn2 / pool / dropout
-    ACVAE_TRY(acvae::bn_bwd(Y2, dp_cur, L.pool[b] ? UP_POOL : UP_DROP, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
+    ACVAE_TRY(acvae::bn_bwd<TA>(Y2, dp_cur, L.pool[b] ? UP_POOL : UP_DROP, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
                             G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, training), st,
                             training != 0));
-    ACVAE_TRY(acvae::conv3x3_wgrad(dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
-    ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 2)), nullptr, wd, C, C, st));
-    ACVAE_TRY(acvae::conv3x3_igemm(dya, nullptr, nullptr, wd, dyb, nullptr, N, H, W, C, C, st));
+    ACVAE_TRY(acvae::conv3x3_wgrad((const TA*)dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
+    ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 2)), nullptr, wd, C, C, st));
+    ACVAE_TRY(acvae::conv3x3_igemm((const TA*)dya, nullptr, nullptr, (const TA*)wd, dyb, nullptr, N, H, W, C, C, st));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
-    ACVAE_TRY(acvae::bn_bwd(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
+    ACVAE_TRY(acvae::bn_bwd<TA>(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
                             G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st, training != 0));
     if (b > 1) {
-      ACVAE_TRY(acvae::conv3x3_wgrad(dya, saved + L.p[b - 1], nullptr, nullptr, G(p_conv(b, 1)), slab, N, H, W, Cin, C,
-                                     st));
-      ACVAE_TRY(acvae::repack_weights(P(p_conv(b, 1)), nullptr, wd, C, Cin, st));
-      ACVAE_TRY(acvae::conv3x3_igemm(dya, nullptr, nullptr, wd, dp_nxt, nullptr, N, H, W, C, Cin, st));
-      float* t = dp_cur; dp_cur = dp_nxt; dp_nxt = t;
+      ACVAE_TRY(acvae::conv3x3_wgrad((const TA*)dya, (const TA*)(saved + L.p[b - 1]), nullptr, nullptr, G(p_conv(b, 1)),
+                                     slab, N, H, W, Cin, C, st));
+      ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 1)), nullptr, wd, C, Cin, st));
+      ACVAE_TRY(acvae::conv3x3_igemm((const TA*)dya, nullptr, nullptr, (const TA*)wd, dp_nxt, nullptr, N, H, W, C, Cin, st));
+      TA* t = dp_cur; dp_cur = dp_nxt; dp_nxt = t;
     } else {
       BnPtrs b0 = bn_at(saved, L, 0);
-      ACVAE_TRY(acvae::conv1_first_bwd(feats, b0.scale, b0.shift, b0.mean, b0.invstd, P(p_conv(1, 1)), dya,
+      ACVAE_TRY(acvae::conv1_first_bwd<TA>(feats, b0.scale, b0.shift, b0.mean, b0.invstd, P(p_conv(1, 1)), (const TA*)dya,
                                        scratch + L.s_c1w, scratch + L.s_c1b, G(p_conv(1, 1)), G(p_bn0(0)), G(p_bn0(1)),
                                        dpart, N, T, F, st));
     }
     if (block_done) ((void (*)(int, void*))block_done)(b, user);
   }
   return ACVAE_OK;
+}
+}  // namespace
+
+extern "C" int acvae_encoder_bwd_hooked(const void* const* params, void* const* grads, const float* feats,
+                                 const float* d_audio_embeds, void* saved_v, int64_t saved_bytes, void* scratch_v,
+                                 int64_t scratch_bytes, int arch, int N, int T, int F, int training, float p_block,
+                                 uint64_t seed, const uint8_t* const* masks, void* stream, void* block_done,
+                                 void* user) {
+  if (is_bf16(arch))
+    return encoder_bwd_t<bf16_t>(params, grads, feats, d_audio_embeds, saved_v, saved_bytes, scratch_v, scratch_bytes, arch,
+                                 N, T, F, training, p_block, seed, masks, stream, block_done, user);
+  return encoder_bwd_t<float>(params, grads, feats, d_audio_embeds, saved_v, saved_bytes, scratch_v, scratch_bytes, arch, N,
+                              T, F, training, p_block, seed, masks, stream, block_done, user);
 }
 
 extern "C" int acvae_encoder_bwd(const void* const* params, void* const* grads, const float* feats,

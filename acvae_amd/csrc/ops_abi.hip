@@ -20,8 +20,13 @@ ConvWs conv_ws(int N, int H, int W, int Cin, int Cout) {
   const long part = Cin == 1 ? (long)acvae::conv1_first_blocks(N, H) * 128 : (long)acvae::conv_partials_rows(N, H, W) * 2 * Cout;
   w.partials = o; o = al64(o + part);
   w.dpart = o; o = al64(o + 2 * acvae::colsum_scratch_doubles(2 * Cout > 1024 ? 2 * Cout : 1024));
-  w.slab = o; o = al64(o + (Cin == 1 ? (long)acvae::conv1_first_blocks(N, H) * (576 + 128)
-                                     : acvae::conv3x3_wgrad_slab_floats(N, H, W, Cin, Cout)));
+  long slab = Cin == 1 ? (long)acvae::conv1_first_blocks(N, H) * (576 + 128)
+                       : acvae::conv3x3_wgrad_slab_floats(N, H, W, Cin, Cout);
+  if (Cin % 64 == 0) {                              // the bf16 forms share this workspace
+    const long sb = acvae::conv3x3_wgrad_bf16_slab_floats(N, H, W, Cin, Cout);
+    if (sb > slab) slab = sb;
+  }
+  w.slab = o; o = al64(o + slab);
   w.total = o;
   return w;
 }
@@ -57,7 +62,7 @@ extern "C" int acvae_conv3x3_fwd(const float* X, const float* W_oihw, const floa
     ACVAE_TRY(acvae::conv1_first_fwd(X, in_scale, in_shift, W_oihw, Y, partials, N, H, W, st));
     nparts = acvae::conv1_first_blocks(N, H);
   } else {
-    ACVAE_TRY(acvae::repack_weights(W_oihw, ws + L.wp, nullptr, Cout, Cin, st));
+    ACVAE_TRY(acvae::repack_weights<float>(W_oihw, ws + L.wp, nullptr, Cout, Cin, st));
     ACVAE_TRY(acvae::conv3x3_igemm(X, in_scale, in_shift, ws + L.wp, Y, partials, N, H, W, Cin, Cout, st));
     nparts = acvae::conv_partials_rows(N, H, W);
   }
@@ -76,7 +81,7 @@ extern "C" int acvae_conv3x3_dgrad(const float* dY, const float* W_oihw, float* 
   if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)ws_v;
-  ACVAE_TRY(acvae::repack_weights(W_oihw, nullptr, ws + L.wp, Cout, Cin, st));
+  ACVAE_TRY(acvae::repack_weights<float>(W_oihw, nullptr, ws + L.wp, Cout, Cin, st));
   // the data gradient is the same implicit GEMM on dY with the flipped, transposed weights: Cout plays Cin
   return acvae::conv3x3_igemm(dY, nullptr, nullptr, ws + L.wp, dX, nullptr, N, H, W, Cout, Cin, st);
 }
@@ -91,6 +96,55 @@ extern "C" int acvae_conv3x3_wgrad(const float* dY, const float* X, const float*
   if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
   return acvae::conv3x3_wgrad(dY, X, in_scale, in_shift, dW_oihw, (float*)ws_v + L.slab, N, H, W, Cin, Cout,
                               (hipStream_t)stream);
+}
+
+// ---- bf16 storage
+extern "C" int acvae_conv3x3_fwd_bf16(const void* X, const float* W_oihw, const float* in_scale, const float* in_shift,
+                                      void* Y, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, int training, float* bn_out,
+                                      void* ws_v, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream) {
+  if (!conv_dims_ok(N, H, W, Cin, Cout) || !X || !W_oihw || !Y || !ws_v) return ACVAE_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return ACVAE_EINVAL;
+  if (bn_out && (!gamma || !beta || !running_mean || !running_var)) return ACVAE_EINVAL;
+  if (Cin % 64 != 0) return ACVAE_EUNSUPPORTED;
+  const ConvWs L = conv_ws(N, H, W, Cin, Cout);
+  if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  if (!aligned16(ws_v)) return ACVAE_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)ws_v;
+  float* partials = (bn_out && training) ? ws + L.partials : nullptr;
+  bf16_t* wp = (bf16_t*)(ws + L.wp);
+  ACVAE_TRY(acvae::repack_weights<bf16_t>(W_oihw, wp, nullptr, Cout, Cin, st));
+  ACVAE_TRY(acvae::conv3x3_igemm_bf16((const bf16_t*)X, in_scale, in_shift, wp, (bf16_t*)Y, partials, N, H, W, Cin, Cout, st));
+  if (bn_out)
+    ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_partials_rows(N, H, W), Cout, (double)N * H * W, gamma, beta,
+                                 running_mean, running_var, num_batches_tracked, training, bn_out, bn_out + Cout,
+                                 bn_out + 2 * Cout, bn_out + 3 * Cout, (double*)(ws + L.dpart), st));
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_conv3x3_dgrad_bf16(const void* dY, const float* W_oihw, void* dX, void* ws_v, int64_t ws_bytes, int N,
+                                        int H, int W, int Cin, int Cout, void* stream) {
+  if (!conv_dims_ok(N, H, W, Cin, Cout) || !dY || !W_oihw || !dX || !ws_v) return ACVAE_EINVAL;
+  if (Cin % 64 != 0 || Cout % 64 != 0) return ACVAE_EUNSUPPORTED;
+  const ConvWs L = conv_ws(N, H, W, Cin, Cout);
+  if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* wd = (bf16_t*)((float*)ws_v + L.wp);
+  ACVAE_TRY(acvae::repack_weights<bf16_t>(W_oihw, nullptr, wd, Cout, Cin, st));
+  return acvae::conv3x3_igemm_bf16((const bf16_t*)dY, nullptr, nullptr, wd, (bf16_t*)dX, nullptr, N, H, W, Cout, Cin, st);
+}
+
+extern "C" int acvae_conv3x3_wgrad_bf16(const void* dY, const void* X, const float* in_scale, const float* in_shift,
+                                        float* dW_oihw, void* ws_v, int64_t ws_bytes, int N, int H, int W, int Cin,
+                                        int Cout, void* stream) {
+  if (!conv_dims_ok(N, H, W, Cin, Cout) || !dY || !X || !dW_oihw || !ws_v) return ACVAE_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return ACVAE_EINVAL;
+  if (Cin % 64 != 0) return ACVAE_EUNSUPPORTED;
+  const ConvWs L = conv_ws(N, H, W, Cin, Cout);
+  if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  return acvae::conv3x3_wgrad((const bf16_t*)dY, (const bf16_t*)X, in_scale, in_shift, dW_oihw, (float*)ws_v + L.slab, N, H,
+                              W, Cin, Cout, (hipStream_t)stream);
 }
 
 extern "C" int acvae_conv1_first_bwd(const float* x, const float* bn0, const float* W1_oihw, const float* dY, float* dW1,

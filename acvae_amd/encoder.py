@@ -73,7 +73,7 @@ class _Cnn10Fn(torch.autograd.Function):
         N, T, F = feats.shape
         tensors = mod._param_table()
         dev = feats.device
-        arch = mod.ARCH
+        arch = mod._arch()
         saved_b = _lib.call("acvae_encoder_saved_bytes", arch, N, T, F)
         scratch_b = _lib.call("acvae_encoder_scratch_bytes", arch, N, T, F)
         if saved_b < 0:
@@ -95,6 +95,7 @@ class _Cnn10Fn(torch.autograd.Function):
         _lib.call("acvae_encoder_fwd", ptr_table(tensors), feats, ae, pooled, saved, saved_b, scratch, scratch_b, arch,
                   N, T, F, int(training), float(mod.p_block), float(mod.p_fc), seed, mt, _lib.current_stream())
         ctx.mod, ctx.feats, ctx.saved, ctx.masks, ctx.seed, ctx.training = mod, feats, saved, masks, seed, training
+        ctx.arch = arch
         ctx.mark_non_differentiable(pooled)
         return ae, pooled
 
@@ -109,7 +110,7 @@ class _Cnn10Fn(torch.autograd.Function):
             if t.dtype.is_floating_point and t.requires_grad and i < len(tensors) - 2:
                 grads[i] = mod._grad_buffer(t)
         d_ae = d_ae.contiguous().float()
-        scratch_b = _lib.call("acvae_encoder_scratch_bytes", mod.ARCH, N, T, F)
+        scratch_b = _lib.call("acvae_encoder_scratch_bytes", ctx.arch, N, T, F)
         scratch = scratch_buffer(scratch_b, feats.device)
         mt = ptr_table(ctx.masks) if ctx.masks is not None else None
         hook, failed = None, []
@@ -123,7 +124,7 @@ class _Cnn10Fn(torch.autograd.Function):
                     failed.append(exc)
             hook = _BLOCK_HOOK(block_done)
         _lib.call("acvae_encoder_bwd_hooked", ptr_table(tensors), ptr_table(grads), feats, d_ae, ctx.saved,
-                  ctx.saved.numel(), scratch, scratch_b, mod.ARCH, N, T, F, int(ctx.training), float(mod.p_block), ctx.seed, mt,
+                  ctx.saved.numel(), scratch, scratch_b, ctx.arch, N, T, F, int(ctx.training), float(mod.p_block), ctx.seed, mt,
                   _lib.current_stream(), ctypes.cast(hook, ctypes.c_void_p) if hook is not None else None, None)
         if failed:
             raise failed[0]
@@ -151,12 +152,21 @@ class _PannsCnn(nn.Module):
         init_bn(self.bn0)
         init_layer(getattr(self, self.HEAD))
         self.p_block, self.p_fc = 0.2, 0.5      # F.dropout probabilities, encoder.py:684-698 / :929-950
+        # "f32" (the reference's arithmetic, BASELINE configs[1]) or "bf16": BASELINE configs[2] "bf16 forward / fp32
+        # loss" - the conv stack stores its activations in bf16 and multiplies on the bf16 MFMA pipe; parameters,
+        # BatchNorm statistics, gradients of the parameters and both outputs stay fp32 (ACVAE_ENC_BF16)
+        self.compute_dtype = kwargs.get("compute_dtype", "f32")
         self.dropout_masks = None               # optional explicit keep-masks (parity tests)
         self._seed_base, self._calls = None, 0
         self._grad_views = None                 # {param: flat-gradient view}, set by the train-step harness
         self._grad_ready_cb = None              # called with "encoder" when the backward has written all grads
 
     # ---- plumbing
+    def _arch(self):
+        if self.compute_dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'f32' or 'bf16', not {self.compute_dtype!r}")
+        return self.ARCH | (_lib.ENC_BF16 if self.compute_dtype == "bf16" else 0)
+
     def _blocks(self):
         return [getattr(self, f"conv_block{b}") for b in range(1, self.N_BLOCKS + 1)]
 

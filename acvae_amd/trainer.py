@@ -97,8 +97,10 @@ def kl_weight_for(epoch, epochs, beta):
 class TrainStep:
     def __init__(self, model, vocab_size, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
                  label_smoothing=True, smoothing=0.1, alpha=1.0, global_loss="MSE", process_group=None,
-                 broadcast_buffers=True, data_parallel=True):
+                 broadcast_buffers=True, data_parallel=True, precision=None):
         self.model = model
+        if precision is not None:                   # "f32" | "bf16" (bf16 forward / fp32 loss: BASELINE configs[2])
+            model.encoder.compute_dtype = precision
         self.vocab = vocab_size
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm

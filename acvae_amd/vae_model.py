@@ -353,9 +353,13 @@ class Hybrid_VAEModel(CaptionModel):
             if side is not main:
                 side.wait_stream(main)
                 prep["caps_d"].record_stream(side)
+            # The encoder is queued FIRST and the posterior second (it still starts at once: the side stream only waits
+            # for what main held before this point).  Autograd runs the later-created node first, so in the backward
+            # the posterior's kernels and its gradient bucket are queued before the long encoder backward: under data
+            # parallelism the 20 MB posterior bucket then travels beside the encoder backward instead of behind it.
+            encoded = self.encoder(feats, feat_lens)
             with torch.cuda.stream(side):
                 qnetout = self.qnet(prep["caps_d"], cap_lens, eps=eps_q)
-            encoded = self.encoder(feats, feat_lens)
             if side is not main:
                 main.wait_stream(side)
                 for v in qnetout.values():

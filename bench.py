@@ -27,6 +27,7 @@ B, T, F, V, L, E = 32, 1000, 64, 5000, 22, 512
 HOP_S = 0.010  # assumed log-mel hop (PANNs/Cnn10 convention; the reference never states it: SURVEY §8(d))
 ENC_FWD_GFLOP_PER_CLIP = 26.03   # conv MACs x2 of Cnn10 at T=1000
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md, Peak FP32 (matrix)
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md, Peak BF16 MFMA, dense
 
 
 def build_model():
@@ -98,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)     # steps 1-7 of a fresh process run 31-34 ms, later ones 28.7
                                                          # (tools/step_times.py): allocator, event and clock warm-up
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 = BASELINE configs[1] (the headline, default); bf16 = configs[2]: bf16 forward / fp32 loss "
+                         "(conv stack on the bf16 MFMA pipe, activations stored in bf16; text side, loss, parameters fp32)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -114,6 +118,7 @@ def main():
                "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
+        cmd += ["--dtype", args.dtype]
         raise SystemExit(subprocess.call(cmd))
 
     import torch
@@ -142,7 +147,7 @@ def main():
     from acvae_amd.trainer import TrainStep, max_over_ranks
 
     model = build_model().cuda().train()
-    ts = TrainStep(model, V, lr=5e-4, max_grad_norm=1.0, smoothing=0.1, alpha=1.0)
+    ts = TrainStep(model, V, lr=5e-4, max_grad_norm=1.0, smoothing=0.1, alpha=1.0, precision=args.dtype)
     feats_host, caps, feat_lens, cap_lens = synthetic(1 + rank)
     feats = feats_host.cuda()
 
@@ -214,22 +219,28 @@ def main():
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        bf16 = args.dtype == "bf16"
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        kernel = ("conv_igemm_bf16_kernel (conv3x3 implicit GEMM fwd+dgrad, v_mfma_f32_32x32x16_bf16, bf16 activations)"
+                  if bf16 else
+                  "conv_igemm3_kernel (conv3x3 implicit GEMM fwd+dgrad with horizontal-tap reuse, fp32 MFMA)")
+        which = ("BASELINE configs[2] per-GPU shape (bf16 forward / fp32 loss)" if bf16 else "BASELINE configs[1]")
         out = {
             "metric": "train-step captions/s (and audio-sec/s) at B=32, 1/2/4/8 MI355X",
             "value": caps_per_s, "unit": "captions/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: per-GPU batch B={B}, T={T} frames, F={F} mel, {L}-token captions "
-                                   f"(Tc={L - 1} decode steps), vocab {V}, E=H=A={E}, fp32; full optimiser step "
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{which}: per-GPU batch B={B}, T={T} frames, F={F} mel, {L}-token captions "
+                                   f"(Tc={L - 1} decode steps), vocab {V}, E=H=A={E}, {'bf16 conv stack, fp32 text side / loss / parameters' if bf16 else 'fp32'}; full optimiser step "
                                    "(fwd + CE/KL/MSE loss + bwd + global-norm clip + Adam), ss_ratio=1, dis_ratio=0",
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}" if n_gpus > 1 else "single",
                        "frames_per_s": frames_per_s, "audio_s_per_s": frames_per_s * HOP_S, "hop_s_assumed": HOP_S,
                        "loss_last_step": loss, "pcie_inclusive_ms_per_step": pcie_ms,
                        "pcie_inclusive_note": f"{PCIE_STEPS} extra steps after the timed region with the feature batch "
                                               "uploaded from page-locked host memory inside each step"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm3_kernel (conv3x3 implicit GEMM fwd+dgrad with horizontal-tap reuse, fp32 MFMA)",
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": kernel,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None if bf16 else traffic,
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_gflop_per_launch": flops_per_step / 1e9 / max(1.0, launches_per_step),
                          "wgrad_avg_launch_ms": wgrad_ms / max(1, wgrad_n), "wgrad_launches_per_step": wgrad_n / max(1, sampled), "steps_sampled": sampled},

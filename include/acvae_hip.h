@@ -146,6 +146,12 @@ int acvae_mse_bwd(const float* a, const float* b, const float* grad_out, float* 
 #define ACVAE_ENC_NPARAMS 55          /* Cnn10 */
 #define ACVAE_ARCH_CNN10 0
 #define ACVAE_ARCH_CNN14_16K 1
+/* OR-ed into `arch`: BASELINE configs[2] "bf16 forward / fp32 loss".  The conv stack's activations (raw conv outputs,
+ * pooled tensors, their gradients) and the repacked conv weights are STORED in bf16 and the 3x3 convolutions run on
+ * v_mfma_f32_32x32x16_bf16; accumulation, BatchNorm statistics (taken from the rounded tensor that is stored), parameter
+ * gradients, parameters and every output of these calls (audio_embeds, pooled) stay fp32.  Same tables, same dropout
+ * streams; saved / scratch sizes roughly halve (ask acvae_encoder_saved_bytes / _scratch_bytes with the flag set). */
+#define ACVAE_ENC_BF16 256
 int acvae_encoder_nparams(int arch);
 int acvae_encoder_out_dims(int arch, int T, int* S, int* C);
 int64_t acvae_encoder_saved_bytes(int arch, int N, int T, int F);
@@ -206,6 +212,18 @@ int acvae_conv3x3_wgrad(const float* dY, const float* X, const float* in_scale, 
                         void* ws, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
 int acvae_conv1_first_bwd(const float* x, const float* bn0, const float* W1_oihw, const float* dY, float* dW1,
                           float* dgamma0, float* dbeta0, void* ws, int64_t ws_bytes, int N, int T, int F, void* stream);
+/* bf16-storage forms of the three convolutions (acvae_encoder_* with ACVAE_ENC_BF16): X / dY / dX / Y are bf16 NHWC
+ * (uint16 bit patterns, round-to-nearest-even), weights OIHW fp32 (rounded to bf16 inside), dW fp32.  Cin % 64 == 0.
+ * acvae_conv3x3_fwd_bf16 returns this layer's BatchNorm in bn_out exactly like the fp32 form, from the statistics of the
+ * ROUNDED output.  Same workspace size as the fp32 forms. */
+int acvae_conv3x3_fwd_bf16(const void* X, const float* W_oihw, const float* in_scale, const float* in_shift, void* Y,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, int training, float* bn_out, void* ws, int64_t ws_bytes, int N,
+                           int H, int W, int Cin, int Cout, void* stream);
+int acvae_conv3x3_dgrad_bf16(const void* dY, const float* W_oihw, void* dX, void* ws, int64_t ws_bytes, int N, int H, int W,
+                             int Cin, int Cout, void* stream);
+int acvae_conv3x3_wgrad_bf16(const void* dY, const void* X, const float* in_scale, const float* in_shift, float* dW_oihw,
+                             void* ws, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
 int64_t acvae_bn_workspace_bytes(int N, int H, int W, int C);
 int acvae_bn_mel_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, int training, float* bn_out, void* ws, int64_t ws_bytes, int64_t rows,

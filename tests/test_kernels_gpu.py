@@ -130,6 +130,75 @@ def test_conv3x3_kernel_variants_behind_the_switches():
         assert r.returncode == 0, (env, r.stdout[-3000:] + r.stderr[-1000:])
 
 
+def run_conv_bf16(N, H, W, Cin, Cout, act, seed=0):
+    """bf16-storage convolutions (BASELINE configs[2]): operands are bf16 values, so the fp64 reference on the SAME
+    rounded operands differs only by the fp32 accumulation order and the final rounding of a bf16 output (2^-9)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    dy = (torch.randn(N, Cout, H, W, generator=g) / math.sqrt(N * H * W)).bfloat16()
+    wb = w.bfloat16()
+    sc = sh = None
+    if act:
+        sc = torch.rand(Cin, generator=g) + 0.5
+        sh = torch.randn(Cin, generator=g) * 0.3
+        xa = (x.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).clamp_min(0).bfloat16().double()
+    else:
+        xa = x.double()
+    xa = xa.clone().requires_grad_(True)
+    wd = wb.double().requires_grad_(True)
+    y_ref = F.conv2d(xa, wd, padding=1)
+    y_ref.backward(dy.double())
+    wsb = _lib.call("acvae_conv3x3_workspace_bytes", N, H, W, Cin, Cout)
+    ws = ws_buf(wsb)
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    scd = None if sc is None else sc.cuda()
+    shd = None if sh is None else sh.cuda()
+    what = f"bf16 {Cin}->{Cout} {N}x{H}x{W} act={act}"
+
+    def check_bf16(got, ref, K, name):
+        got = got.float().cpu().double(); ref = ref.detach().double()
+        rms = float(ref.pow(2).mean().sqrt())
+        tol = chain_tol(K) * torch.maximum(ref.abs(), torch.full_like(ref, rms)) + 2.0 ** -8 * ref.abs()
+        err = (got - ref).abs()
+        assert bool((err <= tol).all()), f"{name} {what}: worst {float((err / tol).max()):.2f} x tol"
+
+    y = torch.empty(N, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    g_, b_ = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    bn = torch.empty(4, Cout, device="cuda")
+    _lib.call("acvae_conv3x3_fwd_bf16", xd, w.cuda(), scd, shd, y, g_.cuda(), b_.cuda(), rm, rv, None, 1, bn, ws, wsb, N, H,
+              W, Cin, Cout, S())
+    check_bf16(y, nhwc(y_ref), 9 * Cin, "fwd")
+    # the statistics are those of the stored (rounded) tensor
+    ys = y.float().cpu().double()
+    mu, var = ys.mean((0, 1, 2)), ys.var((0, 1, 2), unbiased=False)
+    np.testing.assert_allclose(bn[2].cpu().double(), mu, rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(bn[3].cpu().double(), 1 / torch.sqrt(var + 1e-5), rtol=3e-5)
+    dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    _lib.call("acvae_conv3x3_wgrad_bf16", dyd, xd, scd, shd, dw, ws, wsb, N, H, W, Cin, Cout, S())
+    assert_every_element(dw, wd.grad, N * H * W, "wgrad " + what)
+    if not act:
+        dx = torch.empty(N, H, W, Cin, device="cuda", dtype=torch.bfloat16)
+        _lib.call("acvae_conv3x3_dgrad_bf16", dyd, w.cuda(), dx, ws, wsb, N, H, W, Cin, Cout, S())
+        check_bf16(dx, nhwc(xa.grad), 9 * Cout, "dgrad")
+
+
+@pytest.mark.parametrize("Cin,Cout", LAYERS)
+def test_conv3x3_bf16_every_layer_shape_vs_fp64(Cin, Cout):
+    shapes = SHAPES if Cin <= 512 else SHAPES[:1] + SHAPES[2:]
+    for i, (N, H, W) in enumerate(shapes):
+        for act in (False, True):
+            run_conv_bf16(N, H, W, Cin, Cout, act, seed=100 * Cin + 10 * i + int(act))
+
+
+def test_conv3x3_bf16_real_block_geometry():
+    for (N, H, W, Cin, Cout) in [(2, 11, 64, 64, 64), (3, 9, 32, 64, 128), (2, 37, 8, 256, 512), (3, 21, 4, 512, 512),
+                                 (2, 70, 64, 64, 64)]:
+        run_conv_bf16(N, H, W, Cin, Cout, True, seed=7)
+        run_conv_bf16(N, H, W, Cin, Cout, False, seed=8)
+
+
 def test_first_conv_and_bn_mel_vs_fp64():
     """bn0 over the mel axis (models/encoder.py:679-681) + conv_block1.conv1 (Cin = 1) forward with its BatchNorm
     statistics, and the first layer's backward (dW1, bn0's dgamma / dbeta)."""

@@ -432,9 +432,9 @@ def test_edge_shapes_vs_oracle(B, Tt, L, lens, flens):
 def test_g6_trainstep_against_the_reference_adam_step():
     """TrainStep.step (forward, loss, backward, clip_grad_norm_(1.0), Adam lr 5e-4) on the g6 batch against the state
     the REFERENCE model held after its own optimiser step (golden post_*: three parameters, two BatchNorm running
-    buffers).  Adam's first step moves an element by lr * g / (|g| + 1e-8) ~ lr * sign(g): elements whose clipped
-    gradient is at rounding-noise level (< 1e-5 here) may land anywhere within 2 lr; every other element must agree
-    to 2e-6, the running statistics to rtol 1e-5."""
+    buffers).  Adam's first step moves an element by lr * g / (|g| + 1e-8): the tolerance of an element is 2e-6 plus
+    the first-order effect of the gradient's own tolerance on that quotient (capped at 2 lr: elements whose gradient is
+    at the 1e-8 level may land anywhere within the step); the running statistics agree to rtol 1e-5."""
     from acvae_amd.trainer import TrainStep
     g = load_golden("g6_train_step")
     B, Tt, V, E, L = (int(x) for x in g["dims"])
@@ -457,12 +457,19 @@ def test_g6_trainstep_against_the_reference_adam_step():
         name, ref = k[5:], T(g[k]).double()
         got = sd[name].detach().cpu().double()
         if name in named:
+            # first Adam step: u = lr * g / (|g| + 1e-8)  ->  |du| = lr * 1e-8 * |dg| / (|g| + 1e-8)^2, with the
+            # gradient itself known to 2e-4 of the tensor's max (1e-2 for encoder tensors, whose gradients can carry a
+            # ReLU-boundary flip: the gradient tolerances of the tests above)
             gr = named[name].grad.detach().cpu().double().abs() * coef
+            dg = (1e-2 if name.startswith("encoder.") else 2e-4) * float(gr.max())
+            # (the derivative is taken at the point of the interval [|g| - dg, |g| + dg] nearest zero; an element whose
+            # gradient is smaller than its own uncertainty may land anywhere within the step)
+            near = torch.clamp(gr - dg, min=0.0)
+            tol = 2e-6 + torch.where(gr > dg, torch.clamp(ts.lr * 1e-8 * dg / (near + 1e-8) ** 2, max=2.1 * ts.lr),
+                                     torch.full_like(gr, 2.1 * ts.lr))
             err = (got - ref).abs()
-            firm = gr >= 1e-5
-            assert float(firm.double().mean()) > 0.9, (name, float(firm.double().mean()))
-            assert float(err[firm].max()) <= 2e-6, (name, float(err[firm].max()))
-            assert float(err.max()) <= 2.1 * ts.lr, (name, float(err.max()))
+            assert bool((err <= tol).all()), (name, float((err / tol).max()), float(err.max()))
+            assert float((tol <= 4e-6).double().mean()) > 0.5, (name, "most elements must be pinned tightly")
             assert float((got - state[name].double()).abs().max()) > 0.5 * ts.lr      # the step was taken at all
         else:
             close(got, ref, 1e-5, 1e-7, what=name)
