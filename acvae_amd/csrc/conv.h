@@ -75,6 +75,8 @@ int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const floa
            const float* invstd, float* partials, float* sum_g, float* sum_gy, T* dY, double* dpart, int N, int H,
            int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats = true);
 template <class T>
+int relu_mask(const T* Y, const float* scale, const float* shift, uint8_t* out, int N, int H, int W, int C, hipStream_t st);
+template <class T>
 int freq_mean(const T* P, float* out, long rows, int Fp, int C, hipStream_t st);
 template <class T>
 int freq_mean_bwd(const float* dae, T* dP, long rows, int Fp, int C, hipStream_t st);

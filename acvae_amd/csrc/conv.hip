@@ -1047,6 +1047,23 @@ __global__ void bn_relu_drop_kernel(const T* __restrict__ Y, const float* __rest
   }
 }
 
+// ReLU decisions of a BN+ReLU site exactly as the backward kernels take them (y * scale + shift > 0), written in the
+// reference's NCHW order: test / debugging aid (acvae_encoder_relu_mask)
+template <class T>
+__global__ void relu_mask_kernel(const T* __restrict__ Y, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, uint8_t* __restrict__ out, int N, int H, int W, int C) {
+  const long total = (long)N * H * W * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    const float y = load1(Y + i);
+    out[(((long)n * C + c) * H + h) * W + w] = (y * scale[c] + shift[c] <= 0.f) ? 0 : 1;
+  }
+}
+
 // ------------------------------------------------------------------ BN backward
 // g = relu'(bn(Y)) * upstream;  UP_POOL: upstream = dP[n,h/2,w/2,c] * dropmask * 0.25 (0 for a trailing odd row/col)
 template <int UP, class T>
@@ -1478,6 +1495,15 @@ int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const floa
 }
 template int bn_bwd<float>(const float*, const float*, int, const float*, const float*, const float*, const float*, float*, float*, float*, float*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool);
 template int bn_bwd<bf16_t>(const bf16_t*, const bf16_t*, int, const float*, const float*, const float*, const float*, float*, float*, float*, bf16_t*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool);
+
+template <class T>
+int relu_mask(const T* Y, const float* scale, const float* shift, uint8_t* out, int N, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(relu_mask_kernel<T>, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, st, Y, scale, shift, out, N, H, W, C);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+template int relu_mask<float>(const float*, const float*, const float*, uint8_t*, int, int, int, int, hipStream_t);
+template int relu_mask<bf16_t>(const bf16_t*, const float*, const float*, uint8_t*, int, int, int, int, hipStream_t);
 
 template <class T>
 int freq_mean(const T* P, float* out, long rows, int Fp, int C, hipStream_t st) {

@@ -229,6 +229,25 @@ extern "C" int acvae_encoder_fwd(const void* const* params, const float* feats, 
                               T, F, training, p_block, p_fc, seed, masks, stream);
 }
 
+// The ReLU decisions the backward will take at BN+ReLU site `site` (0 .. 2*blocks-1: block site/2 + 1, bn1 / bn2), read
+// from the `saved` buffer of a forward call and written as uint8 [N,C,H,W] (the reference's layout).  Test aid: lets a
+// checker evaluate the reference under exactly these decisions instead of tolerating rounding-dependent mask flips.
+extern "C" int acvae_encoder_relu_mask(const void* saved_v, int64_t saved_bytes, int arch, int N, int T, int F, int site,
+                                       uint8_t* mask_nchw, void* stream) {
+  EncLayout L;
+  ACVAE_TRY(make_layout(arch, N, T, F, L));
+  if (!saved_v || !mask_nchw || site < 0 || site >= 2 * L.nb) return ACVAE_EINVAL;
+  if (saved_bytes < L.total * (int64_t)sizeof(float)) return ACVAE_EWORKSPACE;
+  float* saved = (float*)saved_v;
+  const int b = site / 2 + 1, which = site % 2;
+  BnPtrs bn = bn_at(saved, L, 1 + 2 * (b - 1) + which);
+  const long off = which ? L.y2[b] : L.y1[b];
+  if (is_bf16(arch))
+    return acvae::relu_mask<bf16_t>((const bf16_t*)(saved + off), bn.scale, bn.shift, mask_nchw, N, L.H[b], L.W[b], kChan[b],
+                                    (hipStream_t)stream);
+  return acvae::relu_mask<float>(saved + off, bn.scale, bn.shift, mask_nchw, N, L.H[b], L.W[b], kChan[b], (hipStream_t)stream);
+}
+
 namespace {
 template <class TA>
 int encoder_bwd_t(const void* const* params, void* const* grads, const float* feats,

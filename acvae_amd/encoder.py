@@ -96,6 +96,8 @@ class _Cnn10Fn(torch.autograd.Function):
                   N, T, F, int(training), float(mod.p_block), float(mod.p_fc), seed, mt, _lib.current_stream())
         ctx.mod, ctx.feats, ctx.saved, ctx.masks, ctx.seed, ctx.training = mod, feats, saved, masks, seed, training
         ctx.arch = arch
+        if mod.keep_saved:                       # test aid: relu_masks() reads the decisions out of this buffer
+            mod._last_saved = (saved, arch, N, T, F)
         ctx.mark_non_differentiable(pooled)
         return ae, pooled
 
@@ -158,6 +160,8 @@ class _PannsCnn(nn.Module):
         self.compute_dtype = kwargs.get("compute_dtype", "f32")
         self.dropout_masks = None               # optional explicit keep-masks (parity tests)
         self._seed_base, self._calls = None, 0
+        self.keep_saved = False                 # test aid: keep the last forward's activation buffer for relu_masks()
+        self._last_saved = None
         self._grad_views = None                 # {param: flat-gradient view}, set by the train-step harness
         self._grad_ready_cb = None              # called with "encoder" when the backward has written all grads
 
@@ -187,6 +191,24 @@ class _PannsCnn(nn.Module):
         if self._grad_views is not None and p in self._grad_views:
             return self._grad_views[p].detach()     # fresh alias: autograd adopts it as .grad without a copy
         return torch.empty_like(p)
+
+    def relu_masks(self):
+        """The ReLU decisions of the last forward (``keep_saved = True`` must have been set before it), one bool tensor
+        [N,C,H,W] per BN+ReLU site in forward order - exactly the masks the backward applies (acvae_encoder_relu_mask)."""
+        if self._last_saved is None:
+            raise RuntimeError("relu_masks(): set keep_saved = True before the forward")
+        saved, arch, N, T, F = self._last_saved
+        chans = [64, 128, 256, 512, 1024, 2048]
+        out, h, w = [], T, F
+        for b in range(self.N_BLOCKS):
+            for which in range(2):
+                m = torch.empty(N, chans[b], h, w, dtype=torch.uint8, device=saved.device)
+                _lib.call("acvae_encoder_relu_mask", saved, saved.numel(), arch, N, T, F, 2 * b + which, m,
+                          _lib.current_stream())
+                out.append(m.bool())
+            if b < self.N_BLOCKS - 1 or self.ARCH == 0:
+                h, w = h // 2, w // 2
+        return out
 
     def _next_seed(self):
         if self._seed_base is None:

@@ -167,6 +167,12 @@ int acvae_encoder_bwd(const void* const* params, void* const* grads, const float
                       const float* d_audio_embeds, void* saved, int64_t saved_bytes, void* scratch,
                       int64_t scratch_bytes, int arch, int N, int T, int F, int training, float p_block, uint64_t seed,
                       const uint8_t* const* masks, void* stream);
+/* Test aid: the ReLU decisions (y * scale + shift > 0, as the backward kernels evaluate them) of BN+ReLU site `site`
+ * (0 .. 2*blocks-1: ConvBlock site/2 + 1, bn1 then bn2) read from the `saved` buffer of a forward call, written as uint8
+ * [N,C,H,W] - the reference's layout.  A checker evaluates the reference under exactly these decisions instead of
+ * tolerating mask bits that two fp32 summation orders put on different sides of zero. */
+int acvae_encoder_relu_mask(const void* saved, int64_t saved_bytes, int arch, int N, int T, int F, int site,
+                            uint8_t* mask_nchw, void* stream);
 /* The same with a host callback: `block_done`, if not NULL, is a `void (*)(int block, void* user)` (passed as void*)
  * that is called on the calling thread right after the kernels producing ALL parameter gradients of ConvBlock `block`
  * (conv1 / conv2 / bn1 / bn2; blocks run nb .. 1) have been queued on `stream`: a data-parallel caller starts the

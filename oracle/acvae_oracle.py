@@ -198,8 +198,20 @@ def _bn_track(state, p, training):
         state[p + ".num_batches_tracked"] += 1
 
 
+def _relu_site(z, site, relu_probe, relu_force):
+    """F.relu with two test hooks (both None in every normal use): `relu_probe` (a list) receives the pre-activation of
+    each site in call order; `relu_force` ({site: bool tensor}) replaces the site's mask z > 0 - used to evaluate the
+    oracle under an explicit assignment of the mask bits whose pre-activation is within fp32 rounding distance of 0,
+    where two summation orders legitimately disagree (tests: relu_mask_cases)."""
+    if relu_probe is not None:
+        relu_probe.append(z.detach().clone())
+    if relu_force is not None and site in relu_force:
+        return z * relu_force[site].to(z.dtype)
+    return F.relu(z)
+
+
 def cnn10_forward(state, feats, feat_lens, training=True, masks=None, record=None, prefix="encoder",
-                  mutate_lens=True):
+                  mutate_lens=True, relu_probe=None, relu_force=None):
     """models/encoder.py:672-707 (Cnn10) and :906-964 (Cnn14_16k, recognised by its conv_block6 / fc1 entries).
     Returns dict(audio_embeds[N,S,C], audio_embeds_pooled[N,C], audio_embeds_lens i64[N], state None)."""
     arch = ENCODERS["Cnn14_16k" if prefix + ".fc1.weight" in state else "Cnn10"]
@@ -215,9 +227,11 @@ def cnn10_forward(state, feats, feat_lens, training=True, masks=None, record=Non
     for b in range(1, nblocks + 1):                            # :683-690 / :928-939, ConvBlock.forward :633-649
         p = f"{prefix}.conv_block{b}"
         x = F.conv2d(x, state[p + ".conv1.weight"], None, 1, 1)
-        x = F.relu(_bn(state, p + ".bn1", x, training)); _bn_track(state, p + ".bn1", training)
+        x = _relu_site(_bn(state, p + ".bn1", x, training), 2 * b - 2, relu_probe, relu_force)
+        _bn_track(state, p + ".bn1", training)
         x = F.conv2d(x, state[p + ".conv2.weight"], None, 1, 1)
-        x = F.relu(_bn(state, p + ".bn2", x, training)); _bn_track(state, p + ".bn2", training)
+        x = _relu_site(_bn(state, p + ".bn2", x, training), 2 * b - 1, relu_probe, relu_force)
+        _bn_track(state, p + ".bn2", training)
         if b < nblocks or arch["pool_last"]:
             x = F.avg_pool2d(x, kernel_size=(2, 2))
         else:
@@ -367,7 +381,9 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
     from torch's CPU generator in the reference's call order.  `record` receives the drawn noise."""
     masks = list(noise["dropout"]) if noise is not None and "dropout" in noise else None
     rec_masks: List[torch.Tensor] = []
-    enc = cnn10_forward(state, feats, feat_lens, training, masks, rec_masks, mutate_lens=mutate_lens)
+    relu_probe = [] if record is not None else None
+    enc = cnn10_forward(state, feats, feat_lens, training, masks, rec_masks, mutate_lens=mutate_lens,
+                        relu_probe=relu_probe, relu_force=None if noise is None else noise.get("relu_force"))
     if "ln.weight" in state:                                                  # vae_model.py:743-744
         enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
     mem, mem_lens = enc["audio_embeds"], enc["audio_embeds_lens"]
@@ -437,6 +453,7 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         record["dropout"] = rec_masks
         record["eps_q"] = q["_eps"] if train else None
         record["eps_p"] = torch.stack(eps_p, 0)
+        record["relu_z"] = relu_probe
         record["sample_noise"] = torch.stack(sample_noise, 0) if sample_noise else None
     return out
 
@@ -608,6 +625,29 @@ def train_loss(out, caps, cap_lens, vocab, smoothing=0.1, kl_weight=0.5, alpha=1
         mse = F.mse_loss(out["q_means_utt"], out["p_means_utt"])
         loss = loss + alpha * mse
     return loss, ce, kl, mse
+
+
+def relu_mask_cases(zs, tau=2e-6, max_bits=16, max_flips=3):
+    """The ReLU mask assignments two correct fp32 implementations may legitimately produce for the pre-activations
+    `zs` (list of tensors, one per ReLU site): a bit whose |z| < tau (z is BatchNorm output, O(1); two summation orders
+    of the convolution move it by a few 1e-7) can fall on either side of 0, every other bit is z > 0.  Returns
+    (lazy iterator over {site: mask} dicts, number of ambiguous bits): the natural assignment first, then every
+    assignment that flips 1, 2, .. max_flips of the ambiguous bits."""
+    import itertools
+    base = {i: (z > 0) for i, z in enumerate(zs)}
+    amb = [(i, int(j)) for i, z in enumerate(zs) for j in torch.nonzero(z.abs().flatten() < tau).flatten()]
+    if len(amb) > max_bits:
+        raise ValueError(f"{len(amb)} pre-activations within {tau} of zero: choose other test data")
+
+    def gen():
+        for nflip in range(min(len(amb), max_flips) + 1):
+            for which in itertools.combinations(range(len(amb)), nflip):
+                m = {i: v.clone() for i, v in base.items()}
+                for a in which:
+                    site, j = amb[a]
+                    m[site].view(-1)[j] = ~m[site].view(-1)[j]
+                yield m
+    return gen(), len(amb)
 
 
 def trainable_keys(state):

@@ -72,52 +72,70 @@ def test_g4_encoder_golden():
         close(o["audio_embeds_pooled"], g[f"c{ci}_eval_pooled"], 1e-4, 1e-4, what=f"c{ci} eval pooled")
 
 
-def cnn10_grad_errors(B, Tt, seed):
-    """forward max error and the relative-L2 gradient error of every parameter (HIP vs CPU autograd through the oracle)"""
-    full = O.closed_form_state(O.state_shapes(10))
-    g = torch.Generator().manual_seed(seed)
-    feats = torch.randn(B, Tt, 64, generator=g) * 1.5 + 0.3
-    R = torch.randn(B, Tt // 16, 512, generator=g)
-    # oracle (CPU autograd), recording its dropout masks
-    st = {k: v.clone() for k, v in full.items() if k.startswith("encoder.")}
-    keys = [k for k in O.trainable_keys(st)]
-    for k in keys:
-        st[k].requires_grad_(True)
-    rec = []
+def encoder_grads_vs_oracle(full, make, head, feats, R, lens, tol=2e-4, fwd_tol=(1e-4, 1e-5), flip_zone=1e-4):
+    """Gradients of every encoder parameter, HIP vs CPU autograd through the oracle, with NO tolerance for ReLU-boundary
+    flips.  The HIP forward reports the ReLU decisions its backward will use (encoder.relu_masks(), read from the saved
+    activations); they may differ from the oracle's z > 0 only where the oracle's pre-activation is within rounding
+    distance of zero (|z| < flip_zone: asserted, and the bits are counted); the oracle is then evaluated under exactly
+    those decisions and EVERY gradient tensor must agree to `tol` relative L2.
+    Returns (number of differing mask bits, largest |z| among them, worst relative L2)."""
+    def fresh():
+        st = {k: v.clone() for k, v in full.items() if k.startswith("encoder.")}
+        keys = list(O.trainable_keys(st))
+        for k in keys:
+            st[k].requires_grad_(True)
+        return st, keys
+    st, keys = fresh()
+    rec, probe = [], []
     torch.manual_seed(5)
-    o = O.cnn10_forward(st, feats, [Tt] * B, True, None, rec)
-    (o["audio_embeds"] * R).sum().backward()
-    enc = make_encoder(full)
+    with torch.no_grad():
+        o0 = O.cnn10_forward(st, feats, list(lens), True, None, rec, relu_probe=probe)
+    enc = make(full)
     enc.train()
-    enc.dropout_masks = rec
-    out = enc(feats.cuda(), [Tt] * B)
-    close(out["audio_embeds"], o["audio_embeds"], what="fwd")
+    enc.keep_saved = True
+    enc.dropout_masks = [m.clone() for m in rec]
+    out = enc(feats.cuda(), list(lens))
+    close(out["audio_embeds"], o0["audio_embeds"], *fwd_tol, what="fwd")
+    masks = [m.cpu() for m in enc.relu_masks()]
+    assert len(masks) == len(probe)
+    nflip, zmax = 0, 0.0
+    for m, z in zip(masks, probe):
+        d = m != (z > 0)
+        nflip += int(d.sum())
+        if bool(d.any()):
+            zmax = max(zmax, float(z[d].abs().max()))
+    assert zmax < flip_zone, f"{nflip} ReLU decisions differ from the oracle, one at |z| = {zmax:.2e}"
     (out["audio_embeds"] * R.cuda()).sum().backward()
     named = dict(enc.named_parameters())
-    errs = {}
+    st, keys = fresh()
+    o = O.cnn10_forward(st, feats, list(lens), True, [m.clone() for m in rec], None,
+                        relu_force={i: m for i, m in enumerate(masks)})
+    (o["audio_embeds"] * R).sum().backward()
+    worst, wk = 0.0, None
     for k in keys:
         kk = k[len("encoder."):]
-        if kk.startswith("embed_pooled"):
+        if kk.startswith(head):
             assert named[kk].grad is None and st[k].grad is None
             continue
         a, b = named[kk].grad.detach().cpu().double(), st[k].grad.double()
-        errs[kk] = float((a - b).pow(2).sum().sqrt() / max(float(b.pow(2).sum().sqrt()), 1e-12))
-    return errs
+        e = float((a - b).pow(2).sum().sqrt() / max(float(b.pow(2).sum().sqrt()), 1e-12))
+        if e > worst:
+            worst, wk = e, kk
+    assert worst <= tol, f"{wk}: relative L2 {worst:.2e} under the HIP path's own ReLU decisions ({nflip} differ from z > 0)"
+    return nflip, zmax, worst
 
 
 @pytest.mark.parametrize("B,Tt,seeds", [(2, 32, (1, 5, 6)), (3, 80, (3, 1, 8)), (2, 250, (1, 2, 4))])
 def test_encoder_backward_vs_oracle(B, Tt, seeds):
-    """Gradients of every encoder parameter.  Two fp32 summation orders (MFMA tiles vs the CPU library) can put a
-    pre-activation on different sides of 0 when it is within rounding distance of it; that ONE mask bit moves one
-    channel's BatchNorm statistics and, through them, every gradient below that layer by 0.1-1 % (tools/grad_sweep.py:
-    layers above the flip agree to 1e-5, exactly one channel of one layer differs, everything below moves).  Roughly
-    half of the seeds have such a flip at these sizes; an indexing error would move every seed by O(1).  So: flip-free
-    seeds must agree to 2e-4 in every tensor (at least one of the three must be flip-free), and no seed may be off by
-    more than a flip explains."""
-    runs = [cnn10_grad_errors(B, Tt, seed) for seed in seeds]
-    for errs in runs:
-        assert max(errs.values()) <= 0.1, max(errs.items(), key=lambda kv: kv[1])
-    assert min(max(e.values()) for e in runs) <= 2e-4, [max(e.values()) for e in runs]
+    """EVERY seed must match the oracle to 2e-4 in every tensor (see encoder_grads_vs_oracle for how pre-activations
+    that sit within rounding distance of the ReLU boundary are handled: read back and replayed, not tolerated)."""
+    full = O.closed_form_state(O.state_shapes(10))
+    for seed in seeds:
+        g = torch.Generator().manual_seed(seed)
+        feats = torch.randn(B, Tt, 64, generator=g) * 1.5 + 0.3
+        R = torch.randn(B, Tt // 16, 512, generator=g)
+        nflip, zmax, err = encoder_grads_vs_oracle(full, make_encoder, "embed_pooled", feats, R, [Tt] * B)
+        print(f"Cnn10 B={B} T={Tt} seed={seed}: {nflip} ReLU decisions differ (max |z| {zmax:.1e}), worst rel-L2 {err:.2e}")
 
 
 def test_encoder_philox_dropout_statistics():
@@ -177,51 +195,18 @@ def test_g12_cnn14_encoder_golden():
         close(o["audio_embeds_pooled"], g[f"c{ci}_eval_pooled"], 2e-4, 1e-4, what=f"c{ci} eval pooled")
 
 
-def cnn14_grad_errors(B, Tt, seed):
-    """relative-L2 gradient error of every parameter"""
-    full = cnn14_state()
-    g = torch.Generator().manual_seed(seed)
-    feats = torch.randn(B, Tt, 64, generator=g) * 1.5 + 0.3
-    R = torch.randn(B, Tt // 32, 2048, generator=g)
-    st = {k: v.clone() for k, v in full.items()}
-    keys = [k for k in O.trainable_keys(st)]
-    for k in keys:
-        st[k].requires_grad_(True)
-    rec = []
-    torch.manual_seed(5)
-    o = O.cnn10_forward(st, feats, [Tt] * B, True, None, rec)
-    (o["audio_embeds"] * R).sum().backward()
-    enc = make_cnn14(full)
-    enc.train()
-    enc.dropout_masks = rec
-    out = enc(feats.cuda(), [Tt] * B)
-    close(out["audio_embeds"], o["audio_embeds"], 5e-4, 1e-4, what="fwd")      # K up to 18432 per conv output
-    (out["audio_embeds"] * R.cuda()).sum().backward()
-    named = dict(enc.named_parameters())
-    errs = {}
-    for k in keys:
-        kk = k[len("encoder."):]
-        if kk.startswith("fc1"):
-            assert named[kk].grad is None and st[k].grad is None
-            continue
-        a, b = named[kk].grad.detach().cpu().double(), st[k].grad.double()
-        errs[kk] = float((a - b).pow(2).sum().sqrt() / max(float(b.pow(2).sum().sqrt()), 1e-12))
-        cos = float((a * b).sum() / max(float(a.pow(2).sum().sqrt() * b.pow(2).sum().sqrt()), 1e-30))
-        assert cos >= 0.995, (kk, cos)
-    return errs
-
-
 def test_cnn14_backward_vs_oracle():
-    """With twelve conv layers whose last four are batch-normalised over 32-128 values nearly every seed has a
-    ReLU-boundary flip somewhere (see test_encoder_backward_vs_oracle; tools/grad_sweep.py with SWEEP_ARCH=Cnn14_16k:
-    11 of 12 seeds between 0.5 % and 4 %, the flip-free one at 3e-5, and which seed is flip-free changes with any
-    change of a summation order).  So every gradient tensor must point the same way as the oracle's (cosine >= 0.995,
-    asserted per tensor) and be within what a flip explains (relative L2 <= 15 %), on three seeds; an indexing error
-    fails both by a wide margin.  The training-step golden g13 (tests/test_model_gpu.py) pins loss and gradient norm
-    against the reference itself."""
+    """Cnn14_16k, twelve conv layers, three seeds, every tensor to 5e-4 relative L2 under the HIP path's own ReLU
+    decisions (K up to 18432 per conv output and BatchNorm over 32-128 values in the last blocks: the rounding distance
+    is larger than in Cnn10, hence the wider flip zone)."""
+    full = cnn14_state()
     for seed in (9, 1, 6):
-        errs = cnn14_grad_errors(4, 128, seed)
-        assert max(errs.values()) <= 0.15, max(errs.items(), key=lambda kv: kv[1])
+        g = torch.Generator().manual_seed(seed)
+        feats = torch.randn(4, 128, 64, generator=g) * 1.5 + 0.3
+        R = torch.randn(4, 128 // 32, 2048, generator=g)
+        nflip, zmax, err = encoder_grads_vs_oracle(full, make_cnn14, "fc1", feats, R, [128] * 4, tol=5e-4,
+                                                   fwd_tol=(5e-4, 1e-4), flip_zone=1e-3)
+        print(f"Cnn14 seed={seed}: {nflip} ReLU decisions differ (max |z| {zmax:.1e}), worst rel-L2 {err:.2e}")
 
 
 @pytest.mark.parametrize("env", [dict(ACVAE_CONV_STRIP="3"), dict(ACVAE_CONV_STRIP="1", ACVAE_WGRAD_STRIP="0"),

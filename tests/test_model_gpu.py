@@ -61,6 +61,39 @@ def close_enc_grad(a, b, what=""):
         f"{what}: median {float(err.median()):.2e} max {float(err.max()):.2e} (ref max {mx:.2e}) rel-L2 {l2:.2e}"
 
 
+def grads_match_oracle(model, named, natural_grads, rec, oracle_grads_under, tol_enc=5e-4, flip_zone=1e-4):
+    """All parameter gradients of the HIP model against the oracle, with no tolerance for ReLU-boundary flips: the HIP
+    encoder reports the ReLU decisions its backward used (model.encoder.relu_masks(); keep_saved must be set before the
+    forward); they may differ from the oracle's only where its pre-activation is within rounding distance of zero
+    (asserted); the oracle is re-evaluated under exactly those decisions and every tensor must agree - encoder tensors
+    to `tol_enc` relative L2, text-side tensors to 2e-3 / 2e-4 x max.  Returns the oracle gradients that were matched."""
+    def check(ref_grads):
+        worst = (0.0, None)
+        for k, ref in ref_grads.items():
+            a = named[k].grad.detach().cpu().double(); b = ref.double()
+            if k.startswith("encoder."):
+                e = float((a - b).pow(2).sum().sqrt() / max(float(b.pow(2).sum().sqrt()), 1e-12)) / tol_enc
+            else:
+                lim = 2e-4 * max(float(b.abs().max()), 1e-3) + 2e-3 * b.abs()
+                e = float(((a - b).abs() / lim).max())
+            if e > worst[0]:
+                worst = (e, k)
+        return worst
+    assert set(k for k, p in named.items() if p.grad is not None) == set(natural_grads)
+    masks = [m.cpu() for m in model.encoder.relu_masks()]
+    nflip, zmax = 0, 0.0
+    for m, z in zip(masks, rec["relu_z"]):
+        d = m != (z > 0)
+        nflip += int(d.sum())
+        if bool(d.any()):
+            zmax = max(zmax, float(z[d].abs().max()))
+    assert zmax < flip_zone, f"{nflip} ReLU decisions differ from the oracle, one at |z| = {zmax:.2e}"
+    ref = natural_grads if nflip == 0 else oracle_grads_under({i: m for i, m in enumerate(masks)})
+    w = check(ref)
+    assert w[0] <= 1.0, f"{w[1]}: {w[0]:.2f} x tolerance under the HIP path's own ReLU decisions ({nflip} differ from z > 0)"
+    return ref
+
+
 def close_grad_of(name, a, ref, what):
     if name.startswith("encoder."):
         close_enc_grad(a, ref, what)
@@ -115,6 +148,7 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
     model = build_model(V, E, state, encoder)
     model.train()
     model.encoder.dropout_masks = masks
+    model.encoder.keep_saved = True
     model.noise = dict(eps_q=eps_q, eps_p=eps_p)
     random.seed(seed)
     out = patched(lambda: model(feats.cuda(), feat_lens.copy(), caps, cap_lens, ss_ratio=1.0, dis_ratio=dis))
@@ -132,13 +166,20 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
     # the global norm is dominated by the encoder gradients: one ReLU-boundary flip (close_enc_grad) moves it by a few 1e-4
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None))
     assert abs(float(gn) - float(g["grad_norm"])) <= gn_tol * float(g["grad_norm"]), (float(gn), float(g["grad_norm"]))
+    matched = None
+    if full_grads:
+        def under(force):
+            st2 = {k: v.clone() for k, v in state.items()}
+            n2 = dict(dropout=[m.clone() for m in masks], eps_q=eps_q, eps_p=eps_p, relu_force=force)
+            random.seed(seed)
+            return patched(lambda: O.OracleTrainer(st2, V).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis, noise=n2,
+                                                                apply_update=False))["grads"]
+        matched = grads_match_oracle(model, named, ores["grads"], rec, under)
     if tensors:
         for k in [k for k in g if k.startswith("grad_") and k != "grad_norm"]:
+            if matched is not None and matched is not ores["grads"] and k[5:].startswith("encoder."):
+                continue      # a rounding-ambiguous ReLU bit fell the other way than in the reference run: checked above
             close_grad_of(k[5:], named[k[5:]].grad, T(g[k]), k)
-    if full_grads:
-        for k, ref in ores["grads"].items():
-            close_grad_of(k, named[k].grad, ref, "oracle grad " + k)
-        assert set(k for k, p in named.items() if p.grad is not None) == set(ores["grads"])
 
 
 def test_g6_train_step_golden():
@@ -388,8 +429,6 @@ def test_single_step_modules_vs_oracle():
 def test_edge_shapes_vs_oracle(B, Tt, L, lens, flens):
     V, E = 44, 64
     state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
-    # seed chosen so that no pre-activation sits within rounding distance of a ReLU boundary: with this few pixels a
-    # single flipped mask bit moves a BatchNorm-bias gradient by ~1 % (seen on 2 of 8 seeds; not an indexing error)
     g = torch.Generator().manual_seed(B * 1000 + Tt + 1)
     feats = torch.randn(B, Tt, 64, generator=g)
     caps = torch.zeros(B, L)
@@ -405,6 +444,7 @@ def test_edge_shapes_vs_oracle(B, Tt, L, lens, flens):
     model = build_model(V, E, state)
     model.train()
     model.encoder.dropout_masks = rec["dropout"]
+    model.encoder.keep_saved = True
     model.noise = dict(eps_q=rec["eps_q"], eps_p=rec["eps_p"])
     random.seed(3)
     out = model(feats.cuda(), fl.copy(), caps, cl, ss_ratio=1.0, dis_ratio=0)
@@ -415,18 +455,12 @@ def test_edge_shapes_vs_oracle(B, Tt, L, lens, flens):
         close(out[k], ores["out"][k], 1e-4, 2e-5, what=k)
     loss.backward()
     named = dict(model.named_parameters())
-    # With this few pixels a pre-activation that sits within rounding distance of a ReLU boundary flips its mask bit
-    # between two fp32 summation orders and moves one layer's gradients by ~1 % (data dependent: seen on 2 of 8 seeds,
-    # always confined to one encoder layer).  Indexing errors give O(1) errors everywhere, so: every tensor within the
-    # usual tolerance, except at most 3 encoder tensors within 3 % of their max.
-    loose = []
-    for k, ref in ores["grads"].items():
-        err = float((named[k].grad.cpu().double() - ref.double()).abs().max())
-        mx = max(float(ref.abs().max()), 1e-3)
-        if err > 2e-3 * mx:
-            assert k.startswith("encoder.") and err <= 3e-2 * mx, (k, err, mx)
-            loose.append(k)
-    assert len(loose) <= 3, loose
+    def under(force):
+        st2 = {k: v.clone() for k, v in state.items()}
+        n2 = dict(dropout=[m.clone() for m in rec["dropout"]], eps_q=rec["eps_q"], eps_p=rec["eps_p"], relu_force=force)
+        random.seed(3)
+        return O.OracleTrainer(st2, V).step(feats, fl.copy(), caps, cl, 1.0, 0, noise=n2, apply_update=False)["grads"]
+    grads_match_oracle(model, named, ores["grads"], rec, under)
 
 
 def test_g6_trainstep_against_the_reference_adam_step():

@@ -82,6 +82,34 @@ def test_g4_encoder():
         close(o["audio_embeds"], g[f"c{ci}_eval_audio_embeds"]); close(o["audio_embeds_pooled"], g[f"c{ci}_eval_pooled"])
 
 
+def test_relu_mask_hooks_of_the_oracle():
+    """The test hooks used by the GPU encoder-gradient tests: probing reports one pre-activation per ReLU site, forcing
+    the natural masks reproduces F.relu bit for bit, flipping one listed bit changes the gradients."""
+    full = O.closed_form_state(O.state_shapes(10))
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(2, 32, 64, generator=g)
+
+    def run(force):
+        st = {k: v.clone() for k, v in full.items() if k.startswith("encoder.")}
+        for k in O.trainable_keys(st):
+            st[k].requires_grad_(True)
+        probe = []
+        torch.manual_seed(1)
+        o = O.cnn10_forward(st, feats, [32, 32], True, None, None, relu_probe=probe, relu_force=force)
+        o["audio_embeds"].square().sum().backward()
+        return o["audio_embeds"].detach(), st["encoder.conv_block1.conv1.weight"].grad.clone(), probe
+
+    y0, g0, probe = run(None)
+    assert len(probe) == 8 and probe[0].shape == (2, 64, 32, 64)
+    cases, nbits = O.relu_mask_cases(probe, tau=1e-5, max_flips=1)
+    cases = list(cases)
+    assert nbits >= 1 and len(cases) == 1 + nbits           # natural + one assignment per single flipped bit
+    y1, g1, _ = run(cases[0])
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)
+    _, g2, _ = run(cases[1])
+    assert not torch.equal(g0, g2)
+
+
 def test_g5_rnn():
     g = load_golden("g5_rnn")
     N, I, H, V, E = (int(x) for x in g["dims"])

@@ -11,6 +11,7 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
+bf16 = "bf16" in sys.argv[3:]
 dst = os.path.join(out, "summary")
 os.makedirs(dst, exist_ok=True)
 
@@ -52,9 +53,15 @@ for k in ("conv_igemm", "conv_wgrad"):
     res[k] = {"dispatches_averaged": nf, "FETCH_SIZE_KB_avg_raw": f, "WRITE_SIZE_KB_avg": w,
               "fetch_bytes_per_launch": 2 * f * 1024, "write_bytes_per_launch": w * 1024,
               "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
-res["kernel"] = "conv_igemm3_kernel<128|64> (conv3x3 implicit GEMM with horizontal-tap reuse, forward + data gradient)"
+res["kernel"] = ("conv_igemm_bf16_kernel<128|64> (bf16 storage, v_mfma_f32_32x32x16_bf16)" if bf16 else
+                 "conv_igemm3_kernel<128|64> (conv3x3 implicit GEMM with horizontal-tap reuse, forward + data gradient)")
 res["hbm_bytes_per_launch"] = res["conv_igemm"]["hbm_bytes_per_launch"]
-res["algorithmic_bytes_per_launch"] = ("one read of the conv input + one write of its output + the weights, averaged "
-                                       "over the 14 launches of a step: ~0.29 GB")
-json.dump(res, open(os.path.join(dst, "traffic_conv_igemm.json"), "w"), indent=1)
+# one read of the conv input + one write of its output + the weights, over the 14 launches of a step at B=32, T=1000
+# (7 forward convolutions + 7 data gradients, every layer but the Cin = 1 one): 5.346 GB fp32, 2.673 GB bf16
+res["algorithmic_bytes_per_launch"] = (2.672934912e9 if bf16 else 5.345869824e9) / 14
+res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+res["fetch_over_algorithmic_reads"] = res["conv_igemm"]["fetch_bytes_per_launch"] / (res["algorithmic_bytes_per_launch"] / 2)
+json.dump(res, open(os.path.join(dst, f"{tag}_traffic_conv_igemm.json"), "w"), indent=1)
+if not bf16:
+    json.dump(res, open(os.path.join(dst, "traffic_conv_igemm.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
