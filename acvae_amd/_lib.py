@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "acvae_hip.h")
-LIB_PATH = os.path.join(_HERE, "libacvae_hip.so")
+LIB_PATH = os.environ.get("ACVAE_DEV_LIB") or os.path.join(_HERE, "libacvae_hip.so")   # dev hook: A/B builds (tools/)
 
 _CT = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
        "uint64_t": ctypes.c_uint64}

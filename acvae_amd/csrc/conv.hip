@@ -18,6 +18,10 @@
 #include "conv.h"
 #include "prof.h"
 
+#ifndef ACVAE_FRAG_PREFETCH
+#define ACVAE_FRAG_PREFETCH 0
+#endif
+
 namespace {
 using namespace mfma;
 
@@ -410,6 +414,46 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
         const float* As = Ag + dxi * (ADMA ? BK : LDS_LD);   // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
         const int asw = (lh ^ ((li + dxi) & 7)) << 2;       // ADMA: swizzled chunk of this lane's first fragment
         const float* Bs = sm.b[(grp * 3 + dxi) & 1] + (wn * (BN / 2) + li) * (BDMA ? BK : LDS_LD) + (BDMA ? 0 : 4 * lh);
+#if ACVAE_FRAG_PREFETCH
+        // Fragments of 8-channel group g + 1 are read from LDS BEFORE the 16 MFMAs of group g are issued (two register
+        // sets): left to itself the compiler reads them just in time, and the matrix pipe then drains for the LDS round
+        // trip at every group boundary (ds_read ... s_waitcnt lgkmcnt ... v_mfma: seen in the ISA of round 1's kernel).
+        float4 afq[2][2], bfq[2][NTN];
+        auto load_frags = [&](int g, float4 (&af)[2], float4 (&bf)[NTN]) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            af[i] = ADMA ? *reinterpret_cast<const float4*>(As + i * 32 * BK + ((g << 3) ^ asw))
+                         : *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+          for (int j = 0; j < NTN; ++j)
+            bf[j] = BDMA ? *reinterpret_cast<const float4*>(Bs + j * 32 * BK + (((g * 2) ^ bsw) << 2))
+                         : *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
+        };
+        load_frags(0, afq[0], bfq[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) load_frags(g + 1, afq[(g + 1) & 1], bfq[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);        // the reads above stay above the MFMAs below
+          float4 af[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            af[i] = afq[g & 1][i];
+            if (dxi == 0 && !okl[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dxi == 2 && !okr[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ADMA && !vok[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          const float4 (&bf)[NTN] = bfq[g & 1];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           float4 af[2], bf[NTN];
@@ -435,6 +479,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
             }
         }
+#endif
         __syncthreads();
       }
     }

@@ -8,7 +8,8 @@ from acvae_amd.encoder import Cnn10, Cnn14_16k
 B, T = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 arch = sys.argv[4] if len(sys.argv) > 4 else "Cnn10"
-enc = (Cnn10(64, 512) if arch == "Cnn10" else Cnn14_16k(64, 2048)).cuda().train()
+dtype = sys.argv[5] if len(sys.argv) > 5 else "f32"
+enc = (Cnn10(64, 512, compute_dtype=dtype) if arch == "Cnn10" else Cnn14_16k(64, 2048, compute_dtype=dtype)).cuda().train()
 x = torch.randn(B, T, 64, device="cuda")
 R = torch.randn(B, T // enc.TIME_DIV, enc.OUT_CHANNELS, device="cuda")
 def step():

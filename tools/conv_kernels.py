@@ -12,5 +12,8 @@ for i, r in enumerate(conv[-per_iter * (n_iter - 2):]):   # skip warm-up iterati
 for i in range(per_iter):
     d = sorted(x for x, _ in seqs[i]); r = seqs[i][0][1]
     name = "igemm" if "igemm" in r["Kernel_Name"] else "wgr192" if "wgrad192" in r["Kernel_Name"] else "wgrad"
-    tmpl = r["Kernel_Name"].split("<")[1].split(">")[0]
+    kn = r["Kernel_Name"]
+    tmpl = kn.split("<")[1].split(">")[0] if "<" in kn else ("bf16" if "bf16" in kn else "")
+    if "bf16" in kn:
+        name += "16"
     print("%2d %-6s<%-8s> grid %8sx%3sx%4s  median %8.1f us" % (i, name, tmpl, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], d[len(d) // 2] / 1e3))
