@@ -363,7 +363,7 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
                                   dis_flags_host, logits, outputs, seqs, sampled_logprobs, attn_w, p_means, p_logs, p_z,
                                   p_means_utt, h_final, hp_final, cp_final, saved_v, saved_bytes, scratch_v,
                                   scratch_bytes, N, Tc, S, E, H, A, V, Eenc, start_idx, end_idx, stream, aux_stream,
-                                  ACVAE_SAMPLE_GREEDY, 1.f, nullptr);
+                                  ACVAE_SAMPLE_GREEDY, 1.f, nullptr, nullptr, 0.f);
 }
 
 extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, const int64_t* mem_lens,
@@ -374,7 +374,9 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
                                         float* h_final, float* hp_final, float* cp_final, void* saved_v,
                                         int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S,
                                         int E, int H, int A, int V, int Eenc, int start_idx, int end_idx, void* stream,
-                                        void* aux_stream, int sample_method, float temp, const float* sample_noise) {
+                                        void* aux_stream, int sample_method, float temp, const float* sample_noise,
+                                        const uint8_t* emb_keep, float emb_drop_p) {
+  if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p < 1.f)) return ACVAE_EINVAL;
   if (sample_method != ACVAE_SAMPLE_GREEDY &&
       ((sample_method != ACVAE_SAMPLE_GUMBEL && sample_method != ACVAE_SAMPLE_MULTINOMIAL) || !sample_noise ||
        !(temp > 0.f)))
@@ -478,6 +480,9 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
     const int M = rows_of(cnt);
     ACVAE_TRY(acvae::embed_gather(words + t0, cnt == Tc ? 1 : Tc, P(TP_DEC_EMB), V, rnn_d + (long)t0 * 3 * E,
                                   ldof(cnt, 3 * E), M, E, st));
+    if (emb_keep)          // the decoder's word-embedding dropout (models/decoder.py:33,184), mask [Tc][N][E]
+      ACVAE_TRY(acvae::dropout_rows(rnn_d + (long)t0 * 3 * E, ld3E, 3 * E, emb_keep + (long)t0 * N * E, E, (long)N * E,
+                                    1.f / (1.f - emb_drop_p), N, cnt, E, st));
     // z: posterior sample unless this step drew the prior (vae_model.py:800-808); one copy when no step did
     if (cnt == Tc && train && !prior_feeds_decoder) {
       ACVAE_TRY(acvae::copy_rows(rnn_d + 2 * E, 3 * E, q_z, E, R, E, st));
@@ -591,7 +596,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
                                 const float* d_p_means, const float* d_p_logs, const float* d_p_z,
                                 const float* d_p_means_utt, float* d_mem_in, float* d_q_z, void* saved_v,
                                 int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S, int E,
-                                int H, int A, int V, int Eenc, void* stream, void* aux_stream) {
+                                int H, int A, int V, int Eenc, void* stream, void* aux_stream, const uint8_t* emb_keep,
+                                float emb_drop_p) {
+  if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p < 1.f)) return ACVAE_EINVAL;
   DecLayout L;
   ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
   if (!params || !grads || !mem_in || !mem_lens || !lens1 || !eps_p || !dis_flags_host || !outputs || !attn_w ||
@@ -738,6 +745,8 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(acvae::colsum2(dvpart, N, A, dp, G(TP_DEC_ATT_V), nullptr, 0, c));
     // d(rnn_input) for the embedding and z columns
     ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, c));                    // d emb
+    if (emb_keep)          // back through the word-embedding dropout
+      ACVAE_TRY(acvae::dropout_rows(drnn, (long)Tc * E, E, emb_keep, E, (long)N * E, 1.f / (1.f - emb_drop_p), N, Tc, E, c));
     ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, c));  // d z
     ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, c));
     ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, c));

@@ -11,6 +11,8 @@ int embed_gather(const int64_t* words, long w_stride, const float* table, int V,
                  int E, hipStream_t st);
 int embed_scatter(const int64_t* words_contig, const float* d, long ld_d, float* dtable, int V, int rows, int E,
                   hipStream_t st);
+int dropout_rows(float* x, long ld_n, long ld_t, const uint8_t* keep, long k_sn, long k_st, float scale, int N, int cnt,
+                 int E, hipStream_t st);
 int gather_words(const int64_t* src, long s_sn, long s_st, int64_t* dst, int N, int T, hipStream_t st);
 int gru_fwd(const float* gi, long ld_gi, const float* gh, long ld_gh, const float* hp, long ld_hp, float* ho,
             long ld_ho, float* oseq, long ld_os, float* save, long ld_sv, float* hps, long ld_hps, const int64_t* lens,

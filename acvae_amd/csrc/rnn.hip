@@ -52,6 +52,19 @@ __global__ void embed_gather_kernel(const int64_t* __restrict__ words, long w_st
     out[r * ld_out + e] = table[w * E + e];
   }
 }
+// nn.Dropout on rows (n, t), t < cnt: x *= keep ? 1/(1-p) : 0   (models/decoder.py:33,184: the decoder's word-embedding
+// dropout; the keep mask is drawn by the host on the CPU generator in the reference's call order)
+__global__ void dropout_rows_kernel(float* __restrict__ x, long ld_n, long ld_t, const uint8_t* __restrict__ keep,
+                                    long k_sn, long k_st, float scale, int N, int cnt, int E) {
+  const long total = (long)N * cnt * E;
+  for (long i = blockIdx.x * (long)TH + threadIdx.x; i < total; i += (long)gridDim.x * TH) {
+    const int e = (int)(i % E);
+    const long r = i / E;
+    const int t = (int)(r % cnt), n = (int)(r / cnt);
+    float* p = x + n * ld_n + t * ld_t + e;
+    *p = keep[n * k_sn + t * k_st + e] ? *p * scale : 0.f;
+  }
+}
 // dTable[w] += sum over rows r with words[r]==w of d[r] — one workgroup per row, the FIRST occurrence of a
 // word sums all its duplicates in row order: deterministic, no atomics.  dTable must be zeroed by the caller.
 __global__ void embed_scatter_kernel(const int64_t* __restrict__ words, const float* __restrict__ d, long ld_d,
@@ -290,6 +303,11 @@ int embed_scatter(const int64_t* words_contig, const float* d, long ld_d, float*
                   hipStream_t st) {
   hipLaunchKernelGGL(embed_scatter_kernel, dim3(rows), dim3(TH), (size_t)((rows + 31) / 32 + 2) * sizeof(unsigned), st,
                      words_contig, d, ld_d, dtable, V, rows, E);
+  ACVAE_LAUNCH_CHECK(); return ACVAE_OK;
+}
+int dropout_rows(float* x, long ld_n, long ld_t, const uint8_t* keep, long k_sn, long k_st, float scale, int N, int cnt,
+                 int E, hipStream_t st) {
+  LAUNCH(dropout_rows_kernel, grid1((long)N * cnt * E), x, ld_n, ld_t, keep, k_sn, k_st, scale, N, cnt, E);
   ACVAE_LAUNCH_CHECK(); return ACVAE_OK;
 }
 int gather_words(const int64_t* src, long s_sn, long s_st, int64_t* dst, int N, int T, hipStream_t st) {

@@ -59,8 +59,8 @@ class VAERNNBahdanauAttnDecoder(RNNDecoder):
         super().__init__(vocab_size, enc_mem_size * 2, **kwargs)
         if kwargs.get("rnn_type", "GRU") != "GRU" or kwargs.get("num_layers", 1) != 1 or kwargs.get("bidirectional", False):
             raise NotImplementedError("the HIP path implements the 1-layer unidirectional GRU decoder")
-        if kwargs.get("dropout", 0.0) != 0.0:
-            raise NotImplementedError("word-embedding dropout > 0 is not on the HIP path (reference default 0.0)")
+        # `dropout` (default 0.0): nn.Dropout on the word embedding (:33,184); applied inside the fused decode loop in
+        # training mode (Hybrid_VAEModel draws the keep masks on the CPU generator in the reference's call order)
         attn_size = kwargs.get("attn_size", self.model.hidden_size)
         self.attn = Seq2SeqAttention(enc_mem_size, self.model.hidden_size, attn_size)
         self.mem_size = enc_mem_size

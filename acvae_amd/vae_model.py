@@ -51,12 +51,15 @@ class _DecodeFn(torch.autograd.Function):
         ss_arr = IntArr(*[int(bool(x)) for x in ss_flags]) if train else None
         dis_arr = IntArr(*[int(bool(x)) for x in dis_flags]) if train else IntArr(*([1] * Tc))
         mem = mem.contiguous()
-        method, temp, noise = sampling if sampling is not None else (0, 1.0, None)
+        method, temp, noise = sampling["sample"] if sampling and sampling.get("sample") else (0, 1.0, None)
+        keep, drop_p = sampling["emb_keep"] if sampling and sampling.get("emb_keep") else (None, 0.0)
         _lib.call("acvae_decode_fwd_sampled", ptr_table(params), mem, mem_lens_d, caps_d,
                   caps_d.stride(0) if train else 0, lens1_d, q_z, eps_p, ss_arr, dis_arr, logits, outputs, seqs, slp,
                   attw, pm, pl, pz, putt, hfin, hp, cp, saved, saved_b, scratch, scratch_b, *dims, model.start_idx,
-                  model.end_idx, _lib.current_stream(), model._aux_stream(), int(method), float(temp), noise)
+                  model.end_idx, _lib.current_stream(), model._aux_stream(), int(method), float(temp), noise, keep,
+                  float(drop_p))
         ctx.model, ctx.saved, ctx.dims, ctx.dis_arr = model, saved, dims, dis_arr
+        ctx.emb_keep, ctx.emb_p = keep, float(drop_p)
         # outputs kept as plain ctx attributes would form tensor -> grad_fn -> ctx -> tensor cycles that are never collected
         ctx.save_for_backward(mem, mem_lens_d, lens1_d, eps_p, outputs, attw, pl)
         ctx.mark_non_differentiable(seqs, slp, attw, hfin, hp, cp)
@@ -86,7 +89,7 @@ class _DecodeFn(torch.autograd.Function):
         main, aux = _lib.current_stream(), model._aux_stream()
         _lib.call("acvae_decode_bwd", ptr_table(params), ptr_table(grads), mem, mem_lens_d, lens1_d, eps_p, ctx.dis_arr,
                   outputs, attw, pl, *ups, d_mem, d_qz, ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, main,
-                  aux)
+                  aux, ctx.emb_keep, ctx.emb_p)
         defers = bool(_lib.lib().acvae_decode_bwd_defers(ctx.dis_arr, Tc, main, aux))   # a yes / no answer, not a status
         if model._grad_ready_cb is not None:
             ev = torch.cuda.Event()
@@ -401,6 +404,12 @@ class Hybrid_VAEModel(CaptionModel):
         sample_noise = None
         if code and (replay is None or replay.get("sample_noise") is None):
             sample_noise = torch.empty(Tc, N, V)
+        # the decoder's word-embedding nn.Dropout (models/decoder.py:33,184): one [N,1,E] Bernoulli draw per step, made
+        # by decoder.forward, i.e. after the step's prior noise and disentangle coin and before sample_next_word
+        drop_p = float(self.decoder.dropoutlayer.p) if (train and self.training) else 0.0
+        dec_keep = None
+        if drop_p > 0.0 and (replay is None or replay.get("dec_keep") is None):
+            dec_keep = torch.empty(Tc, N, E, dtype=torch.bool)
 
         def host_draws(eps):            # eps: [Tc, N, E] staging slot (None when the noise is replayed)
             for t in range(Tc):
@@ -410,6 +419,8 @@ class Hybrid_VAEModel(CaptionModel):
                     torch.randn(N, E, out=eps[t])                                    # text_encoder.py:259 (CPU, F9)
                 if train:
                     dis_flags.append(bool(dis_ratio != 0 and torch.rand(1) <= dis_ratio))   # :802-806
+                if dec_keep is not None:
+                    dec_keep[t].bernoulli_(1 - drop_p)
                 if sample_noise is not None:
                     if code == 1:
                         U = torch.rand(N, V)                                          # word_model.py:189-191
@@ -426,11 +437,15 @@ class Hybrid_VAEModel(CaptionModel):
         if train:
             caps_d = _lib.h2d(caps, dev, torch.long).contiguous()
             lens1_d = _lib.h2d(lens1, dev, torch.long)
-        sampling = None
+        sampling = {}
         if code:
             if sample_noise is None:
                 sample_noise = torch.as_tensor(replay["sample_noise"])[:Tc]
-            sampling = (code, temp, _lib.h2d(sample_noise, dev, torch.float32).contiguous())
+            sampling["sample"] = (code, temp, _lib.h2d(sample_noise, dev, torch.float32).contiguous())
+        if drop_p > 0.0:
+            if dec_keep is None:
+                dec_keep = torch.as_tensor(replay["dec_keep"])[:Tc]
+            sampling["emb_keep"] = (_lib.h2d(dec_keep.to(torch.uint8), dev).contiguous(), drop_p)
         return {"Tc": Tc, "ss_flags": ss_flags, "dis_flags": dis_flags, "eps_p": eps_p, "caps_d": caps_d,
                 "lens1_d": lens1_d, "sampling": sampling}
 

@@ -317,7 +317,10 @@ int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64
 /* The same with sample_next_word's method (models/word_model.py:173-207) chosen by the caller: ACVAE_SAMPLE_GREEDY
  * (= acvae_decode_fwd), or GUMBEL / MULTINOMIAL with `temp` and `sample_noise` [Tc,N,V] (see acvae_sample_next_word; the
  * per-step draws of the reference in step order).  seqs / sampled_logprobs then hold the sampled words; with
- * scheduled sampling or in inference the sampled word of step t-1 is the input of step t (vae_model.py:829-832). */
+ * scheduled sampling or in inference the sampled word of step t-1 is the input of step t (vae_model.py:829-832).
+ * emb_keep (may be NULL): keep mask uint8 [Tc,N,E] of the decoder's word-embedding nn.Dropout(emb_drop_p)
+ * (models/decoder.py:33,184), drawn by the host on the CPU generator after each step's prior noise; kept rows are
+ * scaled by 1/(1-p).  The same mask and p go to acvae_decode_bwd. */
 int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, const int64_t* mem_lens,
                              const int64_t* caps, int64_t ld_caps, const int64_t* lens1, const float* q_z,
                              const float* eps_p, const int* ss_flags_host, const int* dis_flags_host, float* logits,
@@ -325,7 +328,8 @@ int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, con
                              float* p_logs, float* p_z, float* p_means_utt, float* h_final, float* hp_final,
                              float* cp_final, void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes,
                              int N, int Tc, int S, int E, int H, int A, int V, int Eenc, int start_idx, int end_idx,
-                             void* stream, void* aux_stream, int sample_method, float temp, const float* sample_noise);
+                             void* stream, void* aux_stream, int sample_method, float temp, const float* sample_noise,
+                             const uint8_t* emb_keep, float emb_drop_p);
 /* Backward for upstream gradients of logits / outputs / p_means / p_logs / p_z / p_means_utt (each may be
  * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E].
  * Stream contract: d_mem_in is ordered on `stream` when the call returns.  When acvae_decode_bwd_defers() says 1 for the
@@ -342,7 +346,7 @@ int acvae_decode_bwd(const void* const* params, void* const* grads, const float*
                      const float* d_p_means, const float* d_p_logs, const float* d_p_z, const float* d_p_means_utt,
                      float* d_mem_in, float* d_q_z, void* saved, int64_t saved_bytes, void* scratch,
                      int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc, void* stream,
-                     void* aux_stream);
+                     void* aux_stream, const uint8_t* emb_keep, float emb_drop_p);
 /* float caption ids (collate pads with torch.zeros -> float32, caption_dataset.py:293) -> int64 */
 int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, void* stream);
 

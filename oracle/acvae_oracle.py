@@ -337,8 +337,17 @@ def prior_step(state, word, enc_mem, hc, last_z, lens, eps=None, prefix="pnet"):
     return {"mean": mean, "log": log, "hiddens_state": (h, c), "z": z, "_eps": eps}
 
 
-def decoder_step(state, word, h, enc_mem, enc_mem_lens, z, prefix="decoder"):
-    emb = F.embedding(word.long(), state[prefix + ".word_embeddings.weight"]).squeeze(1)   # dropout p=0 (decoder.py:33)
+def decoder_step(state, word, h, enc_mem, enc_mem_lens, z, prefix="decoder", dropout_p=0.0, training=False,
+                 keep=None, record=None):
+    """VAERNNBahdanauAttnDecoder.forward, models/decoder.py:175-203.  `dropout_p` / `training`: the word-embedding
+    nn.Dropout of :33,184 (default 0.0); `keep` replays its mask [N,E], `record` (a list) receives the drawn one."""
+    emb = F.embedding(word.long(), state[prefix + ".word_embeddings.weight"]).squeeze(1)
+    if training and dropout_p > 0.0:
+        if keep is None:
+            keep = torch.empty(emb.shape, dtype=torch.bool).bernoulli_(1 - dropout_p)
+        if record is not None:
+            record.append(keep.clone())
+        emb = emb * keep * (1.0 / (1.0 - dropout_p))
     ctx, w = seq2seq_attention(state, prefix + ".attn", h, enc_mem, enc_mem_lens)
     rnn_input = torch.cat((emb, ctx, z), dim=-1)
     h2 = gru_cell(rnn_input, h, state[prefix + ".model.weight_ih_l0"], state[prefix + ".model.weight_hh_l0"],
@@ -375,7 +384,7 @@ def sample_next_word(logits, method="greedy", temp=1, noise=None):
 
 def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_ratio=1.0, dis_ratio=0,
                    training=True, method="greedy", temp=1, max_length=MAX_LENGTH, noise=None, record=None,
-                   mutate_lens=True):
+                   mutate_lens=True, dec_dropout=0.0):
     """4-input form = train_forward, 2-input form = inference_forward(greedy).
     `noise` (optional): dict(dropout=[masks...], eps_q=[N,Tc,E], eps_p=[Tc,N,E]) to replay; else drawn
     from torch's CPU generator in the reference's call order.  `record` receives the drawn noise."""
@@ -400,7 +409,7 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         steps = max_length
     seqs = torch.full((N, steps), END_IDX, dtype=torch.long)                  # prepare_output :762-790
     logits, outputs, slp, attw = [], [], [], []
-    p_means, p_logs, p_z, eps_p, sample_noise = [], [], [], [], []
+    p_means, p_logs, p_z, eps_p, sample_noise, dec_keep = [], [], [], [], [], []
     h = mem.new_zeros(N, H)
     hc = (mem.new_zeros(N, E), mem.new_zeros(N, E))                           # PriorRNN.init_hidden :240-245
     last_z = mem.new_zeros(N, E)
@@ -421,7 +430,9 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
                 z = pr["z"]
         else:
             z = pr["z"]
-        d = decoder_step(state, word.unsqueeze(1), h, mem, mem_lens, z)
+        dk = None if noise is None or noise.get("dec_keep") is None else noise["dec_keep"][t]
+        d = decoder_step(state, word.unsqueeze(1), h, mem, mem_lens, z, dropout_p=dec_dropout, training=training,
+                         keep=dk, record=dec_keep)
         sn = None if noise is None or noise.get("sample_noise") is None else noise["sample_noise"][t]
         w_t, lp, sn_used = sample_next_word(d["logits"], method, temp, sn)     # word_model.py:173-207
         if sn_used is not None:
@@ -454,6 +465,7 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         record["eps_q"] = q["_eps"] if train else None
         record["eps_p"] = torch.stack(eps_p, 0)
         record["relu_z"] = relu_probe
+        record["dec_keep"] = torch.stack(dec_keep, 0) if dec_keep else None
         record["sample_noise"] = torch.stack(sample_noise, 0) if sample_noise else None
     return out
 
@@ -659,8 +671,9 @@ class OracleTrainer:
     zero_grad, forward, loss, backward, clip_grad_norm_(max_grad_norm), Adam.step."""
 
     def __init__(self, state, vocab, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 smoothing=0.1, kl_weight=0.5, alpha=1.0):
+                 smoothing=0.1, kl_weight=0.5, alpha=1.0, dec_dropout=0.0):
         self.state, self.vocab = state, vocab
+        self.dec_dropout = dec_dropout
         self.keys = trainable_keys(state)
         for k in self.keys:
             state[k].requires_grad_(True)
@@ -676,7 +689,8 @@ class OracleTrainer:
         for k in self.keys:
             st[k].grad = None
         out = hybrid_forward(st, feats, np.array(feat_lens).copy(), caps, cap_lens, ss_ratio=ss_ratio,
-                             dis_ratio=dis_ratio, training=True, noise=noise, record=record)
+                             dis_ratio=dis_ratio, training=True, noise=noise, record=record,
+                             dec_dropout=self.dec_dropout)
         loss, ce, kl, mse = train_loss(out, caps, cap_lens, self.vocab, self.smoothing, self.kl_weight, self.alpha)
         loss.backward()
         grads = {k: st[k].grad for k in self.keys if st[k].grad is not None}

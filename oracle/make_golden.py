@@ -202,10 +202,11 @@ OUT_KEYS = ("logits", "outputs", "seqs", "sampled_logprobs", "attn_weights", "p_
             "q_means", "q_logs", "q_z", "q_means_utt", "p_means_utt")
 
 
-def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True, keep_noise=True, encoder="Cnn10"):
+def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True, keep_noise=True, encoder="Cnn10",
+                  dec_dropout=0.0):
     shapes = O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder)
     state = O.closed_form_state(shapes)
-    model = ref_shim.build_reference_model(ref, V, E, E, encoder=encoder)
+    model = ref_shim.build_reference_model(ref, V, E, E, encoder=encoder, dec_dropout=dec_dropout)
     load_state_into(model, state)
     model.train()
     feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, T, V, L, seed=seed, ragged=ragged)
@@ -215,9 +216,10 @@ def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True
     ostate = {k: v.clone() for k, v in state.items()}
     rec = {}
     torch.manual_seed(seed); random.seed(seed)
-    res = O.OracleTrainer(ostate, V).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis, record=rec)
+    res = O.OracleTrainer(ostate, V, dec_dropout=dec_dropout).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis,
+                                                                   record=rec)
     assert abs(float(res["loss"]) - float(rl["loss"])) < 1e-4 * max(1, abs(float(rl["loss"]))), (res["loss"], rl["loss"])
-    d = dict(dims=np.array([B, T, V, E, L]), seed=np.array(seed), ragged=np.array(int(ragged)), dis_ratio=np.array(float(dis)),
+    d = dict(dims=np.array([B, T, V, E, L]), dec_dropout=np.array(float(dec_dropout)), seed=np.array(seed), ragged=np.array(int(ragged)), dis_ratio=np.array(float(dis)),
              feat_lens=feat_lens, cap_lens=cap_lens, caps=caps,
              loss=rl["loss"], ce=rl["ce"], kl=rl["kl"], mse=rl["mse"], grad_norm=rl["grad_norm"])
     if keep_tensors:
@@ -230,6 +232,8 @@ def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True
             d["post_" + k] = sd[k]
     if keep_noise:
         d["noise_eps_q"] = rec["eps_q"]; d["noise_eps_p"] = rec["eps_p"]
+        if rec.get("dec_keep") is not None:
+            d["noise_dec_keep"] = rec["dec_keep"]
         d.update(pack_masks(rec["dropout"]))
     save(name, **d)
     return model, state, feats, feat_lens
@@ -463,6 +467,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "sampling":
         g14_sampling(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "decdrop":
+        train_fixture(ref, "g15_train_step_decdrop", 3, 48, 40, 64, 7, True, 0, seed=46, dec_dropout=0.3)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cnn14":
         g12_cnn14(ref)
         train_fixture(ref, "g13_train_step_cnn14", 2, 64, 40, 64, 6, True, 0, seed=36, keep_tensors=False,
@@ -476,6 +483,7 @@ def main():
     train_fixture(ref, "g6_train_step", 4, 64, 50, 64, 8, True, 0, seed=6)
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)
     train_fixture(ref, "g6c_train_step_e512", 2, 64, 300, 512, 7, False, 0, seed=26, keep_tensors=False)
+    train_fixture(ref, "g15_train_step_decdrop", 3, 48, 40, 64, 7, True, 0, seed=46, dec_dropout=0.3)
     g7_decode(ref)
     g14_sampling(ref)
     g9_beam(ref)

@@ -87,12 +87,12 @@ def load_losses():
     return loss
 
 
-def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None, encoder="Cnn10"):
+def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None, encoder="Cnn10", dec_dropout=0.0):
     """Hybrid_VAEModel(Cnn10, VAERNNBahdanauAttnDecoder, PosteriorRNN_hybrid, PriorRNN): the
     self-consistent combination of SURVEY F6, built the way runners/pytorch_runner_vae.py:33-73 does."""
     encoder = ref.encoder.Cnn10(64, 512) if encoder == "Cnn10" else ref.encoder.Cnn14_16k(64, 2048)
     decoder = ref.decoder.VAERNNBahdanauAttnDecoder(
-        vocab_size=vocab, enc_mem_size=embed, embed_size=embed, hidden_size=hidden, dropout=0.0,
+        vocab_size=vocab, enc_mem_size=embed, embed_size=embed, hidden_size=hidden, dropout=dec_dropout,
         num_layers=1, rnn_type="GRU", attn_size=hidden)
     model = ref.vae_model.Hybrid_VAEModel(
         encoder, decoder, posterior_model="PosteriorRNN_hybrid",

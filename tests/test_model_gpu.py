@@ -28,9 +28,9 @@ def close(a, b, rtol=1e-4, atol=1e-5, what=""):
                            f"{int((~ok).sum())}/{ok.numel()} out of tolerance"
 
 
-def build_model(V, E, state=None, encoder="Cnn10"):
+def build_model(V, E, state=None, encoder="Cnn10", dec_dropout=0.0):
     enc = Cnn10(64, 512) if encoder == "Cnn10" else Cnn14_16k(64, 2048)
-    dec = VAERNNBahdanauAttnDecoder(vocab_size=V, enc_mem_size=E, embed_size=E, hidden_size=E, dropout=0.0,
+    dec = VAERNNBahdanauAttnDecoder(vocab_size=V, enc_mem_size=E, embed_size=E, hidden_size=E, dropout=dec_dropout,
                                     num_layers=1, rnn_type="GRU", attn_size=E)
     m = Hybrid_VAEModel(enc, dec, posterior_model="PosteriorRNN_hybrid", posterior_args={"hidden_size": E, "dropout": 0.0},
                         prior_model="PriorRNN", prior_args={"hidden_size": E, "dropout": 0.0})
@@ -105,6 +105,8 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
     g = load_golden(name)
     B, Tt, V, E, L = (int(x) for x in g["dims"])
     seed = int(g["seed"])
+    dec_p = float(g["dec_dropout"]) if "dec_dropout" in g else 0.0
+    dec_keep = T(g["noise_dec_keep"]) if "noise_dec_keep" in g else None
     state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder))
     feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, Tt, V, L, seed=seed, ragged=bool(int(g["ragged"])))
     dis = float(g["dis_ratio"])
@@ -140,16 +142,17 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
     ostate = {k: v.clone() for k, v in state.items()}
     rec = {}
     torch.manual_seed(seed); random.seed(seed)
-    noise = None if masks is None else dict(dropout=list(masks), eps_q=eps_q, eps_p=eps_p)
-    ores = patched(lambda: O.OracleTrainer(ostate, V).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis,
-                                                           noise=noise, record=rec, apply_update=False))
+    noise = None if masks is None else dict(dropout=list(masks), eps_q=eps_q, eps_p=eps_p, dec_keep=dec_keep)
+    ores = patched(lambda: O.OracleTrainer(ostate, V, dec_dropout=dec_p).step(feats, feat_lens.copy(), caps, cap_lens, 1.0,
+                                                                            dis, noise=noise, record=rec,
+                                                                            apply_update=False))
     if masks is None:
         masks, eps_q, eps_p = rec["dropout"], rec["eps_q"], rec["eps_p"]
-    model = build_model(V, E, state, encoder)
+    model = build_model(V, E, state, encoder, dec_dropout=dec_p)
     model.train()
     model.encoder.dropout_masks = masks
     model.encoder.keep_saved = True
-    model.noise = dict(eps_q=eps_q, eps_p=eps_p)
+    model.noise = dict(eps_q=eps_q, eps_p=eps_p, dec_keep=dec_keep)
     random.seed(seed)
     out = patched(lambda: model(feats.cuda(), feat_lens.copy(), caps, cap_lens, ss_ratio=1.0, dis_ratio=dis))
     loss, ce, kl, mse = hip_loss(out, caps, cap_lens, V)
@@ -170,9 +173,9 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
     if full_grads:
         def under(force):
             st2 = {k: v.clone() for k, v in state.items()}
-            n2 = dict(dropout=[m.clone() for m in masks], eps_q=eps_q, eps_p=eps_p, relu_force=force)
+            n2 = dict(dropout=[m.clone() for m in masks], eps_q=eps_q, eps_p=eps_p, relu_force=force, dec_keep=dec_keep)
             random.seed(seed)
-            return patched(lambda: O.OracleTrainer(st2, V).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis, noise=n2,
+            return patched(lambda: O.OracleTrainer(st2, V, dec_dropout=dec_p).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis, noise=n2,
                                                                 apply_update=False))["grads"]
         matched = grads_match_oracle(model, named, ores["grads"], rec, under)
     if tensors:
@@ -184,6 +187,27 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
 
 def test_g6_train_step_golden():
     run_case("g6_train_step", tensors=True, full_grads=True)
+
+
+def test_g15_train_step_with_decoder_embedding_dropout_golden():
+    """VAERNNBahdanauAttnDecoder(dropout=0.3): nn.Dropout on the word embedding (models/decoder.py:33,184) inside the
+    fused decode loop, forward and backward, against the reference's own training step (golden g15: outputs, loss,
+    gradients) with the masks that run drew; and the host's own draws follow the reference's generator order."""
+    run_case("g15_train_step_decdrop", tensors=True, full_grads=True)
+    g = load_golden("g15_train_step_decdrop")
+    B, Tt, V, E, L = (int(x) for x in g["dims"])
+    seed = int(g["seed"])
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, Tt, V, L, seed=seed, ragged=True)
+    model = build_model(V, E, state, dec_dropout=0.3).train()
+    masks = unpack_masks(g)
+    model.encoder.dropout_masks = masks
+    torch.manual_seed(seed); random.seed(seed)
+    for m_ in masks:                                  # the reference drew its encoder dropout masks first
+        torch.empty(m_.shape, dtype=torch.bool).bernoulli_(0.5)
+    with torch.no_grad():
+        out = model(feats.cuda(), feat_lens.copy(), caps, cap_lens, ss_ratio=1.0, dis_ratio=0)
+    close(out["logits"], g["out_logits"], 1e-4, 2e-5, what="logits with self-drawn masks")
 
 
 def test_g6b_train_step_prior_z_golden():
