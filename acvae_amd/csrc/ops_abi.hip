@@ -280,3 +280,14 @@ extern "C" int acvae_bigru_seq(const float* X, const int64_t* lens, const void* 
   }
   return ACVAE_OK;
 }
+
+// ------------------------------------------------------------------------------------------ column sums
+// out[c] = sum_r x[r][c] for a contiguous [rows, cols] fp32 matrix (bias gradients), fixed-order fp64 combine.
+extern "C" int64_t acvae_colsum_workspace_bytes(int cols) {
+  return cols > 0 ? al64(2 * acvae::colsum_scratch_doubles(cols)) * 4 : -1;
+}
+extern "C" int acvae_colsum(const float* x, int rows, int cols, float* out, void* ws, int64_t ws_bytes, void* stream) {
+  if (!x || !out || !ws || rows <= 0 || cols <= 0) return ACVAE_EINVAL;
+  if (ws_bytes < acvae_colsum_workspace_bytes(cols)) return ACVAE_EWORKSPACE;
+  return acvae::colsum2(x, rows, cols, (double*)ws, out, nullptr, 0, (hipStream_t)stream);
+}

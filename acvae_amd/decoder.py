@@ -10,6 +10,54 @@ from .attn_model import Seq2SeqAttention
 from .encoder import ptr_table, scratch_buffer
 
 
+class _ProjTableFn(torch.autograd.Function):
+    """table[V,E] = Embedding.weight[V,D0] . Linear.weight[E,D0]^T + Linear.bias: the projected pretrained embeddings of
+    ``load_word_embeddings(.., projection=True)`` (models/decoder.py:58-64) as ONE product per forward instead of a
+    Linear per looked-up word; the decode loop then gathers rows of `table` like a plain embedding, and the table's
+    gradient (the usual embedding scatter) is split here into d Embedding / d Linear."""
+
+    @staticmethod
+    def forward(ctx, owner, emb, w, b):
+        _lib.require_cuda(emb, w, b)
+        V, D0 = emb.shape
+        E = w.shape[0]
+        table = torch.empty(V, E, device=emb.device)
+        _lib.call("acvae_gemm_nt", emb, D0, w, D0, b, table, E, V, E, D0, 0, _lib.current_stream())
+        ctx.owner = owner
+        ctx.save_for_backward(emb, w)
+        return table
+
+    @staticmethod
+    def backward(ctx, d_table):
+        emb, w = ctx.saved_tensors
+        owner = ctx.owner
+        V, D0 = emb.shape
+        E = w.shape[0]
+        d_table = d_table.contiguous().float()
+        st = _lib.current_stream()
+        buf = (lambda p: owner._grad_buffer(p)) if owner is not None else torch.empty_like
+        seq = owner.decoder.word_embeddings if owner is not None else None
+        d_emb = d_w = d_b = None
+        if ctx.needs_input_grad[1]:                     # d Embedding = d_table . W  (W^T as the NT product's second operand)
+            wt = torch.empty(D0, E, device=w.device)
+            _lib.call("acvae_transpose", w, D0, wt, E, E, D0, st)
+            d_emb = buf(seq[0].weight) if seq is not None else torch.empty_like(emb)
+            _lib.call("acvae_gemm_nt", d_table, E, wt, E, None, d_emb, D0, V, D0, E, 0, st)
+        if ctx.needs_input_grad[2]:                     # d W[E,D0] = d_table^T . Embedding
+            d_w = buf(seq[1].weight) if seq is not None else torch.empty_like(w)
+            wsb = _lib.call("acvae_gemm_tn_workspace_bytes", E, D0, V)
+            ws = scratch_buffer(max(int(wsb), 16), w.device, tag="projemb")
+            _lib.call("acvae_gemm_tn", d_table, E, emb, D0, d_w, D0, E, D0, V, 0, ws, wsb, st)
+        if ctx.needs_input_grad[3]:
+            d_b = buf(seq[1].bias) if seq is not None else torch.empty(E, device=w.device)
+            cb = _lib.call("acvae_colsum_workspace_bytes", E)
+            cws = scratch_buffer(int(cb), w.device, tag="projemb_b")
+            _lib.call("acvae_colsum", d_table, V, E, d_b, cws, cb, st)
+        if owner is not None and owner._grad_ready_cb is not None:
+            owner._grad_ready_cb("projemb")         # the last decode-side gradients are queued now
+        return None, d_emb, d_w, d_b
+
+
 class BaseDecoder(nn.Module):
     def __init__(self, embed_size, vocab_size, enc_mem_size):
         super().__init__()
@@ -39,12 +87,30 @@ class RNNDecoder(BaseDecoder):
         """models/decoder.py:50-64"""
         assert embeddings.shape[0] == self.vocab_size, "vocabulary size mismatch!"
         embeddings = torch.as_tensor(embeddings).float()
-        if embeddings.shape[1] != self.embed_size:
-            raise NotImplementedError("projected pretrained embeddings are outside the HIP path (embedding size "
-                                      "must equal embed_size)")
         self.word_embeddings.weight = nn.Parameter(embeddings.to(self.word_embeddings.weight.device))
         for para in self.word_embeddings.parameters():
             para.requires_grad = tune
+        if embeddings.shape[1] != self.embed_size:
+            assert "projection" in kwargs, "embedding size mismatch!"
+            if kwargs["projection"]:
+                self.word_embeddings = nn.Sequential(
+                    self.word_embeddings,
+                    nn.Linear(embeddings.shape[1], self.embed_size).to(self.word_embeddings.weight.device))
+
+    def embedding_table(self):
+        """The [V, embed_size] table the decode loop gathers word vectors from: the embedding weight itself, or - with
+        projected pretrained embeddings - Embedding.weight . Linear.weight^T + bias, computed once per model forward."""
+        we = self.word_embeddings
+        if not isinstance(we, nn.Sequential):
+            return we.weight
+        owner = self._owner() if getattr(self, "_owner", None) is not None else None
+        token = getattr(owner, "_forward_token", None)       # refreshed at every model forward (and reused by its backward)
+        hit = getattr(self, "_table_cache", None)
+        if hit is not None and owner is not None and hit[0] == token:
+            return hit[1]
+        table = _ProjTableFn.apply(owner, we[0].weight, we[1].weight, we[1].bias)
+        self._table_cache = (token, table)
+        return table
 
     def init_hidden(self, bs):
         """models/decoder.py:94-98"""

@@ -135,6 +135,7 @@ class TrainStep:
             model._grad_ready_cb = self._on_grads_ready
             model.encoder._grad_ready_cb = self._on_grads_ready
         self._buf_work = None
+        self._proj_emb = isinstance(model.decoder.word_embeddings, torch.nn.Sequential)
         if self._dist():
             dist.broadcast(self.flat_p, src=0, group=self.pg)
             if self.flat_buf is not None:
@@ -205,7 +206,10 @@ class TrainStep:
         is through.  The order of these calls is fixed by the autograd graph, hence identical on every rank."""
         if tag == "decode":
             self._decode_event = event
-            self.exchange.ready(0)
+            if not self._proj_emb:               # with projected embeddings their gradients are still to come ("projemb")
+                self.exchange.ready(0)
+        elif tag == "projemb":
+            self.exchange.ready(0, after=(getattr(self, "_decode_event", None),))
         elif tag == "decode_deferred":
             self._decode_event = event           # announced at "text", behind the side stream's trailing work
         elif tag == "text":

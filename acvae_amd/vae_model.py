@@ -141,7 +141,7 @@ class Hybrid_VAEModel(CaptionModel):
     def _text_table(self):
         d, q, p = self.decoder, self.qnet, self.pnet
         g, qn, pn = d.model, q.network, p.network
-        t = [d.word_embeddings.weight, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+        t = [d.embedding_table(), g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
              d.classifier.weight, d.classifier.bias, d.attn.v, d.attn.h2attn.weight, d.attn.h2attn.bias,
              q.word_embedding.weight, qn.weight_ih_l0, qn.weight_hh_l0, qn.bias_ih_l0, qn.bias_hh_l0,
              qn.weight_ih_l0_reverse, qn.weight_hh_l0_reverse, qn.bias_ih_l0_reverse, qn.bias_hh_l0_reverse,
@@ -339,6 +339,7 @@ class Hybrid_VAEModel(CaptionModel):
 
     def forward(self, *input, **kwargs):
         """models/vae_model.py:732-760"""
+        self._forward_token = getattr(self, "_forward_token", 0) + 1     # per-forward caches (decoder.embedding_table)
         if len(input) == 4:
             feats, feat_lens, caps, cap_lens = input
             # The posterior (42 serial BiGRU steps of tiny kernels) does not depend on the encoder: run it on a side

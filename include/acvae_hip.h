@@ -40,6 +40,9 @@ int acvae_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, cons
 int acvae_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N,
                   int K, int accumulate, float* slab_ws, int64_t slab_ws_bytes, void* stream);
 int64_t acvae_gemm_tn_workspace_bytes(int M, int N, int K);
+/* out[c] = sum_r x[r,c] of a contiguous [rows, cols] matrix (bias gradients); deterministic (fixed-order fp64 combine) */
+int64_t acvae_colsum_workspace_bytes(int cols);
+int acvae_colsum(const float* x, int rows, int cols, float* out, void* ws, int64_t ws_bytes, void* stream);
 /* out[c,r] = in[r,c] */
 int acvae_transpose(const float* in, int64_t ld_in, float* out, int64_t ld_out, int rows, int cols, void* stream);
 

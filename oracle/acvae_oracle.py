@@ -40,7 +40,8 @@ ENCODERS = {"Cnn10": dict(channels=(64, 128, 256, 512), head="embed_pooled", div
 
 
 def state_shapes(vocab_size: int, embed: int = 512, hidden: int = 512, attn: Optional[int] = None,
-                 q_hidden: Optional[int] = None, enc_embed: int = 512, encoder: str = "Cnn10") -> Dict[str, tuple]:
+                 q_hidden: Optional[int] = None, enc_embed: int = 512, encoder: str = "Cnn10",
+                 proj_embed: Optional[int] = None) -> Dict[str, tuple]:
     """Shapes of every state-dict entry of Hybrid_VAEModel(Cnn10, VAERNNBahdanauAttnDecoder,
     PosteriorRNN_hybrid, PriorRNN) in the reference's registration order.
 
@@ -70,7 +71,11 @@ def state_shapes(vocab_size: int, embed: int = 512, hidden: int = 512, attn: Opt
         cin = cout
     s[f"encoder.{arch['head']}.weight"] = (cin, cin); s[f"encoder.{arch['head']}.bias"] = (cin,)
     mem = E  # decoder is built with enc_mem_size = encoder embed_size (runner :44-48)
-    s["decoder.word_embeddings.weight"] = (V, E)
+    if proj_embed is None:
+        s["decoder.word_embeddings.weight"] = (V, E)
+    else:       # load_word_embeddings(.., projection=True): Sequential(Embedding(V, D0), Linear(D0, E)), decoder.py:58-64
+        s["decoder.word_embeddings.0.weight"] = (V, proj_embed)
+        s["decoder.word_embeddings.1.weight"] = (E, proj_embed); s["decoder.word_embeddings.1.bias"] = (E,)
     s["decoder.model.weight_ih_l0"] = (3 * H, E + 2 * mem)
     s["decoder.model.weight_hh_l0"] = (3 * H, H)
     s["decoder.model.bias_ih_l0"] = (3 * H,); s["decoder.model.bias_hh_l0"] = (3 * H,)
@@ -341,7 +346,11 @@ def decoder_step(state, word, h, enc_mem, enc_mem_lens, z, prefix="decoder", dro
                  keep=None, record=None):
     """VAERNNBahdanauAttnDecoder.forward, models/decoder.py:175-203.  `dropout_p` / `training`: the word-embedding
     nn.Dropout of :33,184 (default 0.0); `keep` replays its mask [N,E], `record` (a list) receives the drawn one."""
-    emb = F.embedding(word.long(), state[prefix + ".word_embeddings.weight"]).squeeze(1)
+    if prefix + ".word_embeddings.0.weight" in state:      # projected pretrained embeddings (decoder.py:58-64)
+        emb = F.linear(F.embedding(word.long(), state[prefix + ".word_embeddings.0.weight"]),
+                       state[prefix + ".word_embeddings.1.weight"], state[prefix + ".word_embeddings.1.bias"]).squeeze(1)
+    else:
+        emb = F.embedding(word.long(), state[prefix + ".word_embeddings.weight"]).squeeze(1)
     if training and dropout_p > 0.0:
         if keep is None:
             keep = torch.empty(emb.shape, dtype=torch.bool).bernoulli_(1 - dropout_p)
@@ -397,7 +406,8 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
     mem, mem_lens = enc["audio_embeds"], enc["audio_embeds_lens"]
     N = mem.shape[0]
-    E = state["decoder.word_embeddings.weight"].shape[1]
+    E = state["decoder.model.weight_hh_l0"].shape[1] if "decoder.word_embeddings.weight" not in state else \
+        state["decoder.word_embeddings.weight"].shape[1]
     H = state["decoder.model.weight_hh_l0"].shape[1]
     out: Dict[str, object] = {}
     train = caps is not None
@@ -481,7 +491,8 @@ def beam_search(state, feats, feat_lens, beam_size=3, max_length=MAX_LENGTH, eps
         enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
     mem_all, lens_all = enc["audio_embeds"], enc["audio_embeds_lens"]
     N = mem_all.shape[0]
-    E = state["decoder.word_embeddings.weight"].shape[1]
+    E = state["decoder.model.weight_hh_l0"].shape[1] if "decoder.word_embeddings.weight" not in state else \
+        state["decoder.word_embeddings.weight"].shape[1]
     H = state["decoder.model.weight_hh_l0"].shape[1]
     V = state["decoder.classifier.weight"].shape[0]
     seqs_out = torch.full((N, max_length), END_IDX, dtype=torch.long)
@@ -528,7 +539,8 @@ def diverse_beam_search(state, feats, feat_lens, beam_size=5, group_size=5, dive
         enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
     mem_all, lens_all = enc["audio_embeds"], enc["audio_embeds_lens"]
     N = mem_all.shape[0]
-    E = state["decoder.word_embeddings.weight"].shape[1]
+    E = state["decoder.model.weight_hh_l0"].shape[1] if "decoder.word_embeddings.weight" not in state else \
+        state["decoder.word_embeddings.weight"].shape[1]
     H = state["decoder.model.weight_hh_l0"].shape[1]
     V = state["decoder.classifier.weight"].shape[0]
     bdash = beam_size // group_size

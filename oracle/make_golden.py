@@ -203,10 +203,10 @@ OUT_KEYS = ("logits", "outputs", "seqs", "sampled_logprobs", "attn_weights", "p_
 
 
 def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True, keep_noise=True, encoder="Cnn10",
-                  dec_dropout=0.0):
-    shapes = O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder)
+                  dec_dropout=0.0, proj_embed=None):
+    shapes = O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder, proj_embed=proj_embed)
     state = O.closed_form_state(shapes)
-    model = ref_shim.build_reference_model(ref, V, E, E, encoder=encoder, dec_dropout=dec_dropout)
+    model = ref_shim.build_reference_model(ref, V, E, E, encoder=encoder, dec_dropout=dec_dropout, proj_embed=proj_embed)
     load_state_into(model, state)
     model.train()
     feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, T, V, L, seed=seed, ragged=ragged)
@@ -219,13 +219,15 @@ def train_fixture(ref, name, B, T, V, E, L, ragged, dis, seed, keep_tensors=True
     res = O.OracleTrainer(ostate, V, dec_dropout=dec_dropout).step(feats, feat_lens.copy(), caps, cap_lens, 1.0, dis,
                                                                    record=rec)
     assert abs(float(res["loss"]) - float(rl["loss"])) < 1e-4 * max(1, abs(float(rl["loss"]))), (res["loss"], rl["loss"])
-    d = dict(dims=np.array([B, T, V, E, L]), dec_dropout=np.array(float(dec_dropout)), seed=np.array(seed), ragged=np.array(int(ragged)), dis_ratio=np.array(float(dis)),
+    d = dict(dims=np.array([B, T, V, E, L]), dec_dropout=np.array(float(dec_dropout)),
+             proj_embed=np.array(0 if proj_embed is None else proj_embed), seed=np.array(seed), ragged=np.array(int(ragged)), dis_ratio=np.array(float(dis)),
              feat_lens=feat_lens, cap_lens=cap_lens, caps=caps,
              loss=rl["loss"], ce=rl["ce"], kl=rl["kl"], mse=rl["mse"], grad_norm=rl["grad_norm"])
     if keep_tensors:
         d["feats"] = feats
         d.update({"out_" + k: rout[k] for k in OUT_KEYS})
         d.update({"grad_" + k: rg[k] for k in GRAD_KEYS if k in rg})
+        d.update({"grad_" + k: rg[k] for k in rg if k.startswith("decoder.word_embeddings.") and "." in k[24:]})
         sd = {k: v.clone() for k, v in model.state_dict().items()}
         for k in ("encoder.conv_block1.conv1.weight", "decoder.attn.v", "pnet.mean_log_out.bias",
                   "encoder.conv_block3.bn1.running_mean", "encoder.bn0.running_var"):
@@ -470,6 +472,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "decdrop":
         train_fixture(ref, "g15_train_step_decdrop", 3, 48, 40, 64, 7, True, 0, seed=46, dec_dropout=0.3)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "projemb":
+        train_fixture(ref, "g16_train_step_projemb", 3, 48, 40, 64, 7, True, 0, seed=56, proj_embed=24)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cnn14":
         g12_cnn14(ref)
         train_fixture(ref, "g13_train_step_cnn14", 2, 64, 40, 64, 6, True, 0, seed=36, keep_tensors=False,
@@ -484,6 +489,7 @@ def main():
     train_fixture(ref, "g6b_train_step_dis", 3, 48, 40, 64, 6, True, 0.7, seed=16)
     train_fixture(ref, "g6c_train_step_e512", 2, 64, 300, 512, 7, False, 0, seed=26, keep_tensors=False)
     train_fixture(ref, "g15_train_step_decdrop", 3, 48, 40, 64, 7, True, 0, seed=46, dec_dropout=0.3)
+    train_fixture(ref, "g16_train_step_projemb", 3, 48, 40, 64, 7, True, 0, seed=56, proj_embed=24)
     g7_decode(ref)
     g14_sampling(ref)
     g9_beam(ref)

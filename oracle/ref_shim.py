@@ -87,13 +87,17 @@ def load_losses():
     return loss
 
 
-def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None, encoder="Cnn10", dec_dropout=0.0):
+def build_reference_model(ref, vocab, embed=512, hidden=512, q_hidden=None, encoder="Cnn10", dec_dropout=0.0,
+                          proj_embed=None):
     """Hybrid_VAEModel(Cnn10, VAERNNBahdanauAttnDecoder, PosteriorRNN_hybrid, PriorRNN): the
     self-consistent combination of SURVEY F6, built the way runners/pytorch_runner_vae.py:33-73 does."""
     encoder = ref.encoder.Cnn10(64, 512) if encoder == "Cnn10" else ref.encoder.Cnn14_16k(64, 2048)
     decoder = ref.decoder.VAERNNBahdanauAttnDecoder(
         vocab_size=vocab, enc_mem_size=embed, embed_size=embed, hidden_size=hidden, dropout=dec_dropout,
         num_layers=1, rnn_type="GRU", attn_size=hidden)
+    if proj_embed is not None:          # runners/pytorch_runner_vae.py:51-56: pretrained vectors of another width
+        import numpy as np
+        decoder.load_word_embeddings(np.zeros((vocab, proj_embed), dtype=np.float32), tune=True, projection=True)
     model = ref.vae_model.Hybrid_VAEModel(
         encoder, decoder, posterior_model="PosteriorRNN_hybrid",
         posterior_args={"hidden_size": q_hidden or embed, "dropout": 0.0},

@@ -28,10 +28,12 @@ def close(a, b, rtol=1e-4, atol=1e-5, what=""):
                            f"{int((~ok).sum())}/{ok.numel()} out of tolerance"
 
 
-def build_model(V, E, state=None, encoder="Cnn10", dec_dropout=0.0):
+def build_model(V, E, state=None, encoder="Cnn10", dec_dropout=0.0, proj_embed=0):
     enc = Cnn10(64, 512) if encoder == "Cnn10" else Cnn14_16k(64, 2048)
     dec = VAERNNBahdanauAttnDecoder(vocab_size=V, enc_mem_size=E, embed_size=E, hidden_size=E, dropout=dec_dropout,
                                     num_layers=1, rnn_type="GRU", attn_size=E)
+    if proj_embed:                                  # runners/pytorch_runner_vae.py:51-56
+        dec.load_word_embeddings(np.zeros((V, proj_embed), dtype=np.float32), tune=True, projection=True)
     m = Hybrid_VAEModel(enc, dec, posterior_model="PosteriorRNN_hybrid", posterior_args={"hidden_size": E, "dropout": 0.0},
                         prior_model="PriorRNN", prior_args={"hidden_size": E, "dropout": 0.0})
     if state is not None:
@@ -106,8 +108,10 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
     B, Tt, V, E, L = (int(x) for x in g["dims"])
     seed = int(g["seed"])
     dec_p = float(g["dec_dropout"]) if "dec_dropout" in g else 0.0
+    proj = int(g["proj_embed"]) if "proj_embed" in g else 0
     dec_keep = T(g["noise_dec_keep"]) if "noise_dec_keep" in g else None
-    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder))
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512 if encoder == "Cnn10" else 2048, encoder=encoder,
+                                               proj_embed=proj or None))
     feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, Tt, V, L, seed=seed, ragged=bool(int(g["ragged"])))
     dis = float(g["dis_ratio"])
     if "noise_eps_q" in g:
@@ -148,7 +152,7 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
                                                                             apply_update=False))
     if masks is None:
         masks, eps_q, eps_p = rec["dropout"], rec["eps_q"], rec["eps_p"]
-    model = build_model(V, E, state, encoder, dec_dropout=dec_p)
+    model = build_model(V, E, state, encoder, dec_dropout=dec_p, proj_embed=proj)
     model.train()
     model.encoder.dropout_masks = masks
     model.encoder.keep_saved = True
@@ -187,6 +191,29 @@ def run_case(name, tensors, full_grads, encoder="Cnn10", gn_tol=1e-3):
 
 def test_g6_train_step_golden():
     run_case("g6_train_step", tensors=True, full_grads=True)
+
+
+def test_g16_train_step_with_projected_pretrained_embeddings_golden():
+    """decoder.load_word_embeddings(vectors [V,24], tune=True, projection=True) (models/decoder.py:50-64, runner :51-56):
+    word_embeddings = Sequential(Embedding(V,24), Linear(24,E)); same state-dict keys as the reference, outputs, loss and
+    all gradients (incl. the three of the Sequential) against the reference's own training step (golden g16); and one
+    TrainStep moves those parameters."""
+    run_case("g16_train_step_projemb", tensors=True, full_grads=True)
+    from acvae_amd.trainer import TrainStep
+    g = load_golden("g16_train_step_projemb")
+    B, Tt, V, E, L = (int(x) for x in g["dims"])
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512, proj_embed=24))
+    model = build_model(V, E, state, proj_embed=24).train()
+    assert list(model.state_dict().keys()) == list(state.keys())
+    feats, caps, feat_lens, cap_lens = O.synthetic_batch(B, Tt, V, L, seed=int(g["seed"]), ragged=True)
+    ts = TrainStep(model, V)
+    before = {k: v.clone() for k, v in model.state_dict().items() if "word_embeddings" in k}
+    torch.manual_seed(1); random.seed(1)
+    parts = ts.step(feats.cuda(), feat_lens.copy(), caps, cap_lens, 1.0, 0, 0.5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts["loss"])
+    for k, v in before.items():
+        assert not torch.equal(v, model.state_dict()[k]), k
 
 
 def test_g15_train_step_with_decoder_embedding_dropout_golden():
