@@ -237,14 +237,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const bf16_t* _
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
-constexpr int KP = 32;                  // pixels per K-step (two MFMA k-steps)
-constexpr int WG_TM = 128;              // output channels per tile
-constexpr int A_LD = WG_TM + 32;        // dY tile row: 256 B + 64 B pad -> the 4 pixel rows of a transposed read hit 4 bank quarters
-constexpr int S_LD = KC + 32;           // strip row: 128 B + 64 B pad
+// EM = 2: 128 output channels per tile, 32 pixels per K-step, the wave rows split the channels.
+// EM = 1: 64 output channels (the 64-channel layers: a 128-row tile would multiply zeros half the time), 64 pixels per
+//         K-step, the wave rows split the K-step (k-steps wm, wm + 2) and write slabs of their own (2z + wm).
+constexpr int S_LD = KC + 32;           // strip row: 128 B + 64 B pad -> the 4 pixel rows of a transposed read hit 4 bank quarters
+template <int EM>
 struct alignas(16) WgSmem {
-  alignas(16) bf16_t a[2][KP * A_LD];
-  alignas(16) bf16_t s[2][(KP + 2) * S_LD];
-  alignas(16) unsigned short mk[2][2][KP];    // [side 0 = left neighbour ok, 1 = right][pixel]: 0xffff / 0
+  static constexpr int TM = 64 * EM, KPT = EM == 1 ? 64 : 32, A_LD = TM + 32;   // dY tile row + 64 B pad
+  alignas(16) bf16_t a[2][KPT * A_LD];
+  alignas(16) bf16_t s[2][(KPT + 2) * S_LD];
+  alignas(16) unsigned short mk[2][2][KPT];    // [side 0 = left neighbour ok, 1 = right][pixel]: 0xffff / 0
 };
 
 __device__ __forceinline__ bf16x4 tr_read(const bf16_t* p) {
@@ -254,13 +256,17 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+template <int EM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const bf16_t* __restrict__ dY,
                                                                  const bf16_t* __restrict__ X,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ shift,
                                                                  float* __restrict__ slab, int M, int Cout, int H, int W,
                                                                  int C, FastDivB dW_, FastDivB dH_, int k_per) {
-  __shared__ WgSmem sm;
+  constexpr int TM = WgSmem<EM>::TM, KP = WgSmem<EM>::KPT, A_LD = WgSmem<EM>::A_LD;
+  constexpr int CPR = TM / 8, RPP = 256 / CPR;      // dY tile: 16-byte chunks per pixel row, pixel rows per loader pass (2 passes)
+  constexpr int SJ = (KP + 2 + 31) / 32;            // strip slots per thread
+  __shared__ WgSmem<EM> sm;
   const int NC = 9 * C;
   const int tiles = gridDim.x * gridDim.y;
   const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const bf16_t* _
   const int dyi = by / ncg, c0 = (by - dyi * ncg) * KC, dy = dyi - 1;
   const int k_begin = z * k_per, k_end = min(M, k_begin + k_per);
   const int nk = k_end > k_begin ? (k_end - k_begin + KP - 1) / KP : 0;
-  const int row0 = bx * WG_TM;
+  const int row0 = bx * TM;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -285,27 +291,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const bf16_t* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- loader: dY tile 32 pixels x 128 channels = 512 slots of 16 B (2 per thread); strip 34 x 64 = 272 slots
-  const int ac8 = (tid & 15) * 8, arow = tid >> 4;          // dY: rows arow, arow + 16
-  const int sc8 = (tid & 7) * 8, srow = tid >> 3;           // strip: rows srow, and srow + 32 (< 34) for tid < 16
+  // ---- loader: dY tile KP pixels x TM channels = 512 slots of 16 B (2 per thread); strip (KP + 2) x 64 channels
+  const int ac8 = (tid % CPR) * 8, arow = tid / CPR;        // dY: rows arow, arow + RPP
+  const int sc8 = (tid & 7) * 8, srow = tid >> 3;           // strip: rows srow + 32 j
   float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
   if (scale) {
     s0 = *reinterpret_cast<const float4*>(scale + c0 + sc8); s1 = *reinterpret_cast<const float4*>(scale + c0 + sc8 + 4);
     h0 = *reinterpret_cast<const float4*>(shift + c0 + sc8); h1 = *reinterpret_cast<const float4*>(shift + c0 + sc8 + 4);
   }
-  uint4 pa[2], ps[2];
-  bool aok[2], sok[2];
+  uint4 pa[2], ps[SJ];
+  bool aok[2], sok[SJ];
   unsigned short mkv = 0;
   auto issue = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int p = k0 + arow + 16 * j;
+      const int p = k0 + arow + RPP * j;
       const int co = row0 + ac8;
       aok[j] = p < k_end && co < Cout;
       pa[j] = *reinterpret_cast<const uint4*>(aok[j] ? dY + (long)p * Cout + co : dY);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < SJ; ++j) {
       const int r = srow + 32 * j;
       const long q = (long)k0 - 1 + r;
       // a strip row is needed only by pixels of this slice: rows beyond the slice end may stay zero (their dY rows are zero)
@@ -328,9 +334,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const bf16_t* _
   auto stash = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      *reinterpret_cast<uint4*>(&sm.a[buf][(arow + 16 * j) * A_LD + ac8]) = aok[j] ? pa[j] : make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(&sm.a[buf][(arow + RPP * j) * A_LD + ac8]) = aok[j] ? pa[j] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < SJ; ++j) {
       const int r = srow + 32 * j;
       if (r < KP + 2) {
         uint4 v = ps[j];
@@ -353,9 +359,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const bf16_t* _
     const int cur = ks & 1;
     if (ks + 1 < nk) issue(k_begin + (ks + 1) * KP);
 #pragma unroll
-    for (int kk = 0; kk < KP / 16; ++kk) {
+    for (int kq = 0; kq < 2; ++kq) {
+      const int kk = EM == 2 ? kq : 2 * kq + wm;     // EM = 1: the wave rows take alternate k-steps of the 64-pixel K-step
       bf16x8 af[2], bfr[3];
-      const bf16_t* Ap = sm.a[cur] + (kk * 16 + trow) * A_LD + wm * 64 + tcol;
+      const bf16_t* Ap = sm.a[cur] + (kk * 16 + trow) * A_LD + (EM == 2 ? wm * 64 : 0) + tcol;
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i] = cat8(tr_read(Ap + i * 32), tr_read(Ap + 4 * A_LD + i * 32));
       // this lane's 8 pixels of the K-step: k = kk*16 + 8*lh + j -> border masks, 8 x 16 bit
@@ -380,13 +387,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const bf16_t* _
     if (ks + 1 < nk) stash(cur ^ 1);
     __syncthreads();
   }
-  // slab[z][co][(dy*3 + dx)*C + c]
-  float* Cs = slab + (long)z * Cout * NC;
+  // slab[z][co][(dy*3 + dx)*C + c]; EM = 1: the K-halves of the two wave rows go to slabs 2z and 2z + 1
+  float* Cs = slab + (long)(EM == 2 ? z : 2 * z + wm) * Cout * NC;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = row0 + (EM == 2 ? wm * 64 : 0) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= Cout) continue;
       float* out = Cs + (long)m * NC + dyi * 3 * C + c0;
 #pragma unroll
@@ -425,7 +432,8 @@ int conv3x3_igemm_bf16(const bf16_t* X, const float* scale, const float* shift, 
 // pixel slices: whole rounds of the 2 x 256 resident workgroups, at least 8 K-steps per slice, a multiple of 8 (one group of
 // slices per XCD); every slice costs one fp32 slab of Cout x 9 Cin that is written and read once more
 static int wgrad_bf16_splits(int M, int Cout, int NC) {
-  const long tiles = (long)cdiv(Cout, WG_TM) * (NC / 192);
+  const int TM = Cout <= 64 ? 64 : 128, KP = Cout <= 64 ? 64 : 32;
+  const long tiles = (long)cdiv(Cout, TM) * (NC / 192);
   const int maxs = (cdiv(M, 8 * KP) / 8) * 8;
   int best = 8;
   double best_t = 1e30;
@@ -437,10 +445,13 @@ static int wgrad_bf16_splits(int M, int Cout, int NC) {
   }
   return best;
 }
-long conv3x3_wgrad_bf16_slab_floats(int N, int H, int W, int Cin, int Cout) {
-  return (long)wgrad_bf16_splits(N * H * W, Cout, 9 * Cin) * Cout * 9 * Cin;
+// slabs the reduce has to sum: one per pixel slice, two for the 64-channel tile (its wave rows split the K-step)
+int conv3x3_wgrad_bf16_splits(int N, int H, int W, int Cin, int Cout) {
+  return wgrad_bf16_splits(N * H * W, Cout, 9 * Cin) * (Cout <= 64 ? 2 : 1);
 }
-int conv3x3_wgrad_bf16_splits(int N, int H, int W, int Cin, int Cout) { return wgrad_bf16_splits(N * H * W, Cout, 9 * Cin); }
+long conv3x3_wgrad_bf16_slab_floats(int N, int H, int W, int Cin, int Cout) {
+  return (long)conv3x3_wgrad_bf16_splits(N, H, W, Cin, Cout) * Cout * 9 * Cin;
+}
 
 int conv3x3_wgrad_bf16_launch(const bf16_t* dY, const bf16_t* X, const float* scale, const float* shift, float* slab, int N,
                               int H, int W, int Cin, int Cout, hipStream_t st) {
@@ -450,11 +461,18 @@ int conv3x3_wgrad_bf16_launch(const bf16_t* dY, const bf16_t* X, const float* sc
   const int M = N * H * W, NC = 9 * Cin;
   if ((long)(M + 4096) * (W > H ? W : H) >= (1L << 40)) return ACVAE_EUNSUPPORTED;   // FastDiv range
   const int s = wgrad_bf16_splits(M, Cout, NC);
+  const int KP = Cout <= 64 ? 64 : 32;
   const int k_per = cdiv(cdiv(M, s), KP) * KP;
   prof_begin(ACVAE_PROF_CONV_WGRAD, st);
-  const dim3 grid(cdiv(Cout, WG_TM), NC / 192, s);
-  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(256), 0, st, dY, X, scale, shift, slab, M, Cout, H, W, Cin,
-                     FastDivB::make(W), FastDivB::make(H), k_per);
+  if (Cout <= 64) {
+    const dim3 grid(cdiv(Cout, 64), NC / 192, s);
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, st, dY, X, scale, shift, slab, M, Cout, H, W, Cin,
+                       FastDivB::make(W), FastDivB::make(H), k_per);
+  } else {
+    const dim3 grid(cdiv(Cout, 128), NC / 192, s);
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, st, dY, X, scale, shift, slab, M, Cout, H, W, Cin,
+                       FastDivB::make(W), FastDivB::make(H), k_per);
+  }
   prof_end(ACVAE_PROF_CONV_WGRAD, st);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
