@@ -22,6 +22,7 @@
 //   channels of one vertical tap) from ONE 34-pixel strip per 32-pixel K-step; pixels whose horizontal neighbour leaves
 //   the image row are switched off by AND-masks staged beside the strip.  Split over pixel slices into fp32 slabs that
 //   wgrad_reduce_kernel (conv.hip) sums in fixed order.
+#include <cstdlib>
 #include "mfma_tile.h"
 #include "../../include/acvae_hip.h"
 #include "conv.h"
@@ -437,10 +438,11 @@ static int wgrad_bf16_splits(int M, int Cout, int NC) {
   const int maxs = (cdiv(M, 8 * KP) / 8) * 8;
   int best = 8;
   double best_t = 1e30;
-  for (int k = 8; k <= (maxs < 8 ? 8 : maxs) && k <= 256; k += 8) {
+  for (int k = 8; k <= (maxs < 8 ? 8 : maxs) && k <= 512; k += 8) {
     const long nb = tiles * k;
     const long rounds = (nb + 511) / 512;
-    const double t = (double)rounds * ((double)M / k) + 6.0 * k * 32.0;    // K-steps per round x rounds + slab cost (in pixel units)
+    static const double slab_cost = getenv("ACVAE_WGB_SLABCOST") ? atof(getenv("ACVAE_WGB_SLABCOST")) : 0.5;   // measured: 6 -> 0.5 took the seven launches from 2.26 to 1.56 ms
+    const double t = (double)rounds * ((double)M / k) + slab_cost * k * 32.0;    // K-steps per round x rounds + slab cost (in pixel units)
     if (t < best_t) { best_t = t; best = k; }
   }
   return best;
