@@ -1359,7 +1359,8 @@ static int wgrad_splits(int M, int Cout, int NC) {
   const int maxs = cdiv(M, 16 * BKT) & ~7;
   const double t_mfma = 2.0 * (double)M * Cout * NC / 1.1e14;
   // measured: a slab costs ~6x its bytes / HBM rate
-  const double t_slab = 2.0 * (double)Cout * NC * 4.0 / 0.67e12 * wgrad_slabs_per_slice(NC, Cout);
+  static const double slab_scale = getenv("ACVAE_WG_SLABSCALE") ? atof(getenv("ACVAE_WG_SLABSCALE")) : 1.0;
+  const double t_slab = slab_scale * 2.0 * (double)Cout * NC * 4.0 / 0.67e12 * wgrad_slabs_per_slice(NC, Cout);
   int best = 8;
   double best_t = 1e30;
   for (int k = 8; k <= (maxs < 8 ? 8 : maxs) && tiles * k <= 5 * slots; k += 8) {
