@@ -252,7 +252,7 @@ class TrainStep:
         self.exchange.begin()
         loss.backward()
         gscale = self.exchange.finish()
-        self._check_grad_aliasing()
+        skipped = self._check_grad_aliasing()
         st = _lib.current_stream()
         n = self.n_active
         tn = None
@@ -260,9 +260,13 @@ class TrainStep:
             _lib.call("acvae_grad_norm", self.flat_g, n, gscale, self.norm_partials, self.total_norm, st)
             tn = self.total_norm
         self.step_count += 1
-        _lib.call("acvae_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, n, self.lr,
-                  self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, gscale,
-                  float(self.max_grad_norm or 0.0), tn, st)
+        # torch.optim.Adam leaves a parameter whose .grad is None alone (no moment decay, no update): the fused pass
+        # then runs over the segments between such parameters (their gradient slices are zero, so the norm is unaffected).
+        # On this path every parameter gets a gradient every step and the loop runs once over the whole buffer.
+        for a, b in self._segments(skipped, n):
+            _lib.call("acvae_adam_step", self.flat_p[a:b], self.flat_g[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], b - a,
+                      self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, gscale,
+                      float(self.max_grad_norm or 0.0), tn, st)
         parts["loss"] = loss.detach()
         parts["grad_norm"] = self.total_norm
         # DDP's broadcast_buffers: rank 0's BatchNorm running statistics reach the other ranks before the next forward
@@ -289,14 +293,33 @@ class TrainStep:
 
     def _check_grad_aliasing(self):
         """The backward kernels write into the flat gradient buffer and autograd is expected to adopt those
-        views as .grad; if it cloned one instead (or a parameter got no gradient), repair the flat buffer."""
+        views as .grad; if it cloned one instead, repair the alias; if a parameter got no gradient at all, zero its
+        slice and report it: returns the list of (offset, end) ranges of active parameters without a gradient."""
+        skipped, off = [], 0
         for p in self.order:
             v = self.views[p]
+            sz = (p.numel() + 3) // 4 * 4
             if p.grad is None:
-                if v.data_ptr() < self.flat_g.data_ptr() + 4 * self.n_active:
+                if off < self.n_active:
                     v.zero_()
+                    skipped.append((off, off + sz))
             elif p.grad.data_ptr() != v.data_ptr():
                 p.grad = v            # autograd cloned the view; the flat buffer (already all-reduced) is authoritative
+            off += sz
+        return skipped
+
+    @staticmethod
+    def _segments(skipped, n):
+        if not skipped:
+            return [(0, n)]
+        segs, cur = [], 0
+        for a, b in skipped:
+            if a > cur:
+                segs.append((cur, a))
+            cur = max(cur, b)
+        if cur < n:
+            segs.append((cur, n))
+        return segs
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}

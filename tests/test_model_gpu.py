@@ -606,6 +606,42 @@ def test_two_host_threads_two_streams_share_nothing():
                 assert torch.equal(a, b), f"thread {i}: result differs from its single-threaded run"
 
 
+def test_adam_leaves_parameters_without_gradient_alone():
+    """torch.optim.Adam skips a parameter whose .grad is None (no moment decay, no update); the fused flat-buffer pass
+    must do the same (it then runs over the segments between such parameters)."""
+    from acvae_amd.trainer import TrainStep
+    assert TrainStep._segments([], 100) == [(0, 100)]
+    assert TrainStep._segments([(0, 8), (40, 48)], 100) == [(8, 40), (48, 100)]
+    assert TrainStep._segments([(92, 100)], 100) == [(0, 92)]
+    V, E = 40, 64
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    feats, caps, fl, cl = O.synthetic_batch(3, 64, V, 7, seed=1, ragged=True)
+    model = build_model(V, E, state).train()
+    ts = TrainStep(model, V)
+    victim = model.decoder.attn.v
+    other = model.decoder.classifier.bias
+
+    def one():
+        torch.manual_seed(3); random.seed(3)
+        return ts.step(feats.cuda(), fl.copy(), caps, cl, 1.0, 0, 0.5)
+
+    one()                                               # step 1: everybody has a gradient, moments become non-zero
+    v_before, o_before = victim.detach().clone(), other.detach().clone()
+    off = ts._offsets()[victim]
+    m_before = ts.exp_avg[off:off + victim.numel()].clone()
+    orig = ts._check_grad_aliasing
+
+    def drop_then_check():
+        victim.grad = None                              # as if this parameter had not taken part in the step
+        return orig()
+    ts._check_grad_aliasing = drop_then_check
+    one()
+    torch.cuda.synchronize()
+    assert torch.equal(victim.detach(), v_before), "a parameter without gradient was moved"
+    assert torch.equal(ts.exp_avg[off:off + victim.numel()], m_before), "its first moment decayed"
+    assert not torch.equal(other.detach(), o_before)
+
+
 def test_checkpoint_round_trip_and_torch_adam_compat():
     """{"model", "optimizer"} checkpoint in the reference's format: resuming from it continues bit for bit, and a
     torch.optim.Adam over the same parameters accepts the optimiser part (it takes the same second step)."""
