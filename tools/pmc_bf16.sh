@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/pmc1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/pmc1 -o p --output-format csv -- python3 "$ROOT/tools/bench_encoder.py" 32 1000 2 Cnn10 ${1:-bf16} > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES ${PMC_EXTRA:-SQ_BUSY_CYCLES} SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/pmc1 -o p --output-format csv -- python3 "$ROOT/tools/bench_encoder.py" 32 1000 2 Cnn10 ${1:-bf16} > /dev/null 2>&1
 python3 - <<'PY'
 import csv, collections, glob
 f = glob.glob('/tmp/pmc1/**/*counter_collection.csv', recursive=True)[0]
