@@ -31,6 +31,13 @@ int wgrad_reduce(const float* slab, int nsplit, float* dW_oihw, int Cout, int Ci
 long conv3x3_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout);
 int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
                   int N, int H, int W, int Cin, int Cout, hipStream_t st);
+// Winograd F(2x2,3x3) forward / data gradient (conv_wino.hip), fp32.  U = conv3x3_wino_weights image (16*Cin*Cout floats)
+bool conv3x3_wino_ok(int H, int W, int Cin, int Cout);
+long conv3x3_wino_weight_floats(int Cin, int Cout);
+int conv_wino_partials_rows(int N, int H, int W);
+int conv3x3_wino_weights(const float* W_oihw, float* U, int Cout, int Cin, bool dgrad, hipStream_t st);
+int conv3x3_wino(const float* X, const float* scale, const float* shift, const float* U, float* Y, float* partials, int N,
+                 int H, int W, int Cin, int Cout, hipStream_t st);
 // T = float or bf16_t (storage type of activations / repacked weights; arithmetic is fp32 either way)
 template <class T>
 int repack_weights(const float* W_oihw, T* Wf, T* Wd, int Cout, int Cin, hipStream_t st);

@@ -1,0 +1,339 @@
+// A1 (models/encoder.py:606-649 ConvBlock): the 3x3 convolutions of the encoder as Winograd F(2x2, 3x3) on the fp32
+// matrix pipe - 16 multiplies per 2x2 output tile and channel pair instead of 36, i.e. 2.25x fewer MFMA flops than the
+// implicit GEMM of conv.hip for the same result (fp32 throughout; the transforms only add and halve, their rounding is
+// of the order of the accumulation's own - bounds in tests/test_kernels_gpu.py).
+//
+//   Y = At [ sum_ci (G g G^T) .* (Bt d B) ] A      d: 4x4 input window, g: 3x3 filter, Y: 2x2 outputs
+//
+// One workgroup = 64 output tiles (R tile rows x TW tile columns of ONE clip, TW = W/2, R = 64/TW) x 64 output channels
+// x all 16 transform positions: 16 GEMMs [64 tiles x Cin] x [Cin x 64] whose 65536 accumulators fill the accumulation
+// registers of the CU (8 wavefronts x 128).  Nothing transformed ever touches HBM or LDS:
+//   * the activation window (2R+2 pixel rows x W+2 columns, 16 channels per stage) is staged ONCE, with the previous
+//     layer's BatchNorm+ReLU and the zero padding applied on the way, into four (row parity, column parity) planes, so
+//     that the 16 tiles a 16-lane LDS read group serves are 16 consecutive 16-byte slots;
+//   * every wavefront builds the Bt d B fragments of its 8 positions in registers from 12 ds_read_b128 (64 adds per
+//     32 MFMAs) - the vertical half of the transform splits cleanly over the two position halves: rows 0-2 / 1-3;
+//   * G g G^T is precomputed per step into the exact LDS image of a weight panel (wino_weights_kernel) and streams
+//     global -> LDS by LDS-DMA, 32 KB per 8-channel chunk;
+//   * the epilogue applies At . A in registers, the two position halves of a tile meet through LDS once per tile, and
+//     the BatchNorm batch statistics of the raw output are reduced exactly like conv.hip's epilogue does.
+// The same kernel is the data gradient (X = dY, filter flipped and transposed by wino_weights_kernel, no activation).
+#include "mfma_tile.h"
+#include "../../include/acvae_hip.h"
+#include "conv.h"
+#include "prof.h"
+
+namespace {
+using namespace mfma;
+
+constexpr int WN_THREADS = 512;
+constexpr int WN_TILES = 64;      // output tiles (2x2 pixels each) per workgroup
+constexpr int WN_TN = 64;         // output channels per workgroup
+constexpr int WN_RAWMAX = 100;    // float4 slots per (channel quad, parity plane): (R+1)*(TW+1) <= 99
+constexpr int WN_BCHUNK = 16 * 2 * 64;   // float4 per weight chunk image: [position][k half][column]
+
+struct alignas(16) WinoSmem {
+  float4 raw[2][16 * WN_RAWMAX];   // [stage buffer][(quad*4 + plane)*WN_RAWMAX + row*(TW+1) + col]     51200 B
+  float4 b[2][WN_BCHUNK];          // [chunk buffer][(pos*2 + h)*64 + col]                              65536 B
+};
+
+struct WinoParams {
+  const float* X;       // [N][H][W][C]
+  const float* scale;   // nullable: no activation on the operand
+  const float* shift;
+  const float* U;       // wino_weights_kernel image
+  float* Y;             // [N][H][W][Cout]
+  float* partials;      // [blocks][2][Cout] or nullptr
+  int N, H, W, C, Cout;
+  int tw_shift;         // TW = W/2 = 1 << tw_shift
+  int R;                // tile rows per workgroup = 64 / TW
+  int bpc;              // workgroups (row blocks) per clip = ceil(ceil(H/2) / R)
+};
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  // wavefront roles: xh = position half (vertical frequencies {0,1} / {3,2}), mh = tile half, nh = column half
+  const int xh = wave & 1, mh = (wave >> 1) & 1, nh = wave >> 2;
+  int bm, bn;
+  xcd_tile(gridDim.x, gridDim.y, bm, bn);
+  const int TW = 1 << p.tw_shift, RW = TW + 1, R = p.R;
+  const int n = bm / p.bpc, ty0 = (bm - n * p.bpc) * R;
+  const int H = p.H, W = p.W, C = p.C;
+
+  // ---------------------------------------------------------------- staging items of this thread (fixed over stages)
+  // item e = tid + 512 j -> window pixel e / 4, channel quad e % 4 (= tid % 4)
+  const int W2 = W + 2;
+  const int nitems = (2 * R + 2) * W2 * 4;
+  const int q = tid & 3;
+  unsigned live = 0, okm = 0;
+  long goff[4];
+  int loff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + WN_THREADS * j;
+    const bool lv = e < nitems;
+    const int px = e >> 2;
+    const int ry = px / W2, rx = px - ry * W2;
+    const int y = 2 * ty0 - 1 + ry, x = rx - 1;
+    const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
+    live |= (lv ? 1u : 0u) << j;
+    okm |= (ok ? 1u : 0u) << j;
+    goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;     // always a legal address
+    loff[j] = (q * 4 + (ry & 1) * 2 + (rx & 1)) * WN_RAWMAX + (ry >> 1) * RW + (rx >> 1);
+  }
+  float4 pv[4];
+  auto issue_raw = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
+  };
+  auto put_raw = [&](int st, int buf) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool act = p.scale != nullptr;
+    if (act) {
+      sc = *reinterpret_cast<const float4*>(p.scale + st * 16 + q * 4);
+      sh = *reinterpret_cast<const float4*>(p.shift + st * 16 + q * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = pv[j];
+      if (act) {
+        v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+        v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+      }
+      if (!((okm >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding / rows of another clip
+      if ((live >> j) & 1u) sm.raw[buf][loff[j]] = v;
+    }
+  };
+  // weight chunk c: 32 KB, already in LDS order; one LDS-DMA instruction of a wave moves 1 KB
+  const int nchunk = C >> 3;
+  const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
+  auto fetch_b = [&](int c, int buf) {
+    const float* src = Ub + (long)c * (WN_BCHUNK * 4);
+    float* dst = reinterpret_cast<float*>(&sm.b[buf][0]) + wave * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 2048, dst + i * 2048, 16, 0, 0);
+  };
+
+  // ---------------------------------------------------------------- this lane's tile and fragment addresses
+  const int m = mh * 32 + li;
+  const int abase = (m >> p.tw_shift) * RW + (m & (TW - 1));
+  int rowoff[3];      // window rows xh, xh+1, xh+2 of the tile: plane (row parity) and row index
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int i = xh + a;
+    rowoff[a] = (i & 1) * 2 * WN_RAWMAX + (i >> 1) * RW + abase;
+  }
+  const int xi0 = xh ? 3 : 0, xi1 = xh ? 2 : 1;     // vertical frequencies of local positions 0..3 / 4..7
+  const int bcol = h * 64 + nh * 32 + li;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  auto mfma4 = [&](f32x16& c, float4 a, float4 b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+  };
+  // K-step j of a chunk pairs channel c0 + j (lanes 0-31) with c0 + 4 + j (lanes 32-63): quad 2*sub + h
+  auto compute = [&](int rawbuf, int sub, int bbuf) {
+    const float4* rq = &sm.raw[rawbuf][(2 * sub + h) * 4 * WN_RAWMAX];
+    const float4* bq = &sm.b[bbuf][bcol];
+    float4 d[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_RAWMAX + (j >> 1)];
+#pragma unroll
+    for (int xl = 0; xl < 2; ++xl) {
+      float4 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (xl == 0) t[j] = f4sub(d[0][j], d[2][j]);                // frequency 0 (rows 0,2) / 3 (rows 1,3)
+        else t[j] = xh ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);   // frequency 1: r1 + r2 / 2: r2 - r1
+      }
+      const int xi = xl ? xi1 : xi0;
+      const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
+      const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
+      mfma4(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0);
+      mfma4(acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
+      mfma4(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2);
+      mfma4(acc[xl * 4 + 3], f4sub(t[1], t[3]), b3);
+    }
+  };
+
+  // ---------------------------------------------------------------- main loop: one barrier per 8-channel chunk
+  const int nstage = C >> 4;
+  issue_raw(0);
+  fetch_b(0, 0);
+  put_raw(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int st = c >> 1, sub = c & 1;
+    if (c + 1 < nchunk) fetch_b(c + 1, (c + 1) & 1);       // its last readers (chunk c - 1) are behind the barrier
+    if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);    // in flight for this chunk and the next
+    compute(st & 1, sub, c & 1);
+    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, (st + 1) & 1);   // that buffer's last readers: stage st - 1
+    // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue: At . A, position halves meet through LDS
+  float* ex = reinterpret_cast<float*>(&sm.b[0][0]);        // [wave][32][64 lanes] = 64 KB
+  float keep[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float hl[2][2];
+#pragma unroll
+    for (int xl = 0; xl < 2; ++xl) {
+      const float m0 = acc[xl * 4 + 0][r], m1 = acc[xl * 4 + 1][r], m2 = acc[xl * 4 + 2][r], m3 = acc[xl * 4 + 3][r];
+      hl[xl][0] = m0 + m1 + m2;
+      hl[xl][1] = m1 - m2 - m3;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float s = hl[0][b] + hl[1][b];
+      keep[r][b] = xh ? -s : s;
+      ex[(wave * 32 + r * 2 + b) * 64 + lane] = hl[1][b];
+    }
+  }
+  __syncthreads();
+  const int cout = bn * WN_TN + nh * 32 + li;
+  float s = 0.f, qq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mt = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int y = 2 * (ty0 + (mt >> p.tw_shift)) + xh;       // this wave finishes output row xh of its tiles
+    const int x = 2 * (mt & (TW - 1));
+    const float o0 = keep[r][0] + ex[((wave ^ 1) * 32 + r * 2 + 0) * 64 + lane];
+    const float o1 = keep[r][1] + ex[((wave ^ 1) * 32 + r * 2 + 1) * 64 + lane];
+    if (y < H) {
+      float* out = p.Y + ((long)(n * H + y) * W + x) * p.Cout + cout;
+      out[0] = o0;
+      out[p.Cout] = o1;
+      s += o0 + o1;
+      qq += o0 * o0 + o1 * o1;
+    }
+  }
+  if (p.partials) {
+    float* red = reinterpret_cast<float*>(&sm.raw[0][0]);   // [4 waves of a column half][2][64]
+    s += __shfl_xor(s, 32, 64);
+    qq += __shfl_xor(qq, 32, 64);
+    if (h == 0) {
+      red[((mh * 2 + xh) * 2 + 0) * 64 + nh * 32 + li] = s;
+      red[((mh * 2 + xh) * 2 + 1) * 64 + nh * 32 + li] = qq;
+    }
+    __syncthreads();
+    if (tid < WN_TN) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
+      float* out = p.partials + (long)bm * 2 * p.Cout + bn * WN_TN + tid;
+      out[0] = ts;
+      out[p.Cout] = tq;
+    }
+  }
+}
+
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(WinoParams p) {
+  __shared__ WinoSmem sm;
+  conv_wino_body(p, sm);
+}
+
+// U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
+//   [output block of 64][8-channel chunk][position 16][k half 2][column 64][4 channels]
+// dgrad: the data gradient's filter is the forward one flipped and transposed (its input channels are the layer's outputs)
+__global__ void wino_weights_kernel(const float* __restrict__ Wt, float4* __restrict__ U, int Cout, int Cin, int dgrad) {
+  const int K = dgrad ? Cout : Cin, NO = dgrad ? Cin : Cout;
+  const long total = (long)NO * (K >> 2);
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int out = (int)(idx % NO), kq = (int)(idx / NO);
+    float u[16][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int in = kq * 4 + jj;
+      double g[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          g[a][b] = dgrad ? (double)Wt[((long)in * Cin + out) * 9 + (2 - a) * 3 + (2 - b)]
+                          : (double)Wt[((long)out * Cin + in) * 9 + a * 3 + b];
+      double t[4][3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+      }
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        u[xi * 4 + 0][jj] = (float)t[xi][0];
+        u[xi * 4 + 1][jj] = (float)(0.5 * (t[xi][0] + t[xi][1] + t[xi][2]));
+        u[xi * 4 + 2][jj] = (float)(0.5 * (t[xi][0] - t[xi][1] + t[xi][2]));
+        u[xi * 4 + 3][jj] = (float)t[xi][2];
+      }
+    }
+    const int cb = out >> 6, col = out & 63, chunk = kq >> 1, hh = kq & 1;
+    float4* dst = U + (((long)cb * (K >> 3) + chunk) * 16 * 2 + hh) * 64 + col;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) dst[(long)pos * 128] = make_float4(u[pos][0], u[pos][1], u[pos][2], u[pos][3]);
+  }
+}
+
+inline int tile_rows_per_block(int W) { return WN_TILES / (W / 2); }
+}  // namespace
+
+namespace acvae {
+
+bool conv3x3_wino_ok(int H, int W, int Cin, int Cout) {
+  if (H < 1 || W < 4 || W > 64 || (W & (W - 1)) != 0) return false;      // TW = W/2 in {2,..,32}, a power of two
+  return Cin % 16 == 0 && Cout % WN_TN == 0;
+}
+long conv3x3_wino_weight_floats(int Cin, int Cout) { return 16L * Cin * Cout; }
+int conv_wino_partials_rows(int N, int H, int W) { return N * cdiv(cdiv(H, 2), tile_rows_per_block(W)); }
+
+int conv3x3_wino_weights(const float* W_oihw, float* U, int Cout, int Cin, bool dgrad, hipStream_t st) {
+  if (!W_oihw || !U) return ACVAE_EINVAL;
+  const int K = dgrad ? Cout : Cin, NO = dgrad ? Cin : Cout;
+  if (K % 16 != 0 || NO % WN_TN != 0) return ACVAE_EUNSUPPORTED;
+  const long total = (long)NO * (K / 4);
+  hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)), dim3(256), 0, st, W_oihw,
+                     reinterpret_cast<float4*>(U), Cout, Cin, dgrad ? 1 : 0);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+// Y[N][H][W][Cout] = conv3x3(act(X[N][H][W][Cin])), pad 1; act = relu(x * scale + shift) when scale != nullptr.
+// U: conv3x3_wino_weights image for (Cin -> Cout).  partials (nullable): [conv_wino_partials_rows][2][Cout].
+int conv3x3_wino(const float* X, const float* scale, const float* shift, const float* U, float* Y, float* partials, int N,
+                 int H, int W, int Cin, int Cout, hipStream_t st) {
+  if (!X || !U || !Y) return ACVAE_EINVAL;
+  if (!conv3x3_wino_ok(H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
+  if (!aligned16(X) || !aligned16(U) || !aligned16(Y) || (scale && (!aligned16(scale) || !aligned16(shift)))) return ACVAE_EALIGN;
+  WinoParams p;
+  p.X = X; p.scale = scale; p.shift = shift; p.U = U; p.Y = Y; p.partials = partials;
+  p.N = N; p.H = H; p.W = W; p.C = Cin; p.Cout = Cout;
+  const int TW = W / 2;
+  p.tw_shift = __builtin_ctz(TW);
+  p.R = WN_TILES / TW;
+  p.bpc = cdiv(cdiv(H, 2), p.R);
+  const dim3 grid(N * p.bpc, Cout / WN_TN);
+  prof_begin(ACVAE_PROF_CONV_IGEMM, st);
+  hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  prof_end(ACVAE_PROF_CONV_IGEMM, st);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+}  // namespace acvae

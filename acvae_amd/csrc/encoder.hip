@@ -21,6 +21,16 @@ inline bool arch_of(int arch, Arch& a) {
   return false;
 }
 inline bool is_bf16(int arch) { return (arch & ACVAE_ENC_BF16) != 0; }
+// fp32 convolutions (forward and data gradient) as Winograd F(2x2,3x3) wherever conv_wino.hip takes the shape
+// (ACVAE_CONV_WINO=0: the implicit GEMM of conv.hip everywhere)
+inline bool wino_on() {
+  static const bool on = !getenv("ACVAE_CONV_WINO") || atoi(getenv("ACVAE_CONV_WINO")) != 0;
+  return on;
+}
+template <class TA>
+inline bool use_wino(int H, int W, int Cin, int Cout) {
+  return sizeof(TA) == 4 && wino_on() && acvae::conv3x3_wino_ok(H, W, Cin, Cout);
+}
 
 struct EncLayout {
   int N, T, F;
@@ -58,12 +68,17 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
     L.y1[b] = off; off = align4(off + units(act));
     L.y2[b] = off; off = align4(off + units(act));
     L.p[b] = off; off = align4(off + units(pool));
-    L.wf1[b] = off; off = align4(off + units((long)kChan[b] * 9 * kChan[b - 1]));
-    L.wf2[b] = off; off = align4(off + units((long)kChan[b] * 9 * kChan[b]));
+    const long wtaps = esz == 4 ? 16 : 9;      // fp32: room for the 16 Winograd positions of conv_wino.hip
+    L.wf1[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b - 1]));
+    L.wf2[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b]));
     if (act > max_act) max_act = act;
     if (pool > max_pool) max_pool = pool;
     const long part = (long)acvae::conv_partials_rows(N, h, w) * 2 * kChan[b];
     if (part > max_part) max_part = part;
+    if (w >= 4) {
+      const long wpart = (long)acvae::conv_wino_partials_rows(N, h, w) * 2 * kChan[b];
+      if (wpart > max_part) max_part = wpart;
+    }
     long sl = esz == 2 ? acvae::conv3x3_wgrad_bf16_slab_floats(N, h, w, kChan[b], kChan[b])
                        : acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b], kChan[b]);
     if (sl > max_slab) max_slab = sl;
@@ -92,7 +107,7 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
   L.s_dpart = s; s = align4(s + 2 * acvae::colsum_scratch_doubles(2 * L.Cemb > 1024 ? 2 * L.Cemb : 1024));
   L.s_partials = s; s = align4(s + max_part);
   L.s_bnpart = s; s = align4(s + max_bnpart);
-  L.s_wd = s; s = align4(s + units((long)L.Cemb * 9 * L.Cemb));
+  L.s_wd = s; s = align4(s + units((long)L.Cemb * (esz == 4 ? 16 : 9) * L.Cemb));
   L.s_slab = s; s = align4(s + max_slab);
   L.s_c1w = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 576);
   L.s_c1b = s; s = align4(s + (long)acvae::conv1_first_blocks(N, T) * 128);
@@ -110,6 +125,34 @@ inline int p_conv(int b, int which) { return 5 + (b - 1) * 12 + (which - 1); }
 inline int p_bn(int b, int which, int k) { return 5 + (b - 1) * 12 + 2 + (which - 1) * 5 + k; }
 inline int p_fc_w(int nb) { return 5 + nb * 12; }       // embed_pooled (Cnn10) / fc1 (Cnn14_16k)
 inline int p_fc_b(int nb) { return 6 + nb * 12; }
+
+// Y = conv3x3(act(X), W): weights repacked / transformed into `wbuf`, BN partial rows returned in *nparts
+template <class TA>
+int conv_fwd(const TA* X, const float* scale, const float* shift, const float* W_oihw, float* wbuf, TA* Y, float* partials,
+             int N, int H, int W, int Cin, int Cout, int* nparts, hipStream_t st) {
+  if constexpr (sizeof(TA) == 4) {
+    if (use_wino<TA>(H, W, Cin, Cout)) {
+      ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, wbuf, Cout, Cin, false, st));
+      *nparts = acvae::conv_wino_partials_rows(N, H, W);
+      return acvae::conv3x3_wino(X, scale, shift, wbuf, Y, partials, N, H, W, Cin, Cout, st);
+    }
+  }
+  ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, (TA*)wbuf, nullptr, Cout, Cin, st));
+  *nparts = acvae::conv_partials_rows(N, H, W);
+  return acvae::conv3x3_igemm(X, scale, shift, (const TA*)wbuf, Y, partials, N, H, W, Cin, Cout, st);
+}
+// dX = conv3x3(dY, flipped / transposed W) for the layer Cin -> Cout
+template <class TA>
+int conv_dgrad(const TA* dY, const float* W_oihw, TA* wbuf, TA* dX, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  if constexpr (sizeof(TA) == 4) {
+    if (use_wino<TA>(H, W, Cout, Cin)) {
+      ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, (float*)wbuf, Cout, Cin, true, st));
+      return acvae::conv3x3_wino(dY, nullptr, nullptr, (const float*)wbuf, dX, nullptr, N, H, W, Cout, Cin, st);
+    }
+  }
+  ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, nullptr, wbuf, Cout, Cin, st));
+  return acvae::conv3x3_igemm(dY, nullptr, nullptr, (const TA*)wbuf, dX, nullptr, N, H, W, Cout, Cin, st);
+}
 
 struct BnPtrs { float *scale, *shift, *mean, *invstd; };
 inline BnPtrs bn_at(float* saved, const EncLayout& L, int i) {
@@ -188,18 +231,16 @@ int encoder_fwd_t(const void* const* params, const float* feats, float* audio_em
                                        N, T, F, st));
       np1 = acvae::conv1_first_blocks(N, T);
     } else {
-      ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 1)), (TA*)(saved + L.wf1[b]), nullptr, C, Cin, st));
-      ACVAE_TRY(acvae::conv3x3_igemm(x_in, nullptr, nullptr, (const TA*)(saved + L.wf1[b]), Y1,
-                                     training ? partials : nullptr, N, H, W, Cin, C, st));
-      np1 = acvae::conv_partials_rows(N, H, W);
+      ACVAE_TRY(conv_fwd<TA>(x_in, nullptr, nullptr, P(p_conv(b, 1)), saved + L.wf1[b], Y1, training ? partials : nullptr, N,
+                             H, W, Cin, C, &np1, st));
     }
     ACVAE_TRY(acvae::bn_finalize(partials, np1, C, cnt, P(p_bn(b, 1, 0)), P(p_bn(b, 1, 1)), P(p_bn(b, 1, 2)),
                                  P(p_bn(b, 1, 3)), (int64_t*)params[p_bn(b, 1, 4)], training, n1.scale, n1.shift,
                                  n1.mean, n1.invstd, dpart, st));
-    ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 2)), (TA*)(saved + L.wf2[b]), nullptr, C, C, st));
-    ACVAE_TRY(acvae::conv3x3_igemm((const TA*)Y1, n1.scale, n1.shift, (const TA*)(saved + L.wf2[b]), Y2,
-                                   training ? partials : nullptr, N, H, W, C, C, st));
-    ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_partials_rows(N, H, W), C, cnt, P(p_bn(b, 2, 0)),
+    int np2;
+    ACVAE_TRY(conv_fwd<TA>((const TA*)Y1, n1.scale, n1.shift, P(p_conv(b, 2)), saved + L.wf2[b], Y2,
+                           training ? partials : nullptr, N, H, W, C, C, &np2, st));
+    ACVAE_TRY(acvae::bn_finalize(partials, np2, C, cnt, P(p_bn(b, 2, 0)),
                                  P(p_bn(b, 2, 1)), P(p_bn(b, 2, 2)), P(p_bn(b, 2, 3)), (int64_t*)params[p_bn(b, 2, 4)],
                                  training, n2.scale, n2.shift, n2.mean, n2.invstd, dpart, st));
     ACVAE_TRY(acvae::bn_relu_pool<TA>(Y2, n2.scale, n2.shift, (TA*)(saved + L.p[b]), N, H, W, C,
@@ -285,8 +326,7 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
                             G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, training), st,
                             training != 0));
     ACVAE_TRY(acvae::conv3x3_wgrad((const TA*)dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
-    ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 2)), nullptr, wd, C, C, st));
-    ACVAE_TRY(acvae::conv3x3_igemm((const TA*)dya, nullptr, nullptr, (const TA*)wd, dyb, nullptr, N, H, W, C, C, st));
+    ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd, dyb, N, H, W, C, C, st));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
     ACVAE_TRY(acvae::bn_bwd<TA>(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
@@ -294,8 +334,7 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
     if (b > 1) {
       ACVAE_TRY(acvae::conv3x3_wgrad((const TA*)dya, (const TA*)(saved + L.p[b - 1]), nullptr, nullptr, G(p_conv(b, 1)),
                                      slab, N, H, W, Cin, C, st));
-      ACVAE_TRY(acvae::repack_weights<TA>(P(p_conv(b, 1)), nullptr, wd, C, Cin, st));
-      ACVAE_TRY(acvae::conv3x3_igemm((const TA*)dya, nullptr, nullptr, (const TA*)wd, dp_nxt, nullptr, N, H, W, C, Cin, st));
+      ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 1)), wd, dp_nxt, N, H, W, Cin, C, st));
       TA* t = dp_cur; dp_cur = dp_nxt; dp_nxt = t;
     } else {
       BnPtrs b0 = bn_at(saved, L, 0);

@@ -16,8 +16,10 @@ struct ConvWs {
 ConvWs conv_ws(int N, int H, int W, int Cin, int Cout) {
   ConvWs w;
   long o = 0;
-  w.wp = o; o = al64(o + (long)Cout * 9 * Cin);
-  const long part = Cin == 1 ? (long)acvae::conv1_first_blocks(N, H) * 128 : (long)acvae::conv_partials_rows(N, H, W) * 2 * Cout;
+  w.wp = o; o = al64(o + (long)Cout * 16 * Cin);     // 9: repacked taps; 16: Winograd positions
+  long part = Cin == 1 ? (long)acvae::conv1_first_blocks(N, H) * 128 : (long)acvae::conv_partials_rows(N, H, W) * 2 * Cout;
+  if (Cin > 1 && W >= 4 && W % 2 == 0 && (long)acvae::conv_wino_partials_rows(N, H, W) * 2 * Cout > part)
+    part = (long)acvae::conv_wino_partials_rows(N, H, W) * 2 * Cout;
   w.partials = o; o = al64(o + part);
   w.dpart = o; o = al64(o + 2 * acvae::colsum_scratch_doubles(2 * Cout > 1024 ? 2 * Cout : 1024));
   long slab = Cin == 1 ? (long)acvae::conv1_first_blocks(N, H) * (576 + 128)
@@ -96,6 +98,43 @@ extern "C" int acvae_conv3x3_wgrad(const float* dY, const float* X, const float*
   if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
   return acvae::conv3x3_wgrad(dY, X, in_scale, in_shift, dW_oihw, (float*)ws_v + L.slab, N, H, W, Cin, Cout,
                               (hipStream_t)stream);
+}
+
+// ---- Winograd F(2x2,3x3)
+extern "C" int acvae_conv3x3_fwd_wino(const float* X, const float* W_oihw, const float* in_scale, const float* in_shift,
+                                      float* Y, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, int training, float* bn_out,
+                                      void* ws_v, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream) {
+  if (!conv_dims_ok(N, H, W, Cin, Cout) || !X || !W_oihw || !Y || !ws_v) return ACVAE_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return ACVAE_EINVAL;
+  if (bn_out && (!gamma || !beta || !running_mean || !running_var)) return ACVAE_EINVAL;
+  if (!acvae::conv3x3_wino_ok(H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
+  const ConvWs L = conv_ws(N, H, W, Cin, Cout);
+  if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  if (!aligned16(ws_v)) return ACVAE_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)ws_v;
+  float* partials = (bn_out && training) ? ws + L.partials : nullptr;
+  ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, ws + L.wp, Cout, Cin, false, st));
+  ACVAE_TRY(acvae::conv3x3_wino(X, in_scale, in_shift, ws + L.wp, Y, partials, N, H, W, Cin, Cout, st));
+  if (bn_out)
+    ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_wino_partials_rows(N, H, W), Cout, (double)N * H * W, gamma, beta,
+                                 running_mean, running_var, num_batches_tracked, training, bn_out, bn_out + Cout,
+                                 bn_out + 2 * Cout, bn_out + 3 * Cout, (double*)(ws + L.dpart), st));
+  return ACVAE_OK;
+}
+
+extern "C" int acvae_conv3x3_dgrad_wino(const float* dY, const float* W_oihw, float* dX, void* ws_v, int64_t ws_bytes, int N,
+                                        int H, int W, int Cin, int Cout, void* stream) {
+  if (!conv_dims_ok(N, H, W, Cin, Cout) || !dY || !W_oihw || !dX || !ws_v) return ACVAE_EINVAL;
+  if (!acvae::conv3x3_wino_ok(H, W, Cout, Cin)) return ACVAE_EUNSUPPORTED;
+  const ConvWs L = conv_ws(N, H, W, Cin, Cout);
+  if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  if (!aligned16(ws_v)) return ACVAE_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)ws_v;
+  ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, ws + L.wp, Cout, Cin, true, st));
+  return acvae::conv3x3_wino(dY, nullptr, nullptr, ws + L.wp, dX, nullptr, N, H, W, Cout, Cin, st);
 }
 
 // ---- bf16 storage

@@ -221,6 +221,16 @@ int acvae_conv3x3_wgrad(const float* dY, const float* X, const float* in_scale, 
                         void* ws, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
 int acvae_conv1_first_bwd(const float* x, const float* bn0, const float* W1_oihw, const float* dY, float* dW1,
                           float* dgamma0, float* dbeta0, void* ws, int64_t ws_bytes, int N, int T, int F, void* stream);
+/* Winograd F(2x2,3x3) forms of the forward convolution and the data gradient (conv_wino.hip): same contracts, fp32
+ * throughout, 2.25x fewer matrix-pipe flops; results differ from the implicit-GEMM forms by fp32 rounding only.
+ * W a power of two in 4..64, Cin % 16 == 0, Cout % 64 == 0 (dgrad: the roles of Cin / Cout swap), otherwise
+ * ACVAE_EUNSUPPORTED.  Same workspace. */
+int acvae_conv3x3_fwd_wino(const float* X, const float* W_oihw, const float* in_scale, const float* in_shift, float* Y,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, int training, float* bn_out, void* ws, int64_t ws_bytes, int N,
+                           int H, int W, int Cin, int Cout, void* stream);
+int acvae_conv3x3_dgrad_wino(const float* dY, const float* W_oihw, float* dX, void* ws, int64_t ws_bytes, int N, int H,
+                             int W, int Cin, int Cout, void* stream);
 /* bf16-storage forms of the three convolutions (acvae_encoder_* with ACVAE_ENC_BF16): X / dY / dX / Y are bf16 NHWC
  * (uint16 bit patterns, round-to-nearest-even), weights OIHW fp32 (rounded to bf16 inside), dW fp32.  Cin % 64 == 0.
  * acvae_conv3x3_fwd_bf16 returns this layer's BatchNorm in bn_out exactly like the fp32 form, from the statistics of the

@@ -118,6 +118,63 @@ def test_conv3x3_real_block_geometry():
         run_conv(N, H, W, Cin, Cout, False, seed=8)
 
 
+def run_conv_wino(N, H, W, Cin, Cout, act, seed=0):
+    """Winograd F(2x2,3x3) forms (conv_wino.hip): same fp64 reference, same element-wise bound as the implicit GEMM (the
+    transforms only add and halve; measured errors are a third of the implicit GEMM's: 16 products per output, not 36)."""
+    x, w, dy, sc, sh, y_ref, dx_ref, _ = conv_case(N, H, W, Cin, Cout, act, seed)
+    wsb = _lib.call("acvae_conv3x3_workspace_bytes", N, H, W, Cin, Cout)
+    ws = ws_buf(wsb)
+    xd, wd, dyd = nhwc(x).cuda(), w.cuda().contiguous(), nhwc(dy).cuda()
+    scd = None if sc is None else sc.cuda()
+    shd = None if sh is None else sh.cuda()
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    gamma, beta = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    bn = torch.empty(4, Cout, device="cuda")
+    _lib.call("acvae_conv3x3_fwd_wino", xd, wd, scd, shd, y, gamma, beta, rm, rv, nbt, 1, bn, ws, wsb, N, H, W, Cin, Cout, S())
+    assert_every_element(y, nhwc(y_ref), 9 * Cin, f"wino fwd {Cin}->{Cout} {N}x{H}x{W} act={act}")
+    # the fused batch statistics: mean / invstd of the raw output, running buffers with the unbiased variance
+    yr = nhwc(y_ref)
+    cnt = N * H * W
+    mean, var = yr.mean(dim=(0, 1, 2)), yr.var(dim=(0, 1, 2), unbiased=False)
+    rms = float(yr.pow(2).mean().sqrt())
+    assert float((bn[2].cpu().double() - mean).abs().max()) <= 1e-5 * rms
+    assert torch.allclose(bn[3].cpu().double(), 1 / torch.sqrt(var + 1e-5), rtol=1e-4, atol=0)
+    assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * var * cnt / (cnt - 1), rtol=1e-4, atol=1e-6)
+    assert int(nbt) == 1
+    if not act:
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        _lib.call("acvae_conv3x3_dgrad_wino", dyd, wd, dx, ws, wsb, N, H, W, Cin, Cout, S())
+        assert_every_element(dx, nhwc(dx_ref), 9 * Cout, f"wino dgrad {Cin}->{Cout} {N}x{H}x{W}")
+
+
+WINO_SHAPES = [(3, 7, 4), (2, 33, 8), (2, 9, 16)]      # odd H (half-empty last tile row), several / partial row blocks
+
+
+@pytest.mark.parametrize("Cin,Cout", LAYERS)
+def test_conv3x3_winograd_every_layer_shape_vs_fp64(Cin, Cout):
+    shapes = WINO_SHAPES if Cin <= 512 else WINO_SHAPES[:1]
+    for i, (N, H, W) in enumerate(shapes):
+        for act in (False, True):
+            run_conv_wino(N, H, W, Cin, Cout, act, seed=100 * Cin + 10 * i + int(act))
+
+
+def test_conv3x3_winograd_real_block_geometry():
+    """Row lengths of the real stack (W = 64 .. 4): 2 .. 16 tile rows per workgroup, clips that end inside a row block,
+    odd heights, N > 1; and what the kernel refuses."""
+    for (N, H, W, Cin, Cout) in [(2, 11, 64, 64, 64), (3, 9, 32, 64, 128), (2, 37, 16, 128, 256), (2, 37, 8, 256, 512),
+                                 (3, 21, 4, 512, 512), (1, 250, 16, 128, 128), (2, 125, 8, 64, 64)]:
+        run_conv_wino(N, H, W, Cin, Cout, True, seed=7)
+        run_conv_wino(N, H, W, Cin, Cout, False, seed=8)
+    ws = ws_buf(1 << 20)
+    t = torch.zeros(1 << 16, device="cuda")
+    for (H, W, Cin, Cout) in [(8, 6, 64, 64), (8, 2, 64, 64), (8, 8, 24, 64), (8, 8, 64, 96)]:
+        with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+            _lib.call("acvae_conv3x3_fwd_wino", t, t, None, None, t, None, None, None, None, None, 0, None, ws, 1 << 20, 1, H,
+                      W, Cin, Cout, S())
+
+
 def test_conv3x3_kernel_variants_behind_the_switches():
     """ACVAE_CONV_STRIP = 0 / 1 / 3 and ACVAE_WGRAD_STRIP = 0 / 3 select the predecessor kernels (one tap per stage,
     register-staged panels, LDS-DMA strip; one-tap-per-tile weight gradient): same element-wise bound.  The switches are
