@@ -22,6 +22,7 @@
 #include "../../include/acvae_hip.h"
 #include "conv.h"
 #include "prof.h"
+#include <type_traits>
 
 namespace {
 using namespace mfma;
@@ -32,10 +33,12 @@ constexpr int WN_TN = 64;         // output channels per workgroup
 constexpr int WN_RAWMAX = 100;    // float4 slots per (channel quad, parity plane): (R+1)*(TW+1) <= 99
 constexpr int WN_BCHUNK = 16 * 2 * 64;   // float4 per weight chunk image: [position][k half][column]
 
-struct alignas(16) WinoSmem {
-  float4 raw[2][16 * WN_RAWMAX];   // [stage buffer][(quad*4 + plane)*WN_RAWMAX + row*(TW+1) + col]     51200 B
-  float4 b[2][WN_BCHUNK];          // [chunk buffer][(pos*2 + h)*64 + col]                              65536 B
-};
+// LDS: four separate arrays, not one struct with a run-time buffer index: the compiler orders an LDS-DMA against later
+// LDS reads of the SAME wave by itself and waits (vmcnt) before any read it cannot prove disjoint from the DMA's
+// destination - with distinct __shared__ objects selected at compile time (loop unrolled over the buffer parities) the
+// reads of chunk c no longer wait for the DMA of chunk c + 1 issued just before them.
+constexpr int WN_RAWBUF = 16 * WN_RAWMAX;   // float4 per stage buffer: [(quad*4 + plane)*WN_RAWMAX + row*(TW+1) + col]   25600 B
+                                            // weight chunk buffer: [(pos*2 + h)*64 + col]                               32768 B
 
 struct WinoParams {
   const float* X;       // [N][H][W][C]
@@ -52,12 +55,20 @@ struct WinoParams {
 
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+}
 
-__device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm) {
+// XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
+template <int XH>
+__device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
-  // wavefront roles: xh = position half (vertical frequencies {0,1} / {3,2}), mh = tile half, nh = column half
-  const int xh = wave & 1, mh = (wave >> 1) & 1, nh = wave >> 2;
+  // wavefront roles: XH = wave & 1, mh = tile half, nh = column half
+  const int mh = (wave >> 1) & 1, nh = wave >> 2;
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
   const int TW = 1 << p.tw_shift, RW = TW + 1, R = p.R;
@@ -90,7 +101,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
 #pragma unroll
     for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
   };
-  auto put_raw = [&](int st, int buf) {
+  auto put_raw = [&](int st, float4* raw) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool act = p.scale != nullptr;
     if (act) {
@@ -105,15 +116,15 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
         v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
       }
       if (!((okm >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding / rows of another clip
-      if ((live >> j) & 1u) sm.raw[buf][loff[j]] = v;
+      if ((live >> j) & 1u) raw[loff[j]] = v;
     }
   };
   // weight chunk c: 32 KB, already in LDS order; one LDS-DMA instruction of a wave moves 1 KB
   const int nchunk = C >> 3;
   const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
-  auto fetch_b = [&](int c, int buf) {
+  auto fetch_b = [&](int c, float4* bw) {
     const float* src = Ub + (long)c * (WN_BCHUNK * 4);
-    float* dst = reinterpret_cast<float*>(&sm.b[buf][0]) + wave * 256;
+    float* dst = reinterpret_cast<float*>(bw) + wave * 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 2048, dst + i * 2048, 16, 0, 0);
   };
@@ -121,13 +132,13 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
   // ---------------------------------------------------------------- this lane's tile and fragment addresses
   const int m = mh * 32 + li;
   const int abase = (m >> p.tw_shift) * RW + (m & (TW - 1));
-  int rowoff[3];      // window rows xh, xh+1, xh+2 of the tile: plane (row parity) and row index
+  int rowoff[3];      // window rows XH, XH+1, XH+2 of the tile: plane (row parity) and row index
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const int i = xh + a;
+    const int i = XH + a;
     rowoff[a] = (i & 1) * 2 * WN_RAWMAX + (i >> 1) * RW + abase;
   }
-  const int xi0 = xh ? 3 : 0, xi1 = xh ? 2 : 1;     // vertical frequencies of local positions 0..3 / 4..7
+  constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;     // vertical frequencies of local positions 0..3 / 4..7
   const int bcol = h * 64 + nh * 32 + li;
 
   f32x16 acc[8];
@@ -136,16 +147,10 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  auto mfma4 = [&](f32x16& c, float4 a, float4 b) {
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
-  };
   // K-step j of a chunk pairs channel c0 + j (lanes 0-31) with c0 + 4 + j (lanes 32-63): quad 2*sub + h
-  auto compute = [&](int rawbuf, int sub, int bbuf) {
-    const float4* rq = &sm.raw[rawbuf][(2 * sub + h) * 4 * WN_RAWMAX];
-    const float4* bq = &sm.b[bbuf][bcol];
+  auto compute = [&](const float4* raw, int sub, const float4* bw) {
+    const float4* rq = raw + (2 * sub + h) * 4 * WN_RAWMAX;
+    const float4* bq = bw + bcol;
     float4 d[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -157,8 +162,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (xl == 0) t[j] = f4sub(d[0][j], d[2][j]);                // frequency 0 (rows 0,2) / 3 (rows 1,3)
-        else t[j] = xh ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);   // frequency 1: r1 + r2 / 2: r2 - r1
+        else t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);   // frequency 1: r1 + r2 / 2: r2 - r1
       }
+      constexpr int dummy = 0; (void)dummy;
       const int xi = xl ? xi1 : xi0;
       const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
       const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
@@ -169,26 +175,41 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
     }
   };
 
-  // ---------------------------------------------------------------- main loop: one barrier per 8-channel chunk
+  // ---------------------------------------------------------------- main loop: one barrier per 8-channel chunk,
+  // unrolled over (stage parity, chunk of the stage) so that every buffer is a compile-time object
   const int nstage = C >> 4;
   issue_raw(0);
-  fetch_b(0, 0);
-  put_raw(0, 0);
+  fetch_b(0, bw0);
+  put_raw(0, raw0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int st = c >> 1, sub = c & 1;
-    if (c + 1 < nchunk) fetch_b(c + 1, (c + 1) & 1);       // its last readers (chunk c - 1) are behind the barrier
+  auto step = [&](int c, auto kk) {
+    constexpr int K = decltype(kk)::value;            // c % 4
+    constexpr int sub = K & 1, sp = K >> 1;
+    const int st = c >> 1;
+    float4* const bcur = sub ? bw1 : bw0;
+    float4* const bnxt = sub ? bw0 : bw1;
+    float4* const rcur = sp ? raw1 : raw0;
+    float4* const rnxt = sp ? raw0 : raw1;
+    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);              // its last readers (chunk c - 1) are behind the barrier
     if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);    // in flight for this chunk and the next
-    compute(st & 1, sub, c & 1);
-    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, (st + 1) & 1);   // that buffer's last readers: stage st - 1
+    compute(rcur, sub, bcur);
+    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);   // that buffer's last readers: stage st - 1
     // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  };
+  for (int c = 0; c < nchunk; c += 4) {
+    step(c, std::integral_constant<int, 0>());
+    step(c + 1, std::integral_constant<int, 1>());
+    if (c + 2 < nchunk) {
+      step(c + 2, std::integral_constant<int, 2>());
+      step(c + 3, std::integral_constant<int, 3>());
+    }
   }
 
   // ---------------------------------------------------------------- epilogue: At . A, position halves meet through LDS
-  float* ex = reinterpret_cast<float*>(&sm.b[0][0]);        // [wave][32][64 lanes] = 64 KB
+  float* ex = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
   float keep[16][2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -202,8 +223,8 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const float s = hl[0][b] + hl[1][b];
-      keep[r][b] = xh ? -s : s;
-      ex[(wave * 32 + r * 2 + b) * 64 + lane] = hl[1][b];
+      keep[r][b] = XH ? -s : s;
+      ex[((wave & 3) * 32 + r * 2 + b) * 64 + lane] = hl[1][b];
     }
   }
   __syncthreads();
@@ -212,10 +233,10 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int mt = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int y = 2 * (ty0 + (mt >> p.tw_shift)) + xh;       // this wave finishes output row xh of its tiles
+    const int y = 2 * (ty0 + (mt >> p.tw_shift)) + XH;       // this wave finishes output row XH of its tiles
     const int x = 2 * (mt & (TW - 1));
-    const float o0 = keep[r][0] + ex[((wave ^ 1) * 32 + r * 2 + 0) * 64 + lane];
-    const float o1 = keep[r][1] + ex[((wave ^ 1) * 32 + r * 2 + 1) * 64 + lane];
+    const float o0 = keep[r][0] + ex[(((wave & 3) ^ 1) * 32 + r * 2 + 0) * 64 + lane];
+    const float o1 = keep[r][1] + ex[(((wave & 3) ^ 1) * 32 + r * 2 + 1) * 64 + lane];
     if (y < H) {
       float* out = p.Y + ((long)(n * H + y) * W + x) * p.Cout + cout;
       out[0] = o0;
@@ -225,12 +246,12 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
     }
   }
   if (p.partials) {
-    float* red = reinterpret_cast<float*>(&sm.raw[0][0]);   // [4 waves of a column half][2][64]
+    float* red = reinterpret_cast<float*>(raw0);   // [4 waves of a column half][2][64]
     s += __shfl_xor(s, 32, 64);
     qq += __shfl_xor(qq, 32, 64);
     if (h == 0) {
-      red[((mh * 2 + xh) * 2 + 0) * 64 + nh * 32 + li] = s;
-      red[((mh * 2 + xh) * 2 + 1) * 64 + nh * 32 + li] = qq;
+      red[((mh * 2 + XH) * 2 + 0) * 64 + nh * 32 + li] = s;
+      red[((mh * 2 + XH) * 2 + 1) * 64 + nh * 32 + li] = qq;
     }
     __syncthreads();
     if (tid < WN_TN) {
@@ -245,8 +266,10 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, WinoSmem& sm
 }
 
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(WinoParams p) {
-  __shared__ WinoSmem sm;
-  conv_wino_body(p, sm);
+  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
+  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
+  if ((threadIdx.x >> 6) & 1) conv_wino_body<1>(p, raw0, raw1, bw0, bw1);
+  else conv_wino_body<0>(p, raw0, raw1, bw0, bw1);
 }
 
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
