@@ -27,18 +27,41 @@
 namespace {
 using namespace mfma;
 
+#ifndef WN_ABL
+#define WN_ABL 0
+#endif
 constexpr int WN_THREADS = 512;
 constexpr int WN_TILES = 64;      // output tiles (2x2 pixels each) per workgroup
 constexpr int WN_TN = 64;         // output channels per workgroup
-constexpr int WN_RAWMAX = 100;    // float4 slots per (channel quad, parity plane): (R+1)*(TW+1) <= 99
+// activation window in LDS, float4 slots: [quad WN_SQ][row parity WN_SR][column parity WN_SC][row (R+1)][col RW]; a plane
+// holds (R+1)*RW <= 99 slots.  The strides are padded so that the 16 lanes of a staging write (4 pixels x 4 quads) land in
+// 16 different 16-byte bank groups: WN_SC = 2 (mod 4) spreads the 4 pixels, WN_SQ = 4 (mod 16) the quads.
+constexpr int WN_SC = 102, WN_SR = 2 * WN_SC, WN_SQ = 420;
 constexpr int WN_BCHUNK = 16 * 2 * 64;   // float4 per weight chunk image: [position][k half][column]
 
 // LDS: four separate arrays, not one struct with a run-time buffer index: the compiler orders an LDS-DMA against later
 // LDS reads of the SAME wave by itself and waits (vmcnt) before any read it cannot prove disjoint from the DMA's
 // destination - with distinct __shared__ objects selected at compile time (loop unrolled over the buffer parities) the
 // reads of chunk c no longer wait for the DMA of chunk c + 1 issued just before them.
-constexpr int WN_RAWBUF = 16 * WN_RAWMAX;   // float4 per stage buffer: [(quad*4 + plane)*WN_RAWMAX + row*(TW+1) + col]   25600 B
-                                            // weight chunk buffer: [(pos*2 + h)*64 + col]                               32768 B
+constexpr int WN_RAWBUF = 4 * WN_SQ;        // float4 per stage buffer (26880 B); weight chunk buffer: [(pos*2 + h)*64 + col] (32768 B)
+
+// Tile (row of the block, column) of row `row` (0..31) of tile half mh.  A ds_read_b128 is served 16 lanes at a time; those
+// 16 tiles must sit in 16 different 16-byte bank groups.  TW >= 16: they are 16 neighbours of one tile row.  TW < 16: the
+// group takes 16/TW tile rows `rstep` apart, chosen with the row pitch RW so that their slots tile the 256-byte bank span
+// (TW = 8: RW = 10, rows r, r+4 -> 0 / 128 B; TW = 4: RW = 5, rows r+4k -> 64 B apart; TW = 2: RW = 3, rows r+2k -> 32 B).
+__device__ __forceinline__ void wino_tile(int mh, int row, int tw_shift, int& tyl, int& tx) {
+  if (tw_shift >= 4) {
+    const int m = mh * 32 + row;
+    tyl = m >> tw_shift;
+    tx = m & ((1 << tw_shift) - 1);
+  } else {
+    const int g = row >> 4, l16 = row & 15;
+    tx = l16 & ((1 << tw_shift) - 1);
+    const int rsel = l16 >> tw_shift;
+    tyl = tw_shift == 1 ? mh * 16 + g + 2 * rsel : mh * 2 + g + 4 * rsel;
+  }
+}
+__host__ __device__ __forceinline__ int wino_row_pitch(int tw_shift) { return tw_shift == 3 ? 10 : (1 << tw_shift) + 1; }
 
 struct WinoParams {
   const float* X;       // [N][H][W][C]
@@ -71,7 +94,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   const int mh = (wave >> 1) & 1, nh = wave >> 2;
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  const int TW = 1 << p.tw_shift, RW = TW + 1, R = p.R;
+  const int RW = wino_row_pitch(p.tw_shift), R = p.R;
   const int n = bm / p.bpc, ty0 = (bm - n * p.bpc) * R;
   const int H = p.H, W = p.W, C = p.C;
 
@@ -94,7 +117,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     live |= (lv ? 1u : 0u) << j;
     okm |= (ok ? 1u : 0u) << j;
     goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;     // always a legal address
-    loff[j] = (q * 4 + (ry & 1) * 2 + (rx & 1)) * WN_RAWMAX + (ry >> 1) * RW + (rx >> 1);
+    loff[j] = q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1);
   }
   float4 pv[4];
   auto issue_raw = [&](int st) {
@@ -130,13 +153,14 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   };
 
   // ---------------------------------------------------------------- this lane's tile and fragment addresses
-  const int m = mh * 32 + li;
-  const int abase = (m >> p.tw_shift) * RW + (m & (TW - 1));
+  int tyl_a, tx_a;
+  wino_tile(mh, li, p.tw_shift, tyl_a, tx_a);
+  const int abase = tyl_a * RW + tx_a;
   int rowoff[3];      // window rows XH, XH+1, XH+2 of the tile: plane (row parity) and row index
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int i = XH + a;
-    rowoff[a] = (i & 1) * 2 * WN_RAWMAX + (i >> 1) * RW + abase;
+    rowoff[a] = (i & 1) * WN_SR + (i >> 1) * RW + abase;
   }
   constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;     // vertical frequencies of local positions 0..3 / 4..7
   const int bcol = h * 64 + nh * 32 + li;
@@ -147,15 +171,26 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+#if WN_ABL >= 1
+  const float4 abl = *reinterpret_cast<const float4*>(p.U + lane * 4);
+#endif
   // K-step j of a chunk pairs channel c0 + j (lanes 0-31) with c0 + 4 + j (lanes 32-63): quad 2*sub + h
   auto compute = [&](const float4* raw, int sub, const float4* bw) {
-    const float4* rq = raw + (2 * sub + h) * 4 * WN_RAWMAX;
+    const float4* rq = raw + (2 * sub + h) * WN_SQ;
     const float4* bq = bw + bcol;
     float4 d[3][4];
+#if WN_ABL >= 1          // ablation (tools/wino_ablate.sh): no activation reads
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_RAWMAX + (j >> 1)];
+      for (int j = 0; j < 4; ++j) d[a][j] = make_float4(abl.x + a, abl.y + j, abl.z, abl.w);
+    (void)rq;
+#else
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_SC + (j >> 1)];
+#endif
 #pragma unroll
     for (int xl = 0; xl < 2; ++xl) {
       float4 t[4];
@@ -166,8 +201,13 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
       }
       constexpr int dummy = 0; (void)dummy;
       const int xi = xl ? xi1 : xi0;
+#if WN_ABL >= 2          // no weight-fragment reads either
+      const float4 b0 = abl, b1 = abl, b2 = abl, b3 = abl;
+      (void)bq; (void)xi;
+#else
       const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
       const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
+#endif
       mfma4(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0);
       mfma4(acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
       mfma4(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2);
@@ -191,10 +231,17 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     float4* const bnxt = sub ? bw0 : bw1;
     float4* const rcur = sp ? raw1 : raw0;
     float4* const rnxt = sp ? raw0 : raw1;
+#if WN_ABL < 3           // 3: no global traffic in the loop at all
     if (c + 1 < nchunk) fetch_b(c + 1, bnxt);              // its last readers (chunk c - 1) are behind the barrier
     if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);    // in flight for this chunk and the next
+#endif
     compute(rcur, sub, bcur);
+#if WN_ABL < 3
     if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);   // that buffer's last readers: stage st - 1
+#endif
+#if WN_ABL >= 4          // 4: no barrier either
+    return;
+#endif
     // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -232,9 +279,10 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   float s = 0.f, qq = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int mt = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int y = 2 * (ty0 + (mt >> p.tw_shift)) + XH;       // this wave finishes output row XH of its tiles
-    const int x = 2 * (mt & (TW - 1));
+    int tyl, tx;
+    wino_tile(mh, (r & 3) + 8 * (r >> 2) + 4 * h, p.tw_shift, tyl, tx);
+    const int y = 2 * (ty0 + tyl) + XH;       // this wave finishes output row XH of its tiles
+    const int x = 2 * tx;
     const float o0 = keep[r][0] + ex[(((wave & 3) ^ 1) * 32 + r * 2 + 0) * 64 + lane];
     const float o1 = keep[r][1] + ex[(((wave & 3) ^ 1) * 32 + r * 2 + 1) * 64 + lane];
     if (y < H) {
