@@ -221,8 +221,10 @@ def main():
                 traffic = None
         bf16 = args.dtype == "bf16"
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        wino = not bf16 and os.environ.get("ACVAE_CONV_WINO", "1") != "0"
         kernel = ("conv_igemm_bf16_kernel (conv3x3 implicit GEMM fwd+dgrad, v_mfma_f32_32x32x16_bf16, bf16 activations)"
                   if bf16 else
+                  "conv_wino_kernel (conv3x3 fwd+dgrad as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)" if wino else
                   "conv_igemm3_kernel (conv3x3 implicit GEMM fwd+dgrad with horizontal-tap reuse, fp32 MFMA)")
         which = ("BASELINE configs[2] per-GPU shape (bf16 forward / fp32 loss)" if bf16 else "BASELINE configs[1]")
         out = {
@@ -245,6 +247,13 @@ def main():
                          "algorithmic_gflop_per_launch": flops_per_step / 1e9 / max(1.0, launches_per_step),
                          "wgrad_avg_launch_ms": wgrad_ms / max(1, wgrad_n), "wgrad_launches_per_step": wgrad_n / max(1, sampled), "steps_sampled": sampled},
         }
+        if wino:
+            # `achieved` counts the ALGORITHMIC flops of the convolution (2 x 9 x Cin x Cout per pixel); the
+            # Winograd kernel issues 16/36 of them to the matrix pipe, so its pipe utilisation is executed_frac
+            out["roofline"]["executed_tflops"] = achieved / 2.25
+            out["roofline"]["executed_frac"] = achieved / 2.25 / peak
+            out["roofline"]["note"] = ("achieved/frac = algorithmic direct-convolution flops over measured time (can exceed 1: "
+                                       "F(2x2,3x3) needs 2.25x fewer multiplies); executed_* = flops actually issued to the MFMA pipe")
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
