@@ -38,6 +38,10 @@ int conv_wino_partials_rows(int N, int H, int W);
 int conv3x3_wino_weights(const float* W_oihw, float* U, int Cout, int Cin, bool dgrad, hipStream_t st);
 int conv3x3_wino(const float* X, const float* scale, const float* shift, const float* U, float* Y, float* partials, int N,
                  int H, int W, int Cin, int Cout, hipStream_t st);
+bool conv3x3_wino_wgrad_ok(int H, int W, int Cin, int Cout);
+long conv3x3_wino_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout);     // 0 when the shape is not taken
+int conv3x3_wino_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
+                       int N, int H, int W, int Cin, int Cout, hipStream_t st);
 // T = float or bf16_t (storage type of activations / repacked weights; arithmetic is fp32 either way)
 template <class T>
 int repack_weights(const float* W_oihw, T* Wf, T* Wd, int Cout, int Cin, hipStream_t st);

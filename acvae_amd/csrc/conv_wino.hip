@@ -408,3 +408,299 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
 }
 
 }  // namespace acvae
+
+namespace {
+using namespace mfma;
+// =====================================================================================================================
+// Weight gradient as Winograd F(2x2, 3x3):   dW = G^T [ sum_tiles (Bt d B) .* (A dY_tile A^T) ] G
+//   d: 4x4 window of act(X) around the tile, dY_tile: the 2x2 output gradients of the tile, A = At^T.
+// 16 GEMMs [Cin x tiles] x [tiles x Cout] (K = tiles = pixels / 4), again 16/36 of the implicit GEMM's multiplies.  One
+// workgroup owns a 64 x 64 (ci, co) block of all 16 positions (the same 65536 accumulators as the forward kernel) over a
+// contiguous range of 16-tile stages; the K split over workgroups goes through fp32 slabs [z][16][Cin][Cout] that
+// wino_wgrad_reduce_kernel sums in fixed order (in double) and folds through G^T . G into dW[co][ci][3][3].
+//   * both operands are transforms of raw data and are built in registers: per pair of tiles (one MFMA k-step: lanes
+//     0-31 take the even tile, 32-63 the odd one) a lane reads its channel of 12 window pixels and 4 gradient pixels
+//     (ds_read_b32, channel-contiguous over lanes) and spends 22 adds for 8 MFMAs; all signs of A and Bt are folded into
+//     the order of subtractions;
+//   * LDS holds the raw window [pixel][64 ci] and the gradients [tile][2x2][64 co]; the channel index is XOR-ed with 32
+//     for odd tile columns / odd tiles so that the two lane halves of a read never meet in a bank.
+constexpr int WG_XW_PIX = 136;                 // window pixels per stage: 4 x 34 (W >= 32) .. 10 x 10 (W = 8)
+constexpr int WG_XW_WORDS = WG_XW_PIX * 64;
+constexpr int WG_DY_WORDS = 16 * 4 * 64;
+
+struct WinoWgradParams {
+  const float* dY;      // [N][H][W][Cout]
+  const float* X;       // [N][H][W][Cin]
+  const float* scale;   // nullable: X is used as is
+  const float* shift;
+  float* slab;          // [Z][16][Cin][Cout]
+  int N, H, W, Cin, Cout;
+  int st_shift;         // tiles per stage row = 1 << st_shift = min(W/2, 16)
+  int RS;               // tile rows per stage = 16 >> st_shift
+  int segs;             // stages per tile row (W = 64: 2) else 1
+  int spc;              // stages per clip
+  int total;            // N * spc
+  int per;              // stages per workgroup
+};
+
+template <int XH>
+__device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float* xw0, float* xw1, float* dy0, float* dy1) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int ah = (wave >> 1) & 1, bh = wave >> 2;       // ci half, co half of this wavefront; XH = wave & 1
+  const int z = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
+  const int H = p.H, W = p.W;
+  const int STW = 1 << p.st_shift, WC = 2 * STW + 2, WR = 2 * p.RS + 2;
+  const int g_begin = z * p.per, g_end = min(p.total, g_begin + p.per);
+
+  // ---------------------------------------------------------------- staging items (window coordinates are per thread)
+  const int quad = tid & 15;
+  int xyx[5], xlo[5];        // window (row << 8 | column) and LDS word of the thread's items
+  unsigned xlive = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int e = tid + 512 * j, wp = e >> 4;
+    const bool lv = wp < WR * WC;
+    xlive |= (lv ? 1u : 0u) << j;
+    const int wy = wp / WC, wx = wp - wy * WC;
+    xyx[j] = (wy << 8) | wx;
+    xlo[j] = wp * 64 + ((quad * 4) ^ (32 * ((wx >> 1) & 1)));
+  }
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool act = p.scale != nullptr;
+  if (act) {
+    sc = *reinterpret_cast<const float4*>(p.scale + cib * 64 + quad * 4);
+    sh = *reinterpret_cast<const float4*>(p.shift + cib * 64 + quad * 4);
+  }
+  float4 px[5], py[2];
+  unsigned xok = 0, yok = 0;
+  auto issue = [&](int g) {
+    const int n = g / p.spc, s = g - n * p.spc;
+    const int trow = s / p.segs, seg = s - trow * p.segs;
+    const int ty0 = trow * p.RS, tx0 = seg * 16;          // first tile of the stage
+    xok = 0; yok = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int y = 2 * ty0 - 1 + (xyx[j] >> 8), x = 2 * tx0 - 1 + (xyx[j] & 255);
+      const bool ok = ((xlive >> j) & 1u) && y >= 0 && y < H && x >= 0 && x < W;
+      xok |= (ok ? 1u : 0u) << j;
+      const long off = ok ? ((long)(n * H + y) * W + x) * p.Cin + cib * 64 + quad * 4 : 0;
+      px[j] = *reinterpret_cast<const float4*>(p.X + off);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tp = (tid + 512 * j) >> 4, t = tp >> 2, pp = tp & 3;
+      const int y = 2 * (ty0 + (t >> p.st_shift)) + (pp >> 1), x = 2 * (tx0 + (t & (STW - 1))) + (pp & 1);
+      const bool ok = y < H;                               // tile rows past the image (odd H / last stage) contribute 0
+      yok |= (ok ? 1u : 0u) << j;
+      const long off = ok ? ((long)(n * H + y) * W + x) * p.Cout + cob * 64 + quad * 4 : 0;
+      py[j] = *reinterpret_cast<const float4*>(p.dY + off);
+    }
+  };
+  auto put = [&](float* xw, float* dys) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float4 v = px[j];
+      if (act) {
+        v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+        v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+      }
+      if (!((xok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((xlive >> j) & 1u) *reinterpret_cast<float4*>(xw + xlo[j]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tp = (tid + 512 * j) >> 4, t = tp >> 2;
+      float4 v = py[j];
+      if (!((yok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dys + tp * 64 + ((quad * 4) ^ (32 * (t & 1)))) = v;
+    }
+  };
+
+  // ---------------------------------------------------------------- fragment addresses of this lane
+  const int ci = ah * 32 + li, co = bh * 32 + li;
+  const int ci_s0 = ci, ci_s1 = ci ^ 32;                  // channel word for an even / odd tile-column parity
+  const int rowstride = WC * 64;
+  const int bbase = kh * 256 + (co ^ (32 * kh));
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  auto compute = [&](const float* xw, const float* dys) {
+#pragma unroll 2
+    for (int j = 0; j < 8; ++j) {
+      const int t = 2 * j + kh;                            // this lane half's tile of the k-step
+      const int tyl = t >> p.st_shift, txl = t & (STW - 1);
+      const float* xb = xw + ((2 * tyl + XH) * WC + 2 * txl) * 64;
+      // window columns 0,1 have the tile's own column parity, columns 2,3 the other one
+      const int c01 = (txl & 1) ? ci_s1 : ci_s0, c23 = (txl & 1) ? ci_s0 : ci_s1;
+      float d[3][4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        d[a][0] = xb[a * rowstride + 0 * 64 + c01];
+        d[a][1] = xb[a * rowstride + 1 * 64 + c01];
+        d[a][2] = xb[a * rowstride + 2 * 64 + c23];
+        d[a][3] = xb[a * rowstride + 3 * 64 + c23];
+      }
+      const float* yb = dys + bbase + j * 512;
+      const float y00 = yb[0], y01 = yb[64], y10 = yb[128], y11 = yb[192];
+      // local position half 0: frequency 0 (XH = 0: rows 0,2; gradient row 0) / 3 (XH = 1: sign folded: rows 3 - 1; row 1)
+      // local position half 1: frequency 1 (rows 1 + 2; gradient rows 0 + 1) / 2 (rows 2 - 1; rows 0 - 1)
+      float t0[4], t1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        t0[c] = XH ? d[2][c] - d[0][c] : d[0][c] - d[2][c];
+        t1[c] = XH ? d[1][c] - d[0][c] : d[1][c] + d[2][c];
+      }
+      const float r00 = XH ? y10 : y00, r01 = XH ? y11 : y01;
+      const float r10 = XH ? y00 - y10 : y00 + y10, r11 = XH ? y01 - y11 : y01 + y11;
+      // horizontal: v = [t0 - t2, t1 + t2, t2 - t1, t3 - t1] against dm = [r0, r0 + r1, r0 - r1, r1] (the minus of A's last row
+      // sits in v[3])
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[0] - t0[2], r00, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[1] + t0[2], r00 + r01, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[2] - t0[1], r00 - r01, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[3] - t0[1], r01, acc[3], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[0] - t1[2], r10, acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[1] + t1[2], r10 + r11, acc[5], 0, 0, 0);
+      acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[2] - t1[1], r10 - r11, acc[6], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[3] - t1[1], r11, acc[7], 0, 0, 0);
+    }
+  };
+
+  // ---------------------------------------------------------------- main loop: one barrier per 16-tile stage
+  if (g_begin < g_end) {
+    issue(g_begin);
+    put(xw0, dy0);
+    __syncthreads();
+    for (int g = g_begin; g < g_end; g += 2) {
+      if (g + 1 < g_end) issue(g + 1);
+      compute(xw0, dy0);
+      if (g + 1 < g_end) put(xw1, dy1);                   // last read at stage g - 1, behind the barrier
+      __syncthreads();
+      if (g + 1 < g_end) {
+        if (g + 2 < g_end) issue(g + 2);
+        compute(xw1, dy1);
+        if (g + 2 < g_end) put(xw0, dy0);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- slab: [z][position][ci][co]
+  constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int pos = ((q >> 2) ? xi1 : xi0) * 4 + (q & 3);
+    float* out = p.slab + (((long)z * 16 + pos) * p.Cin + cib * 64 + ah * 32) * p.Cout + cob * 64 + bh * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      out[(long)row * p.Cout] = acc[q][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p) {
+  __shared__ float xw0[WG_XW_WORDS], xw1[WG_XW_WORDS];
+  __shared__ float dy0[WG_DY_WORDS], dy1[WG_DY_WORDS];
+  if ((threadIdx.x >> 6) & 1) wino_wgrad_body<1>(p, xw0, xw1, dy0, dy1);
+  else wino_wgrad_body<0>(p, xw0, xw1, dy0, dy1);
+}
+
+// Slab reduction in two steps.  1: dU[pos][ci][co] = sum_z slab[z][pos][ci][co] (z in fixed order, accumulated in double), one
+// thread per element so that even the 64 x 64 layer (Z = 256) spreads over 65536 threads; the sum overwrites slab z = 0,
+// an element only its own thread touches.  2: dW[co][ci][a][b] = sum_{xi,nu} G[xi][a] G[nu][b] dU[xi*4+nu][ci][co].
+__global__ void wino_wgrad_zsum_kernel(float* __restrict__ slab, int Z, long per_z) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_z; idx += (long)gridDim.x * blockDim.x) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int z = 0;
+    for (; z + 4 <= Z; z += 4) {          // four loads in flight; the order of the additions is fixed all the same
+      const float a = slab[(long)z * per_z + idx], b = slab[(long)(z + 1) * per_z + idx];
+      const float c = slab[(long)(z + 2) * per_z + idx], d = slab[(long)(z + 3) * per_z + idx];
+      s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+    }
+    for (; z < Z; ++z) s0 += (double)slab[(long)z * per_z + idx];
+    slab[idx] = (float)((s0 + s1) + (s2 + s3));
+  }
+}
+__global__ void wino_wgrad_fold_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout, int Cin) {
+  const long total = (long)Cin * Cout;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % Cout), ci = (int)(idx / Cout);
+    double u[16];
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) u[pos] = (double)dU[((long)pos * Cin + ci) * Cout + co];
+    // t[a][nu] = sum_xi G[xi][a] u[xi][nu];  G^T rows: a=0: (1, .5, .5, 0)  a=1: (0, .5, -.5, 0)  a=2: (0, .5, .5, 1)
+    double t[3][4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      t[0][nu] = u[0 * 4 + nu] + 0.5 * (u[1 * 4 + nu] + u[2 * 4 + nu]);
+      t[1][nu] = 0.5 * (u[1 * 4 + nu] - u[2 * 4 + nu]);
+      t[2][nu] = 0.5 * (u[1 * 4 + nu] + u[2 * 4 + nu]) + u[3 * 4 + nu];
+    }
+    float* out = dW + ((long)co * Cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      out[a * 3 + 0] = (float)(t[a][0] + 0.5 * (t[a][1] + t[a][2]));
+      out[a * 3 + 1] = (float)(0.5 * (t[a][1] - t[a][2]));
+      out[a * 3 + 2] = (float)(0.5 * (t[a][1] + t[a][2]) + t[a][3]);
+    }
+  }
+}
+
+struct WgradPlan { int st_shift, RS, segs, spc, total, Z, per; };
+inline WgradPlan wino_wgrad_plan(int N, int H, int W, int Cin, int Cout) {
+  WgradPlan g;
+  const int TW = W / 2, TH = (H + 1) / 2;
+  const int STW = TW < 16 ? TW : 16;
+  g.st_shift = __builtin_ctz(STW);
+  g.RS = 16 / STW;
+  g.segs = TW / STW;
+  g.spc = TW >= 16 ? TH * g.segs : (TH + g.RS - 1) / g.RS;
+  g.total = N * g.spc;
+  const int blocks = (Cin / 64) * (Cout / 64);
+  // one workgroup per CU (100 KB of LDS, 8 wavefronts x 128 accumulators): K split so that the grid is one round of 256
+  int Z = 256 / blocks;
+  if (Z < 1) Z = 1;
+  if (Z > g.total) Z = g.total;
+  g.per = (g.total + Z - 1) / Z;
+  g.Z = (g.total + g.per - 1) / g.per;
+  return g;
+}
+}  // namespace
+
+namespace acvae {
+bool conv3x3_wino_wgrad_ok(int H, int W, int Cin, int Cout) {
+  if (H < 1 || W < 4 || W > 64 || (W & (W - 1)) != 0) return false;
+  return Cin % 64 == 0 && Cout % 64 == 0;
+}
+long conv3x3_wino_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout) {
+  if (!conv3x3_wino_wgrad_ok(H, W, Cin, Cout)) return 0;
+  return (long)wino_wgrad_plan(N, H, W, Cin, Cout).Z * 16 * Cin * Cout;
+}
+// dW_oihw[co][ci][3][3] = sum_p dY[p][co] * act(X)[p + tap][ci]
+int conv3x3_wino_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
+                       int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  if (!dY || !X || !dW_oihw || !slab) return ACVAE_EINVAL;
+  if (!conv3x3_wino_wgrad_ok(H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
+  if (!aligned16(dY) || !aligned16(X) || !aligned16(slab) || (scale && (!aligned16(scale) || !aligned16(shift)))) return ACVAE_EALIGN;
+  const WgradPlan g = wino_wgrad_plan(N, H, W, Cin, Cout);
+  WinoWgradParams p;
+  p.dY = dY; p.X = X; p.scale = scale; p.shift = shift; p.slab = slab;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.st_shift = g.st_shift; p.RS = g.RS; p.segs = g.segs; p.spc = g.spc; p.total = g.total; p.per = g.per;
+  prof_begin(ACVAE_PROF_CONV_WGRAD, st);
+  hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3(g.Z, Cin / 64, Cout / 64), dim3(512), 0, st, p);
+  prof_end(ACVAE_PROF_CONV_WGRAD, st);
+  const long total = (long)Cin * Cout, per_z = 16 * total;
+  hipLaunchKernelGGL(wino_wgrad_zsum_kernel, dim3(cdiv(per_z, 256) > 8192 ? 8192 : cdiv(per_z, 256)), dim3(256), 0, st, slab, g.Z,
+                     per_z);
+  hipLaunchKernelGGL(wino_wgrad_fold_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)), dim3(256), 0, st, slab,
+                     dW_oihw, Cout, Cin);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+}  // namespace acvae

@@ -82,6 +82,14 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
     long sl = esz == 2 ? acvae::conv3x3_wgrad_bf16_slab_floats(N, h, w, kChan[b], kChan[b])
                        : acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b], kChan[b]);
     if (sl > max_slab) max_slab = sl;
+    if (esz == 4) {
+      sl = acvae::conv3x3_wino_wgrad_slab_floats(N, h, w, kChan[b], kChan[b]);
+      if (sl > max_slab) max_slab = sl;
+      if (b > 1) {
+        sl = acvae::conv3x3_wino_wgrad_slab_floats(N, h, w, kChan[b - 1], kChan[b]);
+        if (sl > max_slab) max_slab = sl;
+      }
+    }
     if (b > 1) {
       sl = esz == 2 ? acvae::conv3x3_wgrad_bf16_slab_floats(N, h, w, kChan[b - 1], kChan[b])
                     : acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b - 1], kChan[b]);
@@ -152,6 +160,17 @@ int conv_dgrad(const TA* dY, const float* W_oihw, TA* wbuf, TA* dX, int N, int H
   }
   ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, nullptr, wbuf, Cout, Cin, st));
   return acvae::conv3x3_igemm(dY, nullptr, nullptr, (const TA*)wbuf, dX, nullptr, N, H, W, Cout, Cin, st);
+}
+
+// dW = sum_p dY[p] (x) act(X)[p + tap]
+template <class TA>
+int conv_wgrad(const TA* dY, const TA* X, const float* scale, const float* shift, float* dW_oihw, float* slab, int N, int H,
+               int W, int Cin, int Cout, hipStream_t st) {
+  if constexpr (sizeof(TA) == 4) {
+    if (wino_on() && acvae::conv3x3_wino_wgrad_ok(H, W, Cin, Cout))
+      return acvae::conv3x3_wino_wgrad(dY, X, scale, shift, dW_oihw, slab, N, H, W, Cin, Cout, st);
+  }
+  return acvae::conv3x3_wgrad(dY, X, scale, shift, dW_oihw, slab, N, H, W, Cin, Cout, st);
 }
 
 struct BnPtrs { float *scale, *shift, *mean, *invstd; };
@@ -325,15 +344,15 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
     ACVAE_TRY(acvae::bn_bwd<TA>(Y2, dp_cur, L.pool[b] ? UP_POOL : UP_DROP, n2.scale, n2.shift, n2.mean, n2.invstd, bnpart, G(p_bn(b, 2, 1)),
                             G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, training), st,
                             training != 0));
-    ACVAE_TRY(acvae::conv3x3_wgrad((const TA*)dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
+    ACVAE_TRY(conv_wgrad<TA>((const TA*)dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
     ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd, dyb, N, H, W, C, C, st));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
     ACVAE_TRY(acvae::bn_bwd<TA>(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
                             G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st, training != 0));
     if (b > 1) {
-      ACVAE_TRY(acvae::conv3x3_wgrad((const TA*)dya, (const TA*)(saved + L.p[b - 1]), nullptr, nullptr, G(p_conv(b, 1)),
-                                     slab, N, H, W, Cin, C, st));
+      ACVAE_TRY(conv_wgrad<TA>((const TA*)dya, (const TA*)(saved + L.p[b - 1]), nullptr, nullptr, G(p_conv(b, 1)), slab, N, H,
+                               W, Cin, C, st));
       ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 1)), wd, dp_nxt, N, H, W, Cin, C, st));
       TA* t = dp_cur; dp_cur = dp_nxt; dp_nxt = t;
     } else {

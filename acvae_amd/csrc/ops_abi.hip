@@ -28,6 +28,10 @@ ConvWs conv_ws(int N, int H, int W, int Cin, int Cout) {
     const long sb = acvae::conv3x3_wgrad_bf16_slab_floats(N, H, W, Cin, Cout);
     if (sb > slab) slab = sb;
   }
+  if (Cin > 1) {
+    const long sw = acvae::conv3x3_wino_wgrad_slab_floats(N, H, W, Cin, Cout);
+    if (sw > slab) slab = sw;
+  }
   w.slab = o; o = al64(o + slab);
   w.total = o;
   return w;
@@ -135,6 +139,19 @@ extern "C" int acvae_conv3x3_dgrad_wino(const float* dY, const float* W_oihw, fl
   float* ws = (float*)ws_v;
   ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, ws + L.wp, Cout, Cin, true, st));
   return acvae::conv3x3_wino(dY, nullptr, nullptr, ws + L.wp, dX, nullptr, N, H, W, Cout, Cin, st);
+}
+
+extern "C" int acvae_conv3x3_wgrad_wino(const float* dY, const float* X, const float* in_scale, const float* in_shift,
+                                        float* dW_oihw, void* ws_v, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout,
+                                        void* stream) {
+  if (!conv_dims_ok(N, H, W, Cin, Cout) || !dY || !X || !dW_oihw || !ws_v) return ACVAE_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return ACVAE_EINVAL;
+  if (!acvae::conv3x3_wino_wgrad_ok(H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
+  const ConvWs L = conv_ws(N, H, W, Cin, Cout);
+  if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
+  if (!aligned16(ws_v)) return ACVAE_EALIGN;
+  return acvae::conv3x3_wino_wgrad(dY, X, in_scale, in_shift, dW_oihw, (float*)ws_v + L.slab, N, H, W, Cin, Cout,
+                                   (hipStream_t)stream);
 }
 
 // ---- bf16 storage

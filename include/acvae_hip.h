@@ -231,6 +231,10 @@ int acvae_conv3x3_fwd_wino(const float* X, const float* W_oihw, const float* in_
                            int H, int W, int Cin, int Cout, void* stream);
 int acvae_conv3x3_dgrad_wino(const float* dY, const float* W_oihw, float* dX, void* ws, int64_t ws_bytes, int N, int H,
                              int W, int Cin, int Cout, void* stream);
+/* weight gradient in the same form (Cin % 64 == 0, Cout % 64 == 0): 16 GEMMs over the tiles, split over workgroups into
+ * fp32 slabs that are summed in fixed order (in double) and folded through G^T . G. */
+int acvae_conv3x3_wgrad_wino(const float* dY, const float* X, const float* in_scale, const float* in_shift, float* dW_oihw,
+                             void* ws, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
 /* bf16-storage forms of the three convolutions (acvae_encoder_* with ACVAE_ENC_BF16): X / dY / dX / Y are bf16 NHWC
  * (uint16 bit patterns, round-to-nearest-even), weights OIHW fp32 (rounded to bf16 inside), dW fp32.  Cin % 64 == 0.
  * acvae_conv3x3_fwd_bf16 returns this layer's BatchNorm in bn_out exactly like the fp32 form, from the statistics of the

@@ -121,12 +121,16 @@ def test_conv3x3_real_block_geometry():
 def run_conv_wino(N, H, W, Cin, Cout, act, seed=0):
     """Winograd F(2x2,3x3) forms (conv_wino.hip): same fp64 reference, same element-wise bound as the implicit GEMM (the
     transforms only add and halve; measured errors are a third of the implicit GEMM's: 16 products per output, not 36)."""
-    x, w, dy, sc, sh, y_ref, dx_ref, _ = conv_case(N, H, W, Cin, Cout, act, seed)
+    x, w, dy, sc, sh, y_ref, dx_ref, dw_ref = conv_case(N, H, W, Cin, Cout, act, seed)
     wsb = _lib.call("acvae_conv3x3_workspace_bytes", N, H, W, Cin, Cout)
     ws = ws_buf(wsb)
     xd, wd, dyd = nhwc(x).cuda(), w.cuda().contiguous(), nhwc(dy).cuda()
     scd = None if sc is None else sc.cuda()
     shd = None if sh is None else sh.cuda()
+    if Cin % 64 == 0:
+        dw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+        _lib.call("acvae_conv3x3_wgrad_wino", dyd, xd, scd, shd, dw, ws, wsb, N, H, W, Cin, Cout, S())
+        assert_every_element(dw, dw_ref, N * H * W, f"wino wgrad {Cin}->{Cout} {N}x{H}x{W} act={act}")
     y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
     gamma, beta = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
     rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
@@ -164,7 +168,7 @@ def test_conv3x3_winograd_real_block_geometry():
     """Row lengths of the real stack (W = 64 .. 4): 2 .. 16 tile rows per workgroup, clips that end inside a row block,
     odd heights, N > 1; and what the kernel refuses."""
     for (N, H, W, Cin, Cout) in [(2, 11, 64, 64, 64), (3, 9, 32, 64, 128), (2, 37, 16, 128, 256), (2, 37, 8, 256, 512),
-                                 (3, 21, 4, 512, 512), (1, 250, 16, 128, 128), (2, 125, 8, 64, 64)]:
+                                 (3, 21, 4, 512, 512), (1, 250, 16, 128, 128), (2, 125, 8, 64, 64), (5, 40, 64, 64, 64)]:
         run_conv_wino(N, H, W, Cin, Cout, True, seed=7)
         run_conv_wino(N, H, W, Cin, Cout, False, seed=8)
     ws = ws_buf(1 << 20)

@@ -67,6 +67,18 @@ def check(N, H, W, Cin, Cout, act, seed=0):
     dref = nhwc(dx_ref); drms = float(dref.pow(2).mean().sqrt())
     g_d = float((dxs["acvae_conv3x3_dgrad"].double() - dref).abs().max()) / drms
     g_w = float((dxs["acvae_conv3x3_dgrad_wino"].double() - dref).abs().max()) / drms
+    # weight gradient
+    xg = xa.cuda().requires_grad_(False)
+    wref = torch.nn.grad.conv2d_weight(xg, (Cout, Cin, 3, 3), dy.double().cuda(), padding=1)
+    wrms = float(wref.pow(2).mean().sqrt())
+    we = {}
+    for name in ("acvae_conv3x3_wgrad", "acvae_conv3x3_wgrad_wino"):
+        dw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+        _lib.call(name, dyd, xd, scd, shd, dw, ws, wsb, N, H, W, Cin, Cout, S())
+        torch.cuda.synchronize()
+        we[name] = float((dw.double() - wref).abs().max()) / wrms
+    print(f"    wgrad max|err|/rms direct {we['acvae_conv3x3_wgrad']:.2e} wino {we['acvae_conv3x3_wgrad_wino']:.2e}")
+    g_w = max(g_w, we["acvae_conv3x3_wgrad_wino"])
     print(f"N={N} H={H} W={W} {Cin}->{Cout} act={int(act)}: fwd max|err|/rms direct {e_d:.2e} wino {e_w:.2e}; "
           f"bn mean {e_mean:.1e} invstd {e_istd:.1e}; dgrad direct {g_d:.2e} wino {g_w:.2e}", flush=True)
     return e_w, g_w
@@ -103,6 +115,13 @@ def bench():
             ms = timeit(lambda: _lib.call(name, x, w, sc, sh, y, gamma, beta, rm, rv, nbt, 1, bn, ws, wsb, N, H, W, Cin,
                                           Cout, S()))
             res.append(ms)
+        dyt = torch.randn(N, H, W, Cout, device="cuda")
+        dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+        wres = []
+        for name in ("acvae_conv3x3_wgrad", "acvae_conv3x3_wgrad_wino"):
+            wres.append(timeit(lambda: _lib.call(name, dyt, x, sc, sh, dw, ws, wsb, N, H, W, Cin, Cout, S())))
+        print(f"    wgrad direct {wres[0]:.3f} ms ({gf / wres[0]:.1f} TFLOP/s)  wino {wres[1]:.3f} ms ({gf / wres[1]:.1f} algorithmic, "
+              f"{gf / 2.25 / wres[1]:.1f} executed)  incl. slab reduce")
         print(f"{H}x{W} {Cin}->{Cout}: direct {res[0]:.3f} ms ({gf / res[0]:.1f} TFLOP/s)  wino {res[1]:.3f} ms "
               f"({gf / res[1]:.1f} algorithmic TFLOP/s, {gf / 2.25 / res[1]:.1f} executed)  incl. weight transform + bn finalize",
               flush=True)
