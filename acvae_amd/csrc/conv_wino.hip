@@ -86,7 +86,7 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
 }
 
 // XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
-template <int XH>
+template <int XH, bool ACT>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
@@ -117,29 +117,34 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     live |= (lv ? 1u : 0u) << j;
     okm |= (ok ? 1u : 0u) << j;
     goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;     // always a legal address
-    loff[j] = q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1);
+    // items past the window write a slot nobody reads (the staging code then has no branch and can be interleaved with MFMAs)
+    loff[j] = lv ? q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1) : WN_RAWBUF - 1 - (tid & 7);
   }
   float4 pv[4];
   auto issue_raw = [&](int st) {
+#if WN_ABL == 9
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = make_float4(1.f, 2.f, 3.f, (float)st);
+#else
 #pragma unroll
     for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
+#endif
   };
   auto put_raw = [&](int st, float4* raw) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool act = p.scale != nullptr;
-    if (act) {
+    if (ACT) {
       sc = *reinterpret_cast<const float4*>(p.scale + st * 16 + q * 4);
       sh = *reinterpret_cast<const float4*>(p.shift + st * 16 + q * 4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float4 v = pv[j];
-      if (act) {
+      if (ACT) {
         v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
         v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
       }
-      if (!((okm >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding / rows of another clip
-      if ((live >> j) & 1u) raw[loff[j]] = v;
+      const bool ok = (okm >> j) & 1u;                                   // zero padding / rows of another clip
+      raw[loff[j]] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
   };
   // weight chunk c: 32 KB, already in LDS order; one LDS-DMA instruction of a wave moves 1 KB
@@ -179,7 +184,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     const float4* rq = raw + (2 * sub + h) * WN_SQ;
     const float4* bq = bw + bcol;
     float4 d[3][4];
-#if WN_ABL >= 1          // ablation (tools/wino_ablate.sh): no activation reads
+#if WN_ABL >= 1 && WN_ABL <= 4          // ablation (tools/wino_ablate.sh): no activation reads
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -201,7 +206,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
       }
       constexpr int dummy = 0; (void)dummy;
       const int xi = xl ? xi1 : xi0;
-#if WN_ABL >= 2          // no weight-fragment reads either
+#if WN_ABL >= 2 && WN_ABL <= 4          // no weight-fragment reads either
       const float4 b0 = abl, b1 = abl, b2 = abl, b3 = abl;
       (void)bq; (void)xi;
 #else
@@ -231,19 +236,28 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     float4* const bnxt = sub ? bw0 : bw1;
     float4* const rcur = sp ? raw1 : raw0;
     float4* const rnxt = sp ? raw0 : raw1;
-#if WN_ABL < 3           // 3: no global traffic in the loop at all
-    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);              // its last readers (chunk c - 1) are behind the barrier
-    if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);    // in flight for this chunk and the next
+    // Order of the vector-memory queue in a chunk: the weight DMA first, the activation loads of the next stage behind it
+    // (sched_barriers: left alone the compiler sinks those loads to the end of the chunk).  vmcnt retires in order, so at the
+    // end of the chunk vmcnt(4) has seen the DMA land while the four activation loads may still fly - they have until the
+    // end of the NEXT chunk; waiting for them here as well (vmcnt(0)) cost 15 % of the kernel (tools/wino_ablate.sh).
+    const bool raw_now = sub == 0 && st + 1 < nstage;
+#if WN_ABL < 3 || WN_ABL >= 6           // 3: no global traffic in the loop at all; 5: no weight DMA; 6: no activation staging
+    if (c + 1 < nchunk) fetch_b(WN_ABL == 7 ? 0 : c + 1, bnxt);              // 7: the same (cache-hot) chunk every time
 #endif
+    __builtin_amdgcn_sched_barrier(0);
+#if WN_ABL < 3 || WN_ABL == 5 || WN_ABL >= 7
+    if (raw_now) issue_raw(st + 1);                        // in flight for this chunk and the next
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // staging of the next stage: into the buffer whose last readers were stage st - 1
     compute(rcur, sub, bcur);
-#if WN_ABL < 3
-    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);   // that buffer's last readers: stage st - 1
-#endif
-#if WN_ABL >= 4          // 4: no barrier either
+    if (sub == 1 && st + 1 < nstage && (WN_ABL < 3 || WN_ABL == 5 || WN_ABL >= 7)) put_raw(st + 1, rnxt);
+#if WN_ABL == 4          // 4: no barrier either
     return;
 #endif
     // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (raw_now) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
   for (int c = 0; c < nchunk; c += 4) {
@@ -313,11 +327,21 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   }
 }
 
+// ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift)
+template <bool ACT>
+__device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
+  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT>(p, raw0, raw1, bw0, bw1);
+  else conv_wino_body<0, ACT>(p, raw0, raw1, bw0, bw1);
+}
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(WinoParams p) {
   __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
   __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  if ((threadIdx.x >> 6) & 1) conv_wino_body<1>(p, raw0, raw1, bw0, bw1);
-  else conv_wino_body<0>(p, raw0, raw1, bw0, bw1);
+  conv_wino_entry<false>(p, raw0, raw1, bw0, bw1);
+}
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_act_kernel(WinoParams p) {
+  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
+  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
+  conv_wino_entry<true>(p, raw0, raw1, bw0, bw1);
 }
 
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
@@ -401,7 +425,8 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   p.bpc = cdiv(cdiv(H, 2), p.R);
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
-  hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  else hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;

@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r['Kernel_Name']
     if 'conv_igemm' in k or 'conv_wgrad' in k or 'conv_wino' in k:
-        short = ('wino' if 'wino' in k else 'igemm' if 'igemm' in k else 'wgrad') + ('<128>' if 'Li128' in k or '<128' in k else '<64>' if 'Li64' in k or '<64' in k else '')
+        short = ('wino_wgrad' if 'wino_wgrad' in k else 'wino' if 'wino' in k else 'igemm' if 'igemm' in k else 'wgrad') + ('<128>' if 'Li128' in k or '<128' in k else '<64>' if 'Li64' in k or '<64' in k else '')
         agg[short][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in agg.items():
     m = {c: sum(x) / len(x) for c, x in v.items()}

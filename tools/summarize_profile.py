@@ -35,7 +35,7 @@ def counter(sub, name):
             if r["Counter_Name"] != name:
                 continue
             k = r["Kernel_Name"]
-            short = ("conv_igemm" if ("conv_igemm" in k or "conv_wino" in k) else "conv_wgrad" if "conv_wgrad" in k else None)
+            short = ("conv_wgrad" if ("conv_wgrad" in k or "conv_wino_wgrad" in k) else "conv_igemm" if ("conv_igemm" in k or "conv_wino_kernel" in k) else None)
             if short:
                 per[short].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
