@@ -554,44 +554,61 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // Two register sets: the 16 LDS reads of tile pair j + 1 are issued before the 8 MFMAs of pair j (sched_barriers keep
+  // them there; left alone the compiler reads each value just in front of the MFMA that takes it).
+  struct Frag { float d[3][4]; float y[4]; };
+  auto load = [&](int j, const float* xw, const float* dys, Frag& f) {
+    const int t = 2 * j + kh;                            // this lane half's tile of the k-step
+    const int tyl = t >> p.st_shift, txl = t & (STW - 1);
+    const float* xb = xw + ((2 * tyl + XH) * WC + 2 * txl) * 64;
+    // window columns 0,1 have the tile's own column parity, columns 2,3 the other one
+    const int c01 = (txl & 1) ? ci_s1 : ci_s0, c23 = (txl & 1) ? ci_s0 : ci_s1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      f.d[a][0] = xb[a * rowstride + 0 * 64 + c01];
+      f.d[a][1] = xb[a * rowstride + 1 * 64 + c01];
+      f.d[a][2] = xb[a * rowstride + 2 * 64 + c23];
+      f.d[a][3] = xb[a * rowstride + 3 * 64 + c23];
+    }
+    const float* yb = dys + bbase + j * 512;
+    f.y[0] = yb[0]; f.y[1] = yb[64]; f.y[2] = yb[128]; f.y[3] = yb[192];
+  };
+  auto mm = [&](const Frag& f) {
+    const float y00 = f.y[0], y01 = f.y[1], y10 = f.y[2], y11 = f.y[3];
+    // local position half 0: frequency 0 (XH = 0: rows 0,2; gradient row 0) / 3 (XH = 1: sign folded: rows 3 - 1; row 1)
+    // local position half 1: frequency 1 (rows 1 + 2; gradient rows 0 + 1) / 2 (rows 2 - 1; rows 0 - 1)
+    float t0[4], t1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      t0[c] = XH ? f.d[2][c] - f.d[0][c] : f.d[0][c] - f.d[2][c];
+      t1[c] = XH ? f.d[1][c] - f.d[0][c] : f.d[1][c] + f.d[2][c];
+    }
+    const float r00 = XH ? y10 : y00, r01 = XH ? y11 : y01;
+    const float r10 = XH ? y00 - y10 : y00 + y10, r11 = XH ? y01 - y11 : y01 + y11;
+    // horizontal: v = [t0 - t2, t1 + t2, t2 - t1, t3 - t1] against dm = [r0, r0 + r1, r0 - r1, r1] (the minus of A's last row
+    // sits in v[3])
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[0] - t0[2], r00, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[1] + t0[2], r00 + r01, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[2] - t0[1], r00 - r01, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[3] - t0[1], r01, acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[0] - t1[2], r10, acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[1] + t1[2], r10 + r11, acc[5], 0, 0, 0);
+    acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[2] - t1[1], r10 - r11, acc[6], 0, 0, 0);
+    acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[3] - t1[1], r11, acc[7], 0, 0, 0);
+  };
   auto compute = [&](const float* xw, const float* dys) {
-#pragma unroll 2
-    for (int j = 0; j < 8; ++j) {
-      const int t = 2 * j + kh;                            // this lane half's tile of the k-step
-      const int tyl = t >> p.st_shift, txl = t & (STW - 1);
-      const float* xb = xw + ((2 * tyl + XH) * WC + 2 * txl) * 64;
-      // window columns 0,1 have the tile's own column parity, columns 2,3 the other one
-      const int c01 = (txl & 1) ? ci_s1 : ci_s0, c23 = (txl & 1) ? ci_s0 : ci_s1;
-      float d[3][4];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        d[a][0] = xb[a * rowstride + 0 * 64 + c01];
-        d[a][1] = xb[a * rowstride + 1 * 64 + c01];
-        d[a][2] = xb[a * rowstride + 2 * 64 + c23];
-        d[a][3] = xb[a * rowstride + 3 * 64 + c23];
-      }
-      const float* yb = dys + bbase + j * 512;
-      const float y00 = yb[0], y01 = yb[64], y10 = yb[128], y11 = yb[192];
-      // local position half 0: frequency 0 (XH = 0: rows 0,2; gradient row 0) / 3 (XH = 1: sign folded: rows 3 - 1; row 1)
-      // local position half 1: frequency 1 (rows 1 + 2; gradient rows 0 + 1) / 2 (rows 2 - 1; rows 0 - 1)
-      float t0[4], t1[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        t0[c] = XH ? d[2][c] - d[0][c] : d[0][c] - d[2][c];
-        t1[c] = XH ? d[1][c] - d[0][c] : d[1][c] + d[2][c];
-      }
-      const float r00 = XH ? y10 : y00, r01 = XH ? y11 : y01;
-      const float r10 = XH ? y00 - y10 : y00 + y10, r11 = XH ? y01 - y11 : y01 + y11;
-      // horizontal: v = [t0 - t2, t1 + t2, t2 - t1, t3 - t1] against dm = [r0, r0 + r1, r0 - r1, r1] (the minus of A's last row
-      // sits in v[3])
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[0] - t0[2], r00, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[1] + t0[2], r00 + r01, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[2] - t0[1], r00 - r01, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[3] - t0[1], r01, acc[3], 0, 0, 0);
-      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[0] - t1[2], r10, acc[4], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[1] + t1[2], r10 + r11, acc[5], 0, 0, 0);
-      acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[2] - t1[1], r10 - r11, acc[6], 0, 0, 0);
-      acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[3] - t1[1], r11, acc[7], 0, 0, 0);
+    Frag fa, fb;
+    load(0, xw, dys, fa);
+#pragma unroll 1
+    for (int j = 0; j < 8; j += 2) {
+      load(j + 1, xw, dys, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < 8) load(j + 2, xw, dys, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fb);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
