@@ -45,17 +45,21 @@ constexpr int WN_BCHUNK = 16 * 2 * 64;   // float4 per weight chunk image: [posi
 // reads of chunk c no longer wait for the DMA of chunk c + 1 issued just before them.
 constexpr int WN_RAWBUF = 4 * WN_SQ;        // float4 per stage buffer (26880 B); weight chunk buffer: [(pos*2 + h)*64 + col] (32768 B)
 
-// Tile (row of the block, column) of row `row` (0..31) of tile half mh.  A ds_read_b128 is served 16 lanes at a time; those
-// 16 tiles must sit in 16 different 16-byte bank groups.  TW >= 16: they are 16 neighbours of one tile row.  TW < 16: the
-// group takes 16/TW tile rows `rstep` apart, chosen with the row pitch RW so that their slots tile the 256-byte bank span
+// Tile (row of the block, column) of MFMA row `row` (0..31, = lane & 31 of the A operand) of tile half mh.  A ds_read_b128
+// is served in four groups of 16 lanes - NOT consecutive ones: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32
+// (MI355X_MICROARCH.md, LDS table) - and the 16 tiles of a group must sit in 16 different 16-byte bank groups.  So the
+// lane is first mapped to (group, rank in the group); then TW >= 16: a group reads 16 neighbours of one tile row; TW < 16:
+// it reads 16/TW tile rows `rstep` apart, chosen with the row pitch RW so that their slots tile the 256-byte bank span
 // (TW = 8: RW = 10, rows r, r+4 -> 0 / 128 B; TW = 4: RW = 5, rows r+4k -> 64 B apart; TW = 2: RW = 3, rows r+2k -> 32 B).
 __device__ __forceinline__ void wino_tile(int mh, int row, int tw_shift, int& tyl, int& tx) {
+  // 4-lane blocks 0..7 -> group * 16 + first rank: 0, 16, 20, 4, 24, 8, 12, 28
+  const int cell = (int)((0x1c0c081804141000ULL >> (8 * (row >> 2))) & 0xff) + (row & 3);
   if (tw_shift >= 4) {
-    const int m = mh * 32 + row;
+    const int m = mh * 32 + cell;
     tyl = m >> tw_shift;
     tx = m & ((1 << tw_shift) - 1);
   } else {
-    const int g = row >> 4, l16 = row & 15;
+    const int g = cell >> 4, l16 = cell & 15;
     tx = l16 & ((1 << tw_shift) - 1);
     const int rsel = l16 >> tw_shift;
     tyl = tw_shift == 1 ? mh * 16 + g + 2 * rsel : mh * 2 + g + 4 * rsel;
@@ -74,6 +78,7 @@ struct WinoParams {
   int tw_shift;         // TW = W/2 = 1 << tw_shift
   int R;                // tile rows per workgroup = 64 / TW
   int bpc;              // workgroups (row blocks) per clip = ceil(ceil(H/2) / R)
+  int ppmap;            // ping-pong kernels: which wavefronts form a group (0: 0-3 / 4-7, 1: even / odd)
 };
 
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -83,6 +88,69 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+}
+
+// Epilogue of both forward kernels: At . A in registers, the two position halves of a tile meet through LDS (`ex`: 8 KB per
+// wavefront, partner = vw ^ 1), raw output + BatchNorm partial sums.  vw = role index of the wavefront (XH = vw & 1).
+template <int XH>
+__device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 (&acc)[8], float* ex_mine, const float* ex_partner,
+                                              float* red, int mh, int nh, int li, int h, int lane, int n, int ty0, int bm,
+                                              int bn) {
+  const int tid = threadIdx.x;
+  const int H = p.H, W = p.W;
+  float keep[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float hl[2][2];
+#pragma unroll
+    for (int xl = 0; xl < 2; ++xl) {
+      const float m0 = acc[xl * 4 + 0][r], m1 = acc[xl * 4 + 1][r], m2 = acc[xl * 4 + 2][r], m3 = acc[xl * 4 + 3][r];
+      hl[xl][0] = m0 + m1 + m2;
+      hl[xl][1] = m1 - m2 - m3;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float s = hl[0][b] + hl[1][b];
+      keep[r][b] = XH ? -s : s;
+      ex_mine[(r * 2 + b) * 64 + lane] = hl[1][b];
+    }
+  }
+  __syncthreads();
+  const int cout = bn * WN_TN + nh * 32 + li;
+  float s = 0.f, qq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int tyl, tx;
+    wino_tile(mh, (r & 3) + 8 * (r >> 2) + 4 * h, p.tw_shift, tyl, tx);
+    const int y = 2 * (ty0 + tyl) + XH;       // this wave finishes output row XH of its tiles
+    const int x = 2 * tx;
+    const float o0 = keep[r][0] + ex_partner[(r * 2 + 0) * 64 + lane];
+    const float o1 = keep[r][1] + ex_partner[(r * 2 + 1) * 64 + lane];
+    if (y < H) {
+      float* out = p.Y + ((long)(n * H + y) * W + x) * p.Cout + cout;
+      out[0] = o0;
+      out[p.Cout] = o1;
+      s += o0 + o1;
+      qq += o0 * o0 + o1 * o1;
+    }
+  }
+  if (p.partials) {
+    s += __shfl_xor(s, 32, 64);
+    qq += __shfl_xor(qq, 32, 64);
+    if (h == 0) {
+      red[((mh * 2 + XH) * 2 + 0) * 64 + nh * 32 + li] = s;
+      red[((mh * 2 + XH) * 2 + 1) * 64 + nh * 32 + li] = qq;
+    }
+    __syncthreads();
+    if (tid < WN_TN) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
+      float* out = p.partials + (long)bm * 2 * p.Cout + bn * WN_TN + tid;
+      out[0] = ts;
+      out[p.Cout] = tq;
+    }
+  }
 }
 
 // XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
@@ -269,62 +337,221 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     }
   }
 
-  // ---------------------------------------------------------------- epilogue: At . A, position halves meet through LDS
-  float* ex = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
-  float keep[16][2];
+  // ---------------------------------------------------------------- epilogue
+  float* exb = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
+  wino_epilogue<XH>(p, acc, exb + (wave & 3) * 2048, exb + ((wave & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw0), mh, nh, li, h,
+                    lane, n, ty0, bm, bn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ping-pong variant.  In conv_wino_body the two wavefronts of a SIMD run the same code between the same barriers, so
+// whatever one of them waits for (LDS reads, the transform adds) nobody covers: tools/wino_ablate.sh gives every removed
+// piece its full time back.  Here the wavefronts of group G = 1 run half a chunk behind those of group 0:
+//   interval c, group 0:  reads + transform + MFMAs of chunk c (as before)
+//   interval c, group 1:  MFMAs of chunk c - 1 from fragments it holds in registers (a pure matrix stream that fills the
+//                         other group's bubbles), THEN reads + transform of chunk c into registers (under the other
+//                         group's MFMAs)
+// Group 1 reads the weight chunk c - 1 while the DMA of chunk c + 1 is in flight, hence a ring of three weight buffers
+// (three distinct __shared__ arrays, loop unrolled by three: see the note on LDS-DMA aliasing above); the activation
+// window keeps its two buffers, indexed at run time (no DMA writes them).  ppmap picks which wavefronts form a group:
+// 0: waves 0-3 / 4-7, 1: even / odd waves (whichever pairs the groups on the SIMDs).
+template <int XH, bool ACT, int G>
+__device__ __forceinline__ void conv_wino_pp_body(const WinoParams& p, int vw, float4* raw, float4* bwA, float4* bwB,
+                                                  float4* bwC) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int mh = (vw >> 1) & 1, nh = vw >> 2;          // XH = vw & 1
+  int bm, bn;
+  xcd_tile(gridDim.x, gridDim.y, bm, bn);
+  const int RW = wino_row_pitch(p.tw_shift), R = p.R;
+  const int n = bm / p.bpc, ty0 = (bm - n * p.bpc) * R;
+  const int H = p.H, W = p.W, C = p.C;
+
+  const int W2 = W + 2;
+  const int nitems = (2 * R + 2) * W2 * 4;
+  const int q = tid & 3;
+  unsigned okm = 0;
+  long goff[4];
+  int loff[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float hl[2][2];
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + WN_THREADS * j;
+    const bool lv = e < nitems;
+    const int px = e >> 2;
+    const int ry = px / W2, rx = px - ry * W2;
+    const int y = 2 * ty0 - 1 + ry, x = rx - 1;
+    const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
+    okm |= (ok ? 1u : 0u) << j;
+    goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;
+    loff[j] = lv ? q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1) : WN_RAWBUF - 1 - (tid & 7);
+  }
+  float4 pv[4];
+  auto issue_raw = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
+  };
+  auto put_raw = [&](int st, float4* rb) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACT) {
+      sc = *reinterpret_cast<const float4*>(p.scale + st * 16 + q * 4);
+      sh = *reinterpret_cast<const float4*>(p.shift + st * 16 + q * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = pv[j];
+      if (ACT) {
+        v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+        v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+      }
+      const bool ok = (okm >> j) & 1u;
+      rb[loff[j]] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+  };
+  const int nchunk = C >> 3, nstage = C >> 4;
+  const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
+  auto fetch_b = [&](int c, float4* bw) {
+    const float* src = Ub + (long)c * (WN_BCHUNK * 4);
+    float* dst = reinterpret_cast<float*>(bw) + wave * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 2048, dst + i * 2048, 16, 0, 0);
+  };
+
+  int tyl_a, tx_a;
+  wino_tile(mh, li, p.tw_shift, tyl_a, tx_a);
+  const int abase = tyl_a * RW + tx_a;
+  int rowoff[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int i = XH + a;
+    rowoff[a] = (i & 1) * WN_SR + (i >> 1) * RW + abase;
+  }
+  constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;
+  const int bcol = h * 64 + nh * 32 + li;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // group 0: reads, transform and MFMAs of one chunk (the compiler's own just-in-time schedule)
+  auto compute = [&](const float4* rs, int sub, const float4* bw) {
+    const float4* rq = rs + (2 * sub + h) * WN_SQ;
+    const float4* bq = bw + bcol;
+    float4 d[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_SC + (j >> 1)];
 #pragma unroll
     for (int xl = 0; xl < 2; ++xl) {
-      const float m0 = acc[xl * 4 + 0][r], m1 = acc[xl * 4 + 1][r], m2 = acc[xl * 4 + 2][r], m3 = acc[xl * 4 + 3][r];
-      hl[xl][0] = m0 + m1 + m2;
-      hl[xl][1] = m1 - m2 - m3;
-    }
+      float4 t[4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float s = hl[0][b] + hl[1][b];
-      keep[r][b] = XH ? -s : s;
-      ex[((wave & 3) * 32 + r * 2 + b) * 64 + lane] = hl[1][b];
+      for (int j = 0; j < 4; ++j) {
+        if (xl == 0) t[j] = f4sub(d[0][j], d[2][j]);
+        else t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);
+      }
+      const int xi = xl ? xi1 : xi0;
+      const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
+      const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
+      mfma4(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0);
+      mfma4(acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
+      mfma4(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2);
+      mfma4(acc[xl * 4 + 3], f4sub(t[1], t[3]), b3);
     }
-  }
+  };
+  // group 1: the transformed fragments of a chunk, built column by column (12 registers of window data alive at a time)
+  float4 vf[8];
+  auto transform = [&](const float4* rs, int sub) {
+    const float4* rq = rs + (2 * sub + h) * WN_SQ;
+    float4 t0[4], t1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 d0 = rq[rowoff[0] + (j & 1) * WN_SC + (j >> 1)];
+      const float4 d1 = rq[rowoff[1] + (j & 1) * WN_SC + (j >> 1)];
+      const float4 d2 = rq[rowoff[2] + (j & 1) * WN_SC + (j >> 1)];
+      t0[j] = f4sub(d0, d2);
+      t1[j] = XH ? f4sub(d1, d0) : f4add(d1, d2);
+      __builtin_amdgcn_sched_barrier(0);      // one column at a time: clustered, the 12 reads would cost 48 registers
+    }
+    vf[0] = f4sub(t0[0], t0[2]); vf[1] = f4add(t0[1], t0[2]); vf[2] = f4sub(t0[2], t0[1]); vf[3] = f4sub(t0[1], t0[3]);
+    vf[4] = f4sub(t1[0], t1[2]); vf[5] = f4add(t1[1], t1[2]); vf[6] = f4sub(t1[2], t1[1]); vf[7] = f4sub(t1[1], t1[3]);
+  };
+  auto matrix = [&](const float4* bw) {
+    const float4* bq = bw + bcol;
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) {
+      const float4 b = bq[(((q8 >> 2) ? xi1 : xi0) * 4 + (q8 & 3)) * 128];
+      mfma4(acc[q8], vf[q8], b);
+    }
+  };
+
+  issue_raw(0);
+  fetch_b(0, bwA);
+  put_raw(0, raw);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int cout = bn * WN_TN + nh * 32 + li;
-  float s = 0.f, qq = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int tyl, tx;
-    wino_tile(mh, (r & 3) + 8 * (r >> 2) + 4 * h, p.tw_shift, tyl, tx);
-    const int y = 2 * (ty0 + tyl) + XH;       // this wave finishes output row XH of its tiles
-    const int x = 2 * tx;
-    const float o0 = keep[r][0] + ex[(((wave & 3) ^ 1) * 32 + r * 2 + 0) * 64 + lane];
-    const float o1 = keep[r][1] + ex[(((wave & 3) ^ 1) * 32 + r * 2 + 1) * 64 + lane];
-    if (y < H) {
-      float* out = p.Y + ((long)(n * H + y) * W + x) * p.Cout + cout;
-      out[0] = o0;
-      out[p.Cout] = o1;
-      s += o0 + o1;
-      qq += o0 * o0 + o1 * o1;
+  auto step = [&](int c, auto kk) {
+    constexpr int K = decltype(kk)::value;            // c % 3: weight ring position
+    float4* const bcur = K == 0 ? bwA : (K == 1 ? bwB : bwC);
+    float4* const bnxt = K == 0 ? bwB : (K == 1 ? bwC : bwA);
+    float4* const bprv = K == 0 ? bwC : (K == 1 ? bwA : bwB);
+    const int st = c >> 1, sub = c & 1;
+    float4* const rcur = raw + (st & 1) * WN_RAWBUF;
+    float4* const rnxt = raw + ((st + 1) & 1) * WN_RAWBUF;
+    const bool raw_now = sub == 0 && st + 1 < nstage;
+    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);      // ring slot of chunk c - 2, whose last readers (group 1) are behind the barrier
+    __builtin_amdgcn_sched_barrier(0);
+    if (raw_now) issue_raw(st + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (G == 0) {
+      compute(rcur, sub, bcur);
+    } else {
+      if (c > 0) matrix(bprv);
+      __builtin_amdgcn_sched_barrier(0);
+      transform(rcur, sub);
     }
-  }
-  if (p.partials) {
-    float* red = reinterpret_cast<float*>(raw0);   // [4 waves of a column half][2][64]
-    s += __shfl_xor(s, 32, 64);
-    qq += __shfl_xor(qq, 32, 64);
-    if (h == 0) {
-      red[((mh * 2 + XH) * 2 + 0) * 64 + nh * 32 + li] = s;
-      red[((mh * 2 + XH) * 2 + 1) * 64 + nh * 32 + li] = qq;
-    }
+    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < WN_TN) {
-      float ts = 0.f, tq = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
-      float* out = p.partials + (long)bm * 2 * p.Cout + bn * WN_TN + tid;
-      out[0] = ts;
-      out[p.Cout] = tq;
-    }
+  };
+  for (int c = 0; c < nchunk; c += 3) {
+    step(c, std::integral_constant<int, 0>());
+    if (c + 1 < nchunk) step(c + 1, std::integral_constant<int, 1>());
+    if (c + 2 < nchunk) step(c + 2, std::integral_constant<int, 2>());
   }
+  if (G == 1) {          // the last chunk's products
+    const int k = (nchunk - 1) % 3;          // run-time pointer: one copy of the MFMA code (no DMA is in flight any more)
+    matrix(k == 0 ? bwA : (k == 1 ? bwB : bwC));
+  }
+  __syncthreads();       // every LDS read of the main loop is done: the buffers are free for the epilogue
+  float* exb = reinterpret_cast<float*>(vw < 4 ? bwA : bwB);
+  wino_epilogue<XH>(p, acc, exb + (vw & 3) * 2048, exb + ((vw & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw), mh, nh, li, h, lane,
+                    n, ty0, bm, bn);
+}
+
+template <bool ACT>
+__device__ __forceinline__ void conv_wino_pp_entry(const WinoParams& p, float4* raw, float4* bwA, float4* bwB, float4* bwC) {
+  const int wave = threadIdx.x >> 6;
+  // role index: XH = vw & 1, tile half (vw >> 1) & 1, column half = group = vw >> 2
+  const int vw = p.ppmap ? ((wave & 1) << 2) | (wave >> 1) : wave;
+  if (vw >> 2) {
+    if (vw & 1) conv_wino_pp_body<1, ACT, 1>(p, vw, raw, bwA, bwB, bwC);
+    else conv_wino_pp_body<0, ACT, 1>(p, vw, raw, bwA, bwB, bwC);
+  } else {
+    if (vw & 1) conv_wino_pp_body<1, ACT, 0>(p, vw, raw, bwA, bwB, bwC);
+    else conv_wino_pp_body<0, ACT, 0>(p, vw, raw, bwA, bwB, bwC);
+  }
+}
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_pp_kernel(WinoParams p) {
+  __shared__ float4 raw[2 * WN_RAWBUF];
+  __shared__ float4 bwA[WN_BCHUNK], bwB[WN_BCHUNK], bwC[WN_BCHUNK];
+  conv_wino_pp_entry<false>(p, raw, bwA, bwB, bwC);
+}
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_pp_act_kernel(WinoParams p) {
+  __shared__ float4 raw[2 * WN_RAWBUF];
+  __shared__ float4 bwA[WN_BCHUNK], bwB[WN_BCHUNK], bwC[WN_BCHUNK];
+  conv_wino_pp_entry<true>(p, raw, bwA, bwB, bwC);
 }
 
 // ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift)
@@ -425,8 +652,16 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   p.bpc = cdiv(cdiv(H, 2), p.R);
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
-  if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
-  else hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  // ACVAE_WINO_PP: 0 = both wavefronts of a SIMD in step (conv_wino_body), 1 / 2 = ping-pong groups (waves 0-3 / 4-7, even / odd)
+  static const int pp = getenv("ACVAE_WINO_PP") ? atoi(getenv("ACVAE_WINO_PP")) : 0;
+  p.ppmap = pp == 2 ? 1 : 0;
+  if (pp) {
+    if (scale) hipLaunchKernelGGL(conv_wino_pp_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(conv_wino_pp_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  } else {
+    if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  }
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
