@@ -80,7 +80,7 @@ int conv1_first_bwd(const float* x, const float* scale0, const float* shift0, co
 template <class T>
 int bn_relu_pool(const T* Y, const float* scale, const float* shift, T* P, int N, int H, int W, int C,
                  DropoutSpec drop, hipStream_t st, bool pool = true);
-int bn_bwd_blocks(int N, int H, int W);
+int bn_bwd_blocks(int N, int H, int W, int C);
 template <class T>
 int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, T* dY, double* dpart, int N, int H,

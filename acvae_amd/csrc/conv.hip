@@ -1514,21 +1514,28 @@ int bn_relu_pool(const T* Y, const float* scale, const float* shift, T* P, int N
 template int bn_relu_pool<float>(const float*, const float*, const float*, float*, int, int, int, int, DropoutSpec, hipStream_t, bool);
 template int bn_relu_pool<bf16_t>(const bf16_t*, const float*, const float*, bf16_t*, int, int, int, int, DropoutSpec, hipStream_t, bool);
 
-constexpr int BNB_PIX = 512;
-int bn_bwd_blocks(int N, int H, int W) { return cdiv((long)N * H * W, BNB_PIX); }
+// Pixels per reduce block: a block's 256 threads are (C/4 channel quads) x (256 / (C/4) pixel lanes) and every thread should
+// walk ~32 pixels - with a fixed 512 pixels per block the 512-channel layers ran 63 blocks of 256-iteration threads
+// (207 us for a 65 MB tensor; 4x that many blocks of short loops: HBM-bound like the wide layers).
+static int bnb_pix(int C) {
+  const int Cc = C < 1024 ? C : 1024;
+  const int npl = 256 / (Cc / 4) > 0 ? 256 / (Cc / 4) : 1;
+  return npl * 32 < 32 ? 32 : npl * 32;
+}
+int bn_bwd_blocks(int N, int H, int W, int C) { return cdiv((long)N * H * W, bnb_pix(C)); }
 template <class T>
 int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, T* dY, double* dpart, int N, int H,
            int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats) {
   const int Cc = C < 1024 ? C : 1024;
   if (C % 4 != 0 || 1024 % Cc != 0 || C % Cc != 0) return ACVAE_EUNSUPPORTED;
-  const dim3 rgrid(bn_bwd_blocks(N, H, W), C / Cc);
+  const dim3 rgrid(bn_bwd_blocks(N, H, W, C), C / Cc);
   const int nb = rgrid.x;
   const size_t shm = 256 * 8 * sizeof(float);
   const long total = (long)N * H * W * (C / 4);
 #define BN_BWD_LAUNCH(UP_)                                                                                             \
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<UP_, T>), rgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials, \
-                     N, H, W, C, BNB_PIX, drop);                                                                       \
+                     N, H, W, C, bnb_pix(C), drop);                                                                       \
   ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st)); /* sum_g (= dbeta) | sum_gy (= dgamma) */        \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<UP_, T>), dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,  \
                      invstd, sum_g, sum_gy, dY, N, H, W, C, drop, batch_stats ? 1 : 0)

@@ -95,7 +95,7 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
                     : acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b - 1], kChan[b]);
       if (sl > max_slab) max_slab = sl;
     }
-    const long bp = (long)acvae::bn_bwd_blocks(N, h, w) * 2 * kChan[b];
+    const long bp = (long)acvae::bn_bwd_blocks(N, h, w, kChan[b]) * 2 * kChan[b];
     if (bp > max_bnpart) max_bnpart = bp;
     if (L.pool[b]) { h /= 2; w /= 2; }
   }

@@ -219,7 +219,7 @@ extern "C" int acvae_conv1_first_bwd(const float* x, const float* bn0, const flo
 // ------------------------------------------------------------------------------------------ BatchNorm pieces
 extern "C" int64_t acvae_bn_workspace_bytes(int N, int H, int W, int C) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;
-  const long part = (long)acvae::bn_bwd_blocks(N, H, W) * 2 * C;
+  const long part = (long)acvae::bn_bwd_blocks(N, H, W, C) * 2 * C;
   const long p0 = (long)acvae::bn0_partials_rows((long)N * H) * 128;
   return (al64(part > p0 ? part : p0) + al64(2 * acvae::colsum_scratch_doubles(2 * C > 1024 ? 2 * C : 1024))) * 4;
 }
@@ -254,7 +254,7 @@ extern "C" int acvae_bn_relu_bwd(const float* Y, const float* dO, int upstream, 
   if (upstream != UP_PLAIN && upstream != UP_POOL && upstream != UP_DROP) return ACVAE_EINVAL;
   if (ws_bytes < acvae_bn_workspace_bytes(N, H, W, C)) return ACVAE_EWORKSPACE;
   float* ws = (float*)ws_v;
-  const long part = al64((long)acvae::bn_bwd_blocks(N, H, W) * 2 * C);
+  const long part = al64((long)acvae::bn_bwd_blocks(N, H, W, C) * 2 * C);
   const long p0 = al64((long)acvae::bn0_partials_rows((long)N * H) * 128);
   DropoutSpec d{p_drop, keep_mask, seed, (uint32_t)site};
   // sum_g (= dbeta) and sum_gy (= dgamma) are also inputs of the apply pass: written first, then read
