@@ -30,6 +30,12 @@ using namespace mfma;
 #ifndef WN_ABL
 #define WN_ABL 0
 #endif
+#ifndef WN_TIMING
+#define WN_TIMING 0   // 1: per-wavefront cycle sums of the main-loop phases written over the start of Y (tools/wino_timing.py)
+#endif
+#ifndef WN_ILV
+#define WN_ILV 0      // 1: MFMAs of two positions interleaved (A/B: tools/wino_ablate.sh)
+#endif
 constexpr int WN_THREADS = 512;
 constexpr int WN_TILES = 64;      // output tiles (2x2 pixels each) per workgroup
 constexpr int WN_TN = 64;         // output channels per workgroup
@@ -151,6 +157,18 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
       out[p.Cout] = tq;
     }
   }
+}
+
+// two positions interleaved: consecutive MFMAs never accumulate into the same registers
+__device__ __forceinline__ void mfma4x2(f32x16& c0, float4 a0, float4 b0, f32x16& c1, float4 a1, float4 b1) {
+  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c1, 0, 0, 0);
 }
 
 // XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
@@ -281,10 +299,15 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
       const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
       const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
 #endif
+#if WN_ILV
+      mfma4x2(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0, acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
+      mfma4x2(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2, acc[xl * 4 + 3], f4sub(t[1], t[3]), b3);
+#else
       mfma4(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0);
       mfma4(acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
       mfma4(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2);
       mfma4(acc[xl * 4 + 3], f4sub(t[1], t[3]), b3);
+#endif
     }
   };
 
@@ -296,6 +319,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   put_raw(0, raw0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#if WN_TIMING
+  float tsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
   auto step = [&](int c, auto kk) {
     constexpr int K = decltype(kk)::value;            // c % 4
     constexpr int sub = K & 1, sp = K >> 1;
@@ -309,6 +335,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     // end of the chunk vmcnt(4) has seen the DMA land while the four activation loads may still fly - they have until the
     // end of the NEXT chunk; waiting for them here as well (vmcnt(0)) cost 15 % of the kernel (tools/wino_ablate.sh).
     const bool raw_now = sub == 0 && st + 1 < nstage;
+#if WN_TIMING
+    const long long tk0 = clock64();
+#endif
 #if WN_ABL < 3 || WN_ABL >= 6           // 3: no global traffic in the loop at all; 5: no weight DMA; 6: no activation staging
     if (c + 1 < nchunk) fetch_b(WN_ABL == 7 ? 0 : c + 1, bnxt);              // 7: the same (cache-hot) chunk every time
 #endif
@@ -318,16 +347,38 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 #endif
     __builtin_amdgcn_sched_barrier(0);
     // staging of the next stage: into the buffer whose last readers were stage st - 1
+#if WN_TIMING
+    const long long tk1 = clock64();
+#endif
     compute(rcur, sub, bcur);
+#if WN_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const long long tk2 = clock64();
+#endif
     if (sub == 1 && st + 1 < nstage && (WN_ABL < 3 || WN_ABL == 5 || WN_ABL >= 7)) put_raw(st + 1, rnxt);
+#if WN_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const long long tk3 = clock64();
+#endif
 #if WN_ABL == 4          // 4: no barrier either
     return;
 #endif
     // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier
     if (raw_now) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if WN_TIMING
+    const long long tk4 = clock64();
+#endif
     __syncthreads();
+#if WN_TIMING
+    const long long tk5 = clock64();
+    tsum[0] += (float)(tk1 - tk0); tsum[1] += (float)(tk2 - tk1); tsum[2] += (float)(tk3 - tk2);
+    tsum[3] += (float)(tk4 - tk3); tsum[4] += (float)(tk5 - tk4);
+#endif
   };
+#if WN_TIMING
+  const long long tkernel0 = clock64();
+#endif
   for (int c = 0; c < nchunk; c += 4) {
     step(c, std::integral_constant<int, 0>());
     step(c + 1, std::integral_constant<int, 1>());
@@ -337,24 +388,36 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     }
   }
 
+#if WN_TIMING
+  const long long tkernel1 = clock64();
+#endif
   // ---------------------------------------------------------------- epilogue
   float* exb = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
   wino_epilogue<XH>(p, acc, exb + (wave & 3) * 2048, exb + ((wave & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw0), mh, nh, li, h,
                     lane, n, ty0, bm, bn);
+#if WN_TIMING
+  __syncthreads();
+  if (lane == 0) {      // [workgroup][wave][8]: dma/load issue, compute, staging, vmcnt wait, barrier, main loop, epilogue, chunks
+    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 8;
+    for (int k = 0; k < 5; ++k) o[k] = tsum[k];
+    o[5] = (float)(tkernel1 - tkernel0); o[6] = (float)(clock64() - tkernel1); o[7] = (float)nchunk;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Ping-pong variant.  In conv_wino_body the two wavefronts of a SIMD run the same code between the same barriers, so
-// whatever one of them waits for (LDS reads, the transform adds) nobody covers: tools/wino_ablate.sh gives every removed
-// piece its full time back.  Here the wavefronts of group G = 1 run half a chunk behind those of group 0:
-//   interval c, group 0:  reads + transform + MFMAs of chunk c (as before)
-//   interval c, group 1:  MFMAs of chunk c - 1 from fragments it holds in registers (a pure matrix stream that fills the
-//                         other group's bubbles), THEN reads + transform of chunk c into registers (under the other
-//                         group's MFMAs)
-// Group 1 reads the weight chunk c - 1 while the DMA of chunk c + 1 is in flight, hence a ring of three weight buffers
-// (three distinct __shared__ arrays, loop unrolled by three: see the note on LDS-DMA aliasing above); the activation
-// window keeps its two buffers, indexed at run time (no DMA writes them).  ppmap picks which wavefronts form a group:
-// 0: waves 0-3 / 4-7, 1: even / odd waves (whichever pairs the groups on the SIMDs).
+// Phase-shifted variant.  In conv_wino_body the two wavefronts of a SIMD run the same code between the same barriers; in-kernel
+// cycle counters (tools/wino_timing.py) show where a chunk's 6200 cycles go: 4430 for reads + transform + 32 MFMAs (the pipe
+// shared with the other wavefront: 4096 would be perfect), 500 to ISSUE eight vector-memory instructions (weight DMA +
+// activation loads: all eight wavefronts push 45 KB into a 64 B/clk path at the same moment and stall in order behind it),
+// 570 for the activation staging (ds_write_b128 goes at 79 B/clk), 650 at the barrier (mostly the slower wavefront of each
+// SIMD) - and nobody issues MFMAs during the 1070 cycles of memory work because both wavefronts of a SIMD do it together.
+// Here the wavefronts of group 1 do their memory work BETWEEN the two position halves of the chunk, those of group 0 at the
+// chunk boundary as before, so one group's stalls sit under the other group's MFMAs.  The weight ring is three deep (DMA two
+// chunks ahead: a DMA issued in mid-chunk has a whole chunk to land; three distinct __shared__ arrays, loop unrolled by
+// three: see the note on LDS-DMA aliasing above); the activation window keeps its two buffers, indexed at run time (no DMA
+// writes them).  ppmap picks the groups: 0: waves 0-3 / 4-7 (the two wavefronts of a SIMD: MI355X_MICROARCH.md, waves go
+// to SIMDs in cyclic order), 1: even / odd waves (A/B).
 template <int XH, bool ACT, int G>
 __device__ __forceinline__ void conv_wino_pp_body(const WinoParams& p, int vw, float4* raw, float4* bwA, float4* bwB,
                                                   float4* bwC) {
@@ -434,95 +497,77 @@ __device__ __forceinline__ void conv_wino_pp_body(const WinoParams& p, int vw, f
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // group 0: reads, transform and MFMAs of one chunk (the compiler's own just-in-time schedule)
-  auto compute = [&](const float4* rs, int sub, const float4* bw) {
+  // one chunk in two halves (position half 0, position half 1) so that group 1 can put its memory work between them
+  float4 d[3][4];
+  auto half0 = [&](const float4* rs, int sub, const float4* bw) {
     const float4* rq = rs + (2 * sub + h) * WN_SQ;
     const float4* bq = bw + bcol;
-    float4 d[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_SC + (j >> 1)];
+    float4 t[4];
 #pragma unroll
-    for (int xl = 0; xl < 2; ++xl) {
-      float4 t[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (xl == 0) t[j] = f4sub(d[0][j], d[2][j]);
-        else t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);
-      }
-      const int xi = xl ? xi1 : xi0;
-      const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
-      const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
-      mfma4(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0);
-      mfma4(acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
-      mfma4(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2);
-      mfma4(acc[xl * 4 + 3], f4sub(t[1], t[3]), b3);
-    }
+    for (int j = 0; j < 4; ++j) t[j] = f4sub(d[0][j], d[2][j]);
+    const float4 b0 = bq[(xi0 * 4 + 0) * 128], b1 = bq[(xi0 * 4 + 1) * 128];
+    const float4 b2 = bq[(xi0 * 4 + 2) * 128], b3 = bq[(xi0 * 4 + 3) * 128];
+    mfma4(acc[0], f4sub(t[0], t[2]), b0);
+    mfma4(acc[1], f4add(t[1], t[2]), b1);
+    mfma4(acc[2], f4sub(t[2], t[1]), b2);
+    mfma4(acc[3], f4sub(t[1], t[3]), b3);
   };
-  // group 1: the transformed fragments of a chunk, built column by column (12 registers of window data alive at a time)
-  float4 vf[8];
-  auto transform = [&](const float4* rs, int sub) {
-    const float4* rq = rs + (2 * sub + h) * WN_SQ;
-    float4 t0[4], t1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 d0 = rq[rowoff[0] + (j & 1) * WN_SC + (j >> 1)];
-      const float4 d1 = rq[rowoff[1] + (j & 1) * WN_SC + (j >> 1)];
-      const float4 d2 = rq[rowoff[2] + (j & 1) * WN_SC + (j >> 1)];
-      t0[j] = f4sub(d0, d2);
-      t1[j] = XH ? f4sub(d1, d0) : f4add(d1, d2);
-      __builtin_amdgcn_sched_barrier(0);      // one column at a time: clustered, the 12 reads would cost 48 registers
-    }
-    vf[0] = f4sub(t0[0], t0[2]); vf[1] = f4add(t0[1], t0[2]); vf[2] = f4sub(t0[2], t0[1]); vf[3] = f4sub(t0[1], t0[3]);
-    vf[4] = f4sub(t1[0], t1[2]); vf[5] = f4add(t1[1], t1[2]); vf[6] = f4sub(t1[2], t1[1]); vf[7] = f4sub(t1[1], t1[3]);
-  };
-  auto matrix = [&](const float4* bw) {
+  auto half1 = [&](const float4* bw) {
     const float4* bq = bw + bcol;
+    float4 t[4];
 #pragma unroll
-    for (int q8 = 0; q8 < 8; ++q8) {
-      const float4 b = bq[(((q8 >> 2) ? xi1 : xi0) * 4 + (q8 & 3)) * 128];
-      mfma4(acc[q8], vf[q8], b);
-    }
+    for (int j = 0; j < 4; ++j) t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);
+    const float4 b0 = bq[(xi1 * 4 + 0) * 128], b1 = bq[(xi1 * 4 + 1) * 128];
+    const float4 b2 = bq[(xi1 * 4 + 2) * 128], b3 = bq[(xi1 * 4 + 3) * 128];
+    mfma4(acc[4], f4sub(t[0], t[2]), b0);
+    mfma4(acc[5], f4add(t[1], t[2]), b1);
+    mfma4(acc[6], f4sub(t[2], t[1]), b2);
+    mfma4(acc[7], f4sub(t[1], t[3]), b3);
   };
 
   issue_raw(0);
   fetch_b(0, bwA);
+  if (nchunk > 1) fetch_b(1, bwB);
   put_raw(0, raw);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   auto step = [&](int c, auto kk) {
     constexpr int K = decltype(kk)::value;            // c % 3: weight ring position
     float4* const bcur = K == 0 ? bwA : (K == 1 ? bwB : bwC);
-    float4* const bnxt = K == 0 ? bwB : (K == 1 ? bwC : bwA);
-    float4* const bprv = K == 0 ? bwC : (K == 1 ? bwA : bwB);
+    float4* const bnx2 = K == 0 ? bwC : (K == 1 ? bwA : bwB);     // slot of chunk c + 2 = slot of chunk c - 1
     const int st = c >> 1, sub = c & 1;
     float4* const rcur = raw + (st & 1) * WN_RAWBUF;
     float4* const rnxt = raw + ((st + 1) & 1) * WN_RAWBUF;
-    const bool raw_now = sub == 0 && st + 1 < nstage;
-    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);      // ring slot of chunk c - 2, whose last readers (group 1) are behind the barrier
+    // the memory work of a chunk: weight DMA two chunks ahead (its slot's last readers, chunk c - 1, are behind the barrier),
+    // the next stage's activation loads (first chunk of a stage) or their staging into LDS (second chunk)
+    auto memwork = [&]() {
+      if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
+      if (c + 2 < nchunk) fetch_b(c + 2, bnx2);
+      if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);
+    };
+    if (G == 0) memwork();
     __builtin_amdgcn_sched_barrier(0);
-    if (raw_now) issue_raw(st + 1);
+    half0(rcur, sub, bcur);
     __builtin_amdgcn_sched_barrier(0);
-    if (G == 0) {
-      compute(rcur, sub, bcur);
-    } else {
-      if (c > 0) matrix(bprv);
-      __builtin_amdgcn_sched_barrier(0);
-      transform(rcur, sub);
-    }
-    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (G == 1) memwork();
+    __builtin_amdgcn_sched_barrier(0);
+    half1(bcur);
+    // Chunk c + 1's weights were fetched during chunk c - 1 and must have landed before the barrier; what THIS chunk issued
+    // (4 DMA instructions, 4 activation loads) may keep flying: vmcnt retires in order, so wait down to that many.
+    const int young = (c + 2 < nchunk ? 4 : 0) + (sub == 0 && st + 1 < nstage ? 4 : 0);
+    if (young == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
   for (int c = 0; c < nchunk; c += 3) {
     step(c, std::integral_constant<int, 0>());
     if (c + 1 < nchunk) step(c + 1, std::integral_constant<int, 1>());
     if (c + 2 < nchunk) step(c + 2, std::integral_constant<int, 2>());
-  }
-  if (G == 1) {          // the last chunk's products
-    const int k = (nchunk - 1) % 3;          // run-time pointer: one copy of the MFMA code (no DMA is in flight any more)
-    matrix(k == 0 ? bwA : (k == 1 ? bwB : bwC));
   }
   __syncthreads();       // every LDS read of the main loop is done: the buffers are free for the epilogue
   float* exb = reinterpret_cast<float*>(vw < 4 ? bwA : bwB);
@@ -652,7 +697,8 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   p.bpc = cdiv(cdiv(H, 2), p.R);
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
-  // ACVAE_WINO_PP: 0 = both wavefronts of a SIMD in step (conv_wino_body), 1 / 2 = ping-pong groups (waves 0-3 / 4-7, even / odd)
+  // ACVAE_WINO_PP: 0 (default) = conv_wino_body (both wavefronts of a SIMD in step, two weight buffers); 1 / 2 = the phase-shifted
+  // kernel (groups = waves 0-3 / 4-7, even / odd): 2.4 % faster alone on the deep layers, no difference inside the training step
   static const int pp = getenv("ACVAE_WINO_PP") ? atoi(getenv("ACVAE_WINO_PP")) : 0;
   p.ppmap = pp == 2 ? 1 : 0;
   if (pp) {
@@ -940,7 +986,8 @@ inline WgradPlan wino_wgrad_plan(int N, int H, int W, int Cin, int Cout) {
   g.total = N * g.spc;
   const int blocks = (Cin / 64) * (Cout / 64);
   // one workgroup per CU (100 KB of LDS, 8 wavefronts x 128 accumulators): K split so that the grid is one round of 256
-  int Z = 256 / blocks;
+  static const int zmul = getenv("ACVAE_WGW_ZMUL") ? atoi(getenv("ACVAE_WGW_ZMUL")) : 1;     // A/B: rounds of workgroups
+  int Z = 256 * zmul / blocks;
   if (Z < 1) Z = 1;
   if (Z > g.total) Z = g.total;
   g.per = (g.total + Z - 1) / Z;
