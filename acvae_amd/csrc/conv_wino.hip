@@ -894,23 +894,48 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   };
 
   // ---------------------------------------------------------------- main loop: one barrier per 16-tile stage
+#if WN_TIMING
+  float tsum[4] = {0.f, 0.f, 0.f, 0.f};
+#define WG_TICK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn = clock64(); tsum[k] += (float)(tn - tprev); tprev = tn; }
+  long long tprev = clock64();
+#else
+#define WG_TICK(k)
+#endif
   if (g_begin < g_end) {
     issue(g_begin);
     put(xw0, dy0);
     __syncthreads();
+#if WN_TIMING
+    tprev = clock64();
+#endif
     for (int g = g_begin; g < g_end; g += 2) {
       if (g + 1 < g_end) issue(g + 1);
+      WG_TICK(0)
       compute(xw0, dy0);
+      WG_TICK(1)
       if (g + 1 < g_end) put(xw1, dy1);                   // last read at stage g - 1, behind the barrier
+      WG_TICK(2)
       __syncthreads();
+      WG_TICK(3)
       if (g + 1 < g_end) {
         if (g + 2 < g_end) issue(g + 2);
+        WG_TICK(0)
         compute(xw1, dy1);
+        WG_TICK(1)
         if (g + 2 < g_end) put(xw0, dy0);
+        WG_TICK(2)
         __syncthreads();
+        WG_TICK(3)
       }
     }
   }
+#if WN_TIMING
+  if (lane == 0) {     // [workgroup][wave][8] over the start of dY (read long ago): load issue, compute, staging, barrier, stages
+    float* o = const_cast<float*>(p.dY) + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+    for (int k = 0; k < 4; ++k) o[k] = tsum[k];
+    o[4] = (float)(g_end - g_begin);
+  }
+#endif
 
   // ---------------------------------------------------------------- slab: [z][position][ci][co]
   constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;

@@ -50,3 +50,24 @@ for (H, W, Cin, Cout, act) in [(125, 8, 512, 512, True), (125, 8, 512, 512, Fals
     bw = t[:, :, 4].mean(dim=0) / nch
     print("    barrier wait per wave:", " ".join(f"{float(v):.0f}" for v in bw), " compute per wave:",
           " ".join(f"{float(v):.0f}" for v in (t[:, :, 1].mean(dim=0) / nch)))
+
+# ---- weight gradient: the sums are written over the start of dY at the end of the kernel
+print("weight gradient:")
+for (H, W, Cin, Cout, act) in [(125, 8, 512, 512, True), (1000, 64, 64, 64, True), (250, 16, 256, 256, False)]:
+    x = torch.randn(N, H, W, Cin, device="cuda")
+    dy = torch.randn(N, H, W, Cout, device="cuda")
+    sc = torch.rand(Cin, device="cuda") + 0.5 if act else None
+    sh = torch.randn(Cin, device="cuda") * 0.3 if act else None
+    dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    wsb = _lib.call("acvae_conv3x3_workspace_bytes", N, H, W, Cin, Cout)
+    ws = torch.zeros(int(wsb), dtype=torch.uint8, device="cuda")
+    for _ in range(1):
+        _lib.call("acvae_conv3x3_wgrad_wino", dy, x, sc, sh, dw, ws, wsb, N, H, W, Cin, Cout, _lib.current_stream())
+    torch.cuda.synchronize()
+    nwg = 256
+    t = dy.flatten()[:nwg * 64].view(nwg, 8, 8).double().cpu()
+    ns = t[:, :, 4].clamp_min(1)
+    per = (t[:, :, :4] / ns.unsqueeze(-1)).mean(dim=(0, 1))
+    print(f"{H}x{W} {Cin}->{Cout} act={int(act)}: {float(ns.mean()):.0f} stages per workgroup; cycles per 16-tile stage (ideal MFMA: 4096 per "
+          f"wave, 8192 per SIMD): load issue {float(per[0]):.0f}, reads+transform+MFMA {float(per[1]):.0f}, staging {float(per[2]):.0f}, "
+          f"barrier {float(per[3]):.0f}; sum {float(per.sum()):.0f}", flush=True)
