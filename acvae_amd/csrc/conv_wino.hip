@@ -87,8 +87,42 @@ struct WinoParams {
   int ppmap;            // ping-pong kernels: which wavefronts form a group (0: 0-3 / 4-7, 1: even / odd)
 };
 
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// The transform adds as v_pk_add_f32: two values per VALU issue slot.  In-kernel counters and the A/B below say the SIMD's issue
+// slots are what a chunk runs out of (every instruction a wavefront issues, MFMA or not, costs its cycles; halving the 64 adds
+// of a chunk: -4 %).  Written as inline asm: from <2 x float> IR the backend scalarises them again because every element ends
+// up as a separate MFMA operand.  IEEE add / subtract, the same rounding as the scalar instructions.  The compiler's hazard
+// recogniser does not look inside inline asm, so the block whose results feed MFMAs ends in the wait it would have inserted
+// between a VALU write and an MFMA reading the register as SrcA (without it the MFMA reads stale values - seen).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define WN_PK_SUB(d, a, b) "v_pk_add_f32 " d ", " a ", " b " neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define WN_PK_ADD(d, a, b) "v_pk_add_f32 " d ", " a ", " b "\n\t"
+// the vertical half: its results only feed the block below (VALU to VALU: no wait needed)
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) {
+  f32x2 lo, hi;
+  asm(WN_PK_SUB("%0", "%2", "%4") WN_PK_SUB("%1", "%3", "%5")
+      : "=&v"(lo), "=&v"(hi) : "v"(f32x2{a.x, a.y}), "v"(f32x2{a.z, a.w}), "v"(f32x2{b.x, b.y}), "v"(f32x2{b.z, b.w}));
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
+  f32x2 lo, hi;
+  asm(WN_PK_ADD("%0", "%2", "%4") WN_PK_ADD("%1", "%3", "%5")
+      : "=&v"(lo), "=&v"(hi) : "v"(f32x2{a.x, a.y}), "v"(f32x2{a.z, a.w}), "v"(f32x2{b.x, b.y}), "v"(f32x2{b.z, b.w}));
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+// the horizontal half of Bt d B for one vertical frequency: v = [t0 - t2, t1 + t2, t2 - t1, t1 - t3], MFMA operands
+__device__ __forceinline__ void wino_htrans(const float4 (&t)[4], float4 (&v)[4]) {
+  f32x2 o[8];
+  asm(WN_PK_SUB("%0", "%8", "%12") WN_PK_SUB("%1", "%9", "%13")
+      WN_PK_ADD("%2", "%10", "%12") WN_PK_ADD("%3", "%11", "%13")
+      WN_PK_SUB("%4", "%12", "%10") WN_PK_SUB("%5", "%13", "%11")
+      WN_PK_SUB("%6", "%10", "%14") WN_PK_SUB("%7", "%11", "%15")
+      "s_nop 1"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(f32x2{t[0].x, t[0].y}), "v"(f32x2{t[0].z, t[0].w}), "v"(f32x2{t[1].x, t[1].y}), "v"(f32x2{t[1].z, t[1].w}),
+        "v"(f32x2{t[2].x, t[2].y}), "v"(f32x2{t[2].z, t[2].w}), "v"(f32x2{t[3].x, t[3].y}), "v"(f32x2{t[3].z, t[3].w}));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = make_float4(o[2 * k][0], o[2 * k][1], o[2 * k + 1][0], o[2 * k + 1][1]);
+}
 __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
@@ -299,14 +333,16 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
       const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
       const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
 #endif
+      float4 v[4];
+      wino_htrans(t, v);
 #if WN_ILV
-      mfma4x2(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0, acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
-      mfma4x2(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2, acc[xl * 4 + 3], f4sub(t[1], t[3]), b3);
+      mfma4x2(acc[xl * 4 + 0], v[0], b0, acc[xl * 4 + 1], v[1], b1);
+      mfma4x2(acc[xl * 4 + 2], v[2], b2, acc[xl * 4 + 3], v[3], b3);
 #else
-      mfma4(acc[xl * 4 + 0], f4sub(t[0], t[2]), b0);
-      mfma4(acc[xl * 4 + 1], f4add(t[1], t[2]), b1);
-      mfma4(acc[xl * 4 + 2], f4sub(t[2], t[1]), b2);
-      mfma4(acc[xl * 4 + 3], f4sub(t[1], t[3]), b3);
+      mfma4(acc[xl * 4 + 0], v[0], b0);
+      mfma4(acc[xl * 4 + 1], v[1], b1);
+      mfma4(acc[xl * 4 + 2], v[2], b2);
+      mfma4(acc[xl * 4 + 3], v[3], b3);
 #endif
     }
   };
@@ -511,10 +547,12 @@ __device__ __forceinline__ void conv_wino_pp_body(const WinoParams& p, int vw, f
     for (int j = 0; j < 4; ++j) t[j] = f4sub(d[0][j], d[2][j]);
     const float4 b0 = bq[(xi0 * 4 + 0) * 128], b1 = bq[(xi0 * 4 + 1) * 128];
     const float4 b2 = bq[(xi0 * 4 + 2) * 128], b3 = bq[(xi0 * 4 + 3) * 128];
-    mfma4(acc[0], f4sub(t[0], t[2]), b0);
-    mfma4(acc[1], f4add(t[1], t[2]), b1);
-    mfma4(acc[2], f4sub(t[2], t[1]), b2);
-    mfma4(acc[3], f4sub(t[1], t[3]), b3);
+    float4 v[4];
+    wino_htrans(t, v);
+    mfma4(acc[0], v[0], b0);
+    mfma4(acc[1], v[1], b1);
+    mfma4(acc[2], v[2], b2);
+    mfma4(acc[3], v[3], b3);
   };
   auto half1 = [&](const float4* bw) {
     const float4* bq = bw + bcol;
@@ -523,10 +561,12 @@ __device__ __forceinline__ void conv_wino_pp_body(const WinoParams& p, int vw, f
     for (int j = 0; j < 4; ++j) t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);
     const float4 b0 = bq[(xi1 * 4 + 0) * 128], b1 = bq[(xi1 * 4 + 1) * 128];
     const float4 b2 = bq[(xi1 * 4 + 2) * 128], b3 = bq[(xi1 * 4 + 3) * 128];
-    mfma4(acc[4], f4sub(t[0], t[2]), b0);
-    mfma4(acc[5], f4add(t[1], t[2]), b1);
-    mfma4(acc[6], f4sub(t[2], t[1]), b2);
-    mfma4(acc[7], f4sub(t[1], t[3]), b3);
+    float4 v[4];
+    wino_htrans(t, v);
+    mfma4(acc[4], v[0], b0);
+    mfma4(acc[5], v[1], b1);
+    mfma4(acc[6], v[2], b2);
+    mfma4(acc[7], v[3], b3);
   };
 
   issue_raw(0);
@@ -778,13 +818,30 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
     sc = *reinterpret_cast<const float4*>(p.scale + cib * 64 + quad * 4);
     sh = *reinterpret_cast<const float4*>(p.shift + cib * 64 + quad * 4);
   }
-  float4 px[5], py[2];
-  unsigned xok = 0, yok = 0;
-  auto issue = [&](int g) {
+  // The gradient tiles go global -> LDS by LDS-DMA (no transform to apply, no registers, no ds_write): a DMA instruction of a
+  // wavefront moves one tile = 4 pixels x 64 channels, lane l = (pixel l / 16, 16-byte slot l % 16), and the XOR swizzle of the
+  // channel with the tile parity sits on the SOURCE address.  A DMA cannot zero-fill: lanes whose pixel lies below the image
+  // (odd H / the clip's last stage) are masked out of the DMA and store zeros themselves - nobody reads that buffer before
+  // the next barrier.
+  float4 px[5];
+  unsigned xok = 0;
+  auto issue = [&](int g, float* dys) {
     const int n = g / p.spc, s = g - n * p.spc;
     const int trow = s / p.segs, seg = s - trow * p.segs;
     const int ty0 = trow * p.RS, tx0 = seg * 16;          // first tile of the stage
-    xok = 0; yok = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = wave * 2 + i, pp = lane >> 4, pq = lane & 15;
+      const int y = 2 * (ty0 + (t >> p.st_shift)) + (pp >> 1), x = 2 * (tx0 + (t & (STW - 1))) + (pp & 1);
+      float* dst = dys + t * 256;
+      if (y < H) {
+        const float* src = p.dY + ((long)(n * H + y) * W + x) * p.Cout + cob * 64 + ((pq ^ (8 * (t & 1))) << 2);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+      } else {
+        *reinterpret_cast<float4*>(dst + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    xok = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int y = 2 * ty0 - 1 + (xyx[j] >> 8), x = 2 * tx0 - 1 + (xyx[j] & 255);
@@ -793,17 +850,8 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
       const long off = ok ? ((long)(n * H + y) * W + x) * p.Cin + cib * 64 + quad * 4 : 0;
       px[j] = *reinterpret_cast<const float4*>(p.X + off);
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int tp = (tid + 512 * j) >> 4, t = tp >> 2, pp = tp & 3;
-      const int y = 2 * (ty0 + (t >> p.st_shift)) + (pp >> 1), x = 2 * (tx0 + (t & (STW - 1))) + (pp & 1);
-      const bool ok = y < H;                               // tile rows past the image (odd H / last stage) contribute 0
-      yok |= (ok ? 1u : 0u) << j;
-      const long off = ok ? ((long)(n * H + y) * W + x) * p.Cout + cob * 64 + quad * 4 : 0;
-      py[j] = *reinterpret_cast<const float4*>(p.dY + off);
-    }
   };
-  auto put = [&](float* xw, float* dys) {
+  auto put = [&](float* xw) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       float4 v = px[j];
@@ -814,13 +862,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
       if (!((xok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((xlive >> j) & 1u) *reinterpret_cast<float4*>(xw + xlo[j]) = v;
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int tp = (tid + 512 * j) >> 4, t = tp >> 2;
-      float4 v = py[j];
-      if (!((yok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(dys + tp * 64 + ((quad * 4) ^ (32 * (t & 1)))) = v;
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of the same stage (older than the loads above) has landed
   };
 
   // ---------------------------------------------------------------- fragment addresses of this lane
@@ -902,27 +944,27 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
 #define WG_TICK(k)
 #endif
   if (g_begin < g_end) {
-    issue(g_begin);
-    put(xw0, dy0);
+    issue(g_begin, dy0);
+    put(xw0);
     __syncthreads();
 #if WN_TIMING
     tprev = clock64();
 #endif
     for (int g = g_begin; g < g_end; g += 2) {
-      if (g + 1 < g_end) issue(g + 1);
+      if (g + 1 < g_end) issue(g + 1, dy1);              // dy1 / xw1: last read at stage g - 1, behind the barrier
       WG_TICK(0)
       compute(xw0, dy0);
       WG_TICK(1)
-      if (g + 1 < g_end) put(xw1, dy1);                   // last read at stage g - 1, behind the barrier
+      if (g + 1 < g_end) put(xw1);
       WG_TICK(2)
       __syncthreads();
       WG_TICK(3)
       if (g + 1 < g_end) {
-        if (g + 2 < g_end) issue(g + 2);
+        if (g + 2 < g_end) issue(g + 2, dy0);
         WG_TICK(0)
         compute(xw1, dy1);
         WG_TICK(1)
-        if (g + 2 < g_end) put(xw0, dy0);
+        if (g + 2 < g_end) put(xw0);
         WG_TICK(2)
         __syncthreads();
         WG_TICK(3)
