@@ -789,14 +789,18 @@ struct WinoWgradParams {
   int per;              // stages per workgroup
 };
 
-template <int XH>
+// SS = log2(tiles per stage row) as a template parameter: every window offset of the eight tile pairs of a stage is then an
+// immediate of its ds_read (the issue slots are what the kernel runs out of; the per-pair address arithmetic was a quarter
+// of its non-MFMA instructions).
+template <int XH, int SS>
 __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float* xw0, float* xw1, float* dy0, float* dy1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
   const int ah = (wave >> 1) & 1, bh = wave >> 2;       // ci half, co half of this wavefront; XH = wave & 1
   const int z = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
   const int H = p.H, W = p.W;
-  const int STW = 1 << p.st_shift, WC = 2 * STW + 2, WR = 2 * p.RS + 2;
+  constexpr int STW = 1 << SS, WC = 2 * STW + 2;
+  const int WR = 2 * p.RS + 2;
   const int g_begin = z * p.per, g_end = min(p.total, g_begin + p.per);
 
   // ---------------------------------------------------------------- staging items (window coordinates are per thread)
@@ -866,9 +870,12 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   };
 
   // ---------------------------------------------------------------- fragment addresses of this lane
+  // tile of pair j for this lane half: t = 2j + kh -> tile row (2j) >> SS, tile column ((2j) & (STW-1)) + kh: kh only shifts the
+  // window by two pixel columns and flips the channel swizzle (window columns 0,1 carry the tile's own column parity = kh,
+  // columns 2,3 the other one)
   const int ci = ah * 32 + li, co = bh * 32 + li;
-  const int ci_s0 = ci, ci_s1 = ci ^ 32;                  // channel word for an even / odd tile-column parity
-  const int rowstride = WC * 64;
+  const int xo01 = kh * 128 + (ci ^ (32 * kh)), xo23 = kh * 128 + (ci ^ (32 * (1 - kh)));
+  constexpr int rowstride = WC * 64;
   const int bbase = kh * 256 + (co ^ (32 * kh));
 
   f32x16 acc[8];
@@ -880,18 +887,17 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   // Two register sets: the 16 LDS reads of tile pair j + 1 are issued before the 8 MFMAs of pair j (sched_barriers keep
   // them there; left alone the compiler reads each value just in front of the MFMA that takes it).
   struct Frag { float d[3][4]; float y[4]; };
-  auto load = [&](int j, const float* xw, const float* dys, Frag& f) {
-    const int t = 2 * j + kh;                            // this lane half's tile of the k-step
-    const int tyl = t >> p.st_shift, txl = t & (STW - 1);
-    const float* xb = xw + ((2 * tyl + XH) * WC + 2 * txl) * 64;
-    // window columns 0,1 have the tile's own column parity, columns 2,3 the other one
-    const int c01 = (txl & 1) ? ci_s1 : ci_s0, c23 = (txl & 1) ? ci_s0 : ci_s1;
+  auto load = [&](auto jj, const float* xw, const float* dys, Frag& f) {
+    constexpr int j = decltype(jj)::value;
+    constexpr int OFF = ((2 * ((2 * j) >> SS) + XH) * WC + 2 * ((2 * j) & (STW - 1))) * 64;
+    const float* x01 = xw + xo01 + OFF;
+    const float* x23 = xw + xo23 + OFF;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      f.d[a][0] = xb[a * rowstride + 0 * 64 + c01];
-      f.d[a][1] = xb[a * rowstride + 1 * 64 + c01];
-      f.d[a][2] = xb[a * rowstride + 2 * 64 + c23];
-      f.d[a][3] = xb[a * rowstride + 3 * 64 + c23];
+      f.d[a][0] = x01[a * rowstride + 0 * 64];
+      f.d[a][1] = x01[a * rowstride + 1 * 64];
+      f.d[a][2] = x23[a * rowstride + 2 * 64];
+      f.d[a][3] = x23[a * rowstride + 3 * 64];
     }
     const float* yb = dys + bbase + j * 512;
     f.y[0] = yb[0]; f.y[1] = yb[64]; f.y[2] = yb[128]; f.y[3] = yb[192];
@@ -921,18 +927,18 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   };
   auto compute = [&](const float* xw, const float* dys) {
     Frag fa, fb;
-    load(0, xw, dys, fa);
-#pragma unroll 1
-    for (int j = 0; j < 8; j += 2) {
-      load(j + 1, xw, dys, fb);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa);
-      __builtin_amdgcn_sched_barrier(0);
-      if (j + 2 < 8) load(j + 2, xw, dys, fa);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    load(std::integral_constant<int, 0>(), xw, dys, fa);
+#define WG_PAIR(J)                                                                       \
+    load(std::integral_constant<int, J + 1>(), xw, dys, fb);                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    mm(fa);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (J + 2 < 8) load(std::integral_constant<int, (J + 2 < 8 ? J + 2 : 0)>(), xw, dys, fa); \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    mm(fb);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);
+    WG_PAIR(0) WG_PAIR(2) WG_PAIR(4) WG_PAIR(6)
+#undef WG_PAIR
   };
 
   // ---------------------------------------------------------------- main loop: one barrier per 16-tile stage
@@ -993,12 +999,19 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   }
 }
 
-__global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p) {
-  __shared__ float xw0[WG_XW_WORDS], xw1[WG_XW_WORDS];
-  __shared__ float dy0[WG_DY_WORDS], dy1[WG_DY_WORDS];
-  if ((threadIdx.x >> 6) & 1) wino_wgrad_body<1>(p, xw0, xw1, dy0, dy1);
-  else wino_wgrad_body<0>(p, xw0, xw1, dy0, dy1);
+template <int SS>
+__device__ __forceinline__ void wino_wgrad_entry(const WinoWgradParams& p, float* xw0, float* xw1, float* dy0, float* dy1) {
+  if ((threadIdx.x >> 6) & 1) wino_wgrad_body<1, SS>(p, xw0, xw1, dy0, dy1);
+  else wino_wgrad_body<0, SS>(p, xw0, xw1, dy0, dy1);
 }
+#define WINO_WGRAD_KERNEL(SS)                                                                                    \
+  __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel_s##SS(WinoWgradParams p) {                     \
+    __shared__ float xw0[WG_XW_WORDS], xw1[WG_XW_WORDS];                                                         \
+    __shared__ float dy0[WG_DY_WORDS], dy1[WG_DY_WORDS];                                                         \
+    wino_wgrad_entry<SS>(p, xw0, xw1, dy0, dy1);                                                                 \
+  }
+WINO_WGRAD_KERNEL(1) WINO_WGRAD_KERNEL(2) WINO_WGRAD_KERNEL(3) WINO_WGRAD_KERNEL(4)
+#undef WINO_WGRAD_KERNEL
 
 // Slab reduction in two steps.  1: dU[pos][ci][co] = sum_z slab[z][pos][ci][co] (z in fixed order, accumulated in double), one
 // thread per element so that even the 64 x 64 layer (Z = 256) spreads over 65536 threads; the sum overwrites slab z = 0,
@@ -1084,7 +1097,13 @@ int conv3x3_wino_wgrad(const float* dY, const float* X, const float* scale, cons
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.st_shift = g.st_shift; p.RS = g.RS; p.segs = g.segs; p.spc = g.spc; p.total = g.total; p.per = g.per;
   prof_begin(ACVAE_PROF_CONV_WGRAD, st);
-  hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3(g.Z, Cin / 64, Cout / 64), dim3(512), 0, st, p);
+  const dim3 wgrid(g.Z, Cin / 64, Cout / 64);
+  switch (g.st_shift) {
+    case 1: hipLaunchKernelGGL(conv_wino_wgrad_kernel_s1, wgrid, dim3(512), 0, st, p); break;
+    case 2: hipLaunchKernelGGL(conv_wino_wgrad_kernel_s2, wgrid, dim3(512), 0, st, p); break;
+    case 3: hipLaunchKernelGGL(conv_wino_wgrad_kernel_s3, wgrid, dim3(512), 0, st, p); break;
+    default: hipLaunchKernelGGL(conv_wino_wgrad_kernel_s4, wgrid, dim3(512), 0, st, p); break;
+  }
   prof_end(ACVAE_PROF_CONV_WGRAD, st);
   const long total = (long)Cin * Cout, per_z = 16 * total;
   hipLaunchKernelGGL(wino_wgrad_zsum_kernel, dim3(cdiv(per_z, 256) > 8192 ? 8192 : cdiv(per_z, 256)), dim3(256), 0, st, slab, g.Z,
