@@ -827,6 +827,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   // channel with the tile parity sits on the SOURCE address.  A DMA cannot zero-fill: lanes whose pixel lies below the image
   // (odd H / the clip's last stage) are masked out of the DMA and store zeros themselves - nobody reads that buffer before
   // the next barrier.
+  const int WCin = W * p.Cin;
   float4 px[5];
   unsigned xok = 0;
   auto issue = [&](int g, float* dys) {
@@ -839,19 +840,23 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
       const int y = 2 * (ty0 + (t >> p.st_shift)) + (pp >> 1), x = 2 * (tx0 + (t & (STW - 1))) + (pp & 1);
       float* dst = dys + t * 256;
       if (y < H) {
-        const float* src = p.dY + ((long)(n * H + y) * W + x) * p.Cout + cob * 64 + ((pq ^ (8 * (t & 1))) << 2);
+        const float* src = p.dY + (unsigned)(((n * H + y) * W + x) * p.Cout + cob * 64 + ((pq ^ (8 * (t & 1))) << 2));
         __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
       } else {
         *reinterpret_cast<float4*>(dst + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    // 32-bit element offsets (the launcher refuses tensors of 2^31 elements or more): a wave-uniform base per stage plus a
+    // per-item part - no 64-bit multiplies per item
+    const int xbase = ((n * H + 2 * ty0 - 1) * W + (2 * tx0 - 1)) * p.Cin + cib * 64 + quad * 4;
     xok = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const int y = 2 * ty0 - 1 + (xyx[j] >> 8), x = 2 * tx0 - 1 + (xyx[j] & 255);
+      const int wy = xyx[j] >> 8, wx = xyx[j] & 255;
+      const int y = 2 * ty0 - 1 + wy, x = 2 * tx0 - 1 + wx;
       const bool ok = ((xlive >> j) & 1u) && y >= 0 && y < H && x >= 0 && x < W;
       xok |= (ok ? 1u : 0u) << j;
-      const long off = ok ? ((long)(n * H + y) * W + x) * p.Cin + cib * 64 + quad * 4 : 0;
+      const unsigned off = ok ? (unsigned)(xbase + wy * WCin + wx * p.Cin) : 0u;     // always a legal address
       px[j] = *reinterpret_cast<const float4*>(p.X + off);
     }
   };
@@ -902,28 +907,59 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
     const float* yb = dys + bbase + j * 512;
     f.y[0] = yb[0]; f.y[1] = yb[64]; f.y[2] = yb[128]; f.y[3] = yb[192];
   };
+  // Both operand transforms of a tile pair as ONE block of 11 v_pk_add_f32 (the scalar form needs 22 adds; issue slots are
+  // what the kernel runs out of).  Register pairs: P(a,0) = window row a, columns 0,1; P(a,1) = columns 2,3; Y0 / Y1 = gradient
+  // rows.  op_sel / op_sel_hi pick the dword of a pair per lane, neg_lo / neg_hi its sign:
+  //   t0 = XH ? r2 - r0 : r0 - r2,  t1 = XH ? r1 - r0 : r1 + r2        (both columns pairs: 4 instructions)
+  //   r1 = XH ? Y0 - Y1 : Y0 + Y1,  r0 = XH ? Y1 : Y0
+  //   A operands (a0,a1) = (t[0] - t[2], t[1] + t[2]),  (a2,a3) = (t[2] - t[1], t[3] - t[1])     for t0 and t1
+  //   B operands (b1,b2) = (r[0] + r[1], r[0] - r[1]),  b0 = r[0], b3 = r[1]                     for r0 and r1
+  // The block ends in the wait between a VALU write and an MFMA read of the register that the compiler's hazard recogniser
+  // would insert if it could see inside.
   auto mm = [&](const Frag& f) {
-    const float y00 = f.y[0], y01 = f.y[1], y10 = f.y[2], y11 = f.y[3];
-    // local position half 0: frequency 0 (XH = 0: rows 0,2; gradient row 0) / 3 (XH = 1: sign folded: rows 3 - 1; row 1)
-    // local position half 1: frequency 1 (rows 1 + 2; gradient rows 0 + 1) / 2 (rows 2 - 1; rows 0 - 1)
-    float t0[4], t1[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      t0[c] = XH ? f.d[2][c] - f.d[0][c] : f.d[0][c] - f.d[2][c];
-      t1[c] = XH ? f.d[1][c] - f.d[0][c] : f.d[1][c] + f.d[2][c];
-    }
-    const float r00 = XH ? y10 : y00, r01 = XH ? y11 : y01;
-    const float r10 = XH ? y00 - y10 : y00 + y10, r11 = XH ? y01 - y11 : y01 + y11;
-    // horizontal: v = [t0 - t2, t1 + t2, t2 - t1, t3 - t1] against dm = [r0, r0 + r1, r0 - r1, r1] (the minus of A's last row
-    // sits in v[3])
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[0] - t0[2], r00, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[1] + t0[2], r00 + r01, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[2] - t0[1], r00 - r01, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(t0[3] - t0[1], r01, acc[3], 0, 0, 0);
-    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[0] - t1[2], r10, acc[4], 0, 0, 0);
-    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[1] + t1[2], r10 + r11, acc[5], 0, 0, 0);
-    acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[2] - t1[1], r10 - r11, acc[6], 0, 0, 0);
-    acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(t1[3] - t1[1], r11, acc[7], 0, 0, 0);
+    f32x2 a01, a23, a45, a67, b12, b56, r1;
+    // the vertical differences overwrite the registers of window rows 0 / 1 (in-out operands): 16 register pairs in the block
+    f32x2 t0l = {f.d[0][0], f.d[0][1]}, t0h = {f.d[0][2], f.d[0][3]}, t1l = {f.d[1][0], f.d[1][1]}, t1h = {f.d[1][2], f.d[1][3]};
+    const f32x2 p20 = {f.d[2][0], f.d[2][1]}, p21 = {f.d[2][2], f.d[2][3]};
+    const f32x2 y0 = {f.y[0], f.y[1]}, y1 = {f.y[2], f.y[3]};
+    const f32x2 r0 = XH ? y1 : y0;
+#define WG_HORIZ(R0)                                                                                         \
+        "v_pk_add_f32 %0, %7, %8 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]\n\t"            /* a01 from t0 */ \
+        "v_pk_add_f32 %1, %8, %7 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* a23 */        \
+        "v_pk_add_f32 %2, %9, %10 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]\n\t"           /* a45 from t1 */ \
+        "v_pk_add_f32 %3, %10, %9 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* a67 */       \
+        "v_pk_add_f32 %4, " R0 ", " R0 " op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\t" /* b12 from r0 */ \
+        "v_pk_add_f32 %5, %6, %6 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\t"   /* b56 from r1 */ \
+        "s_nop 1"
+    if (XH)
+      asm("v_pk_add_f32 %9, %9, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"        // t1l = row1 - row0   (before row0 is overwritten)
+          "v_pk_add_f32 %10, %10, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"      // t1h
+          "v_pk_add_f32 %7, %11, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0l = row2 - row0
+          "v_pk_add_f32 %8, %12, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0h
+          "v_pk_add_f32 %6, %13, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"      // r1 = y0 - y1
+          WG_HORIZ("%14")
+          : "=&v"(a01), "=&v"(a23), "=&v"(a45), "=&v"(a67), "=&v"(b12), "=&v"(b56), "=&v"(r1), "+v"(t0l), "+v"(t0h), "+v"(t1l),
+            "+v"(t1h)
+          : "v"(p20), "v"(p21), "v"(y0), "v"(y1));
+    else
+      asm("v_pk_add_f32 %7, %7, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0l = row0 - row2
+          "v_pk_add_f32 %8, %8, %12 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0h
+          "v_pk_add_f32 %9, %9, %11\n\t"                                 // t1l = row1 + row2
+          "v_pk_add_f32 %10, %10, %12\n\t"                               // t1h
+          "v_pk_add_f32 %6, %13, %14\n\t"                                // r1 = y0 + y1
+          WG_HORIZ("%13")
+          : "=&v"(a01), "=&v"(a23), "=&v"(a45), "=&v"(a67), "=&v"(b12), "=&v"(b56), "=&v"(r1), "+v"(t0l), "+v"(t0h), "+v"(t1l),
+            "+v"(t1h)
+          : "v"(p20), "v"(p21), "v"(y0), "v"(y1));
+#undef WG_HORIZ
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[0], r0[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[1], b12[0], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[0], b12[1], acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[1], r0[1], acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a45[0], r1[0], acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a45[1], b56[0], acc[5], 0, 0, 0);
+    acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a67[0], b56[1], acc[6], 0, 0, 0);
+    acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a67[1], r1[1], acc[7], 0, 0, 0);
   };
   auto compute = [&](const float* xw, const float* dys) {
     Frag fa, fb;
@@ -1081,6 +1117,10 @@ bool conv3x3_wino_wgrad_ok(int H, int W, int Cin, int Cout) {
   if (H < 1 || W < 4 || W > 64 || (W & (W - 1)) != 0) return false;
   return Cin % 64 == 0 && Cout % 64 == 0;
 }
+// the kernel addresses X and dY with 32-bit element offsets
+static bool wino_wgrad_fits(int N, int H, int W, int Cin, int Cout) {
+  return (long)N * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31);
+}
 long conv3x3_wino_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout) {
   if (!conv3x3_wino_wgrad_ok(H, W, Cin, Cout)) return 0;
   return (long)wino_wgrad_plan(N, H, W, Cin, Cout).Z * 16 * Cin * Cout;
@@ -1089,7 +1129,7 @@ long conv3x3_wino_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout) {
 int conv3x3_wino_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
                        int N, int H, int W, int Cin, int Cout, hipStream_t st) {
   if (!dY || !X || !dW_oihw || !slab) return ACVAE_EINVAL;
-  if (!conv3x3_wino_wgrad_ok(H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
+  if (!conv3x3_wino_wgrad_ok(H, W, Cin, Cout) || !wino_wgrad_fits(N, H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
   if (!aligned16(dY) || !aligned16(X) || !aligned16(slab) || (scale && (!aligned16(scale) || !aligned16(shift)))) return ACVAE_EALIGN;
   const WgradPlan g = wino_wgrad_plan(N, H, W, Cin, Cout);
   WinoWgradParams p;

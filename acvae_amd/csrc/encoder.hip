@@ -167,8 +167,10 @@ template <class TA>
 int conv_wgrad(const TA* dY, const TA* X, const float* scale, const float* shift, float* dW_oihw, float* slab, int N, int H,
                int W, int Cin, int Cout, hipStream_t st) {
   if constexpr (sizeof(TA) == 4) {
-    if (wino_on() && acvae::conv3x3_wino_wgrad_ok(H, W, Cin, Cout))
-      return acvae::conv3x3_wino_wgrad(dY, X, scale, shift, dW_oihw, slab, N, H, W, Cin, Cout, st);
+    if (wino_on() && acvae::conv3x3_wino_wgrad_ok(H, W, Cin, Cout)) {
+      const int r = acvae::conv3x3_wino_wgrad(dY, X, scale, shift, dW_oihw, slab, N, H, W, Cin, Cout, st);
+      if (r != ACVAE_EUNSUPPORTED) return r;          // tensors of 2^31 elements or more: the implicit GEMM below
+    }
   }
   return acvae::conv3x3_wgrad(dY, X, scale, shift, dW_oihw, slab, N, H, W, Cin, Cout, st);
 }
