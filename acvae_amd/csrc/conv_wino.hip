@@ -639,6 +639,206 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_pp_act_kernel(WinoParams
   conv_wino_pp_entry<true>(p, raw, bwA, bwB, bwC);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One vertical frequency per wavefront (ACVAE_WINO_PP=4).  Roles: xi = wave & 3, tile half = wave >> 2; a wavefront holds the 4
+// horizontal positions of ITS frequency for 32 tiles x all 64 output channels (the same 128 accumulators).  Against the
+// position-half split of conv_wino_body a chunk needs 8 window reads instead of 12 and 16 packed adds instead of 32 per
+// wavefront (a frequency is a difference of TWO window rows) - the issue slots are what the kernel runs out of.  The price is
+// paid once per tile: the four frequencies of a tile meet through LDS in the epilogue (two passes of 64 KB).
+template <int XI, bool ACT>
+__device__ __forceinline__ void conv_wino_x4_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int mh = wave >> 2;
+  int bm, bn;
+  xcd_tile(gridDim.x, gridDim.y, bm, bn);
+  const int RW = wino_row_pitch(p.tw_shift), R = p.R;
+  const int n = bm / p.bpc, ty0 = (bm - n * p.bpc) * R;
+  const int H = p.H, W = p.W, C = p.C;
+  const int W2 = W + 2;
+  const int nitems = (2 * R + 2) * W2 * 4;
+  const int q = tid & 3;
+  unsigned okm = 0;
+  long goff[4];
+  int loff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + WN_THREADS * j;
+    const bool lv = e < nitems;
+    const int px = e >> 2;
+    const int ry = px / W2, rx = px - ry * W2;
+    const int y = 2 * ty0 - 1 + ry, x = rx - 1;
+    const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
+    okm |= (ok ? 1u : 0u) << j;
+    goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;
+    loff[j] = lv ? q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1) : WN_RAWBUF - 1 - (tid & 7);
+  }
+  float4 pv[4];
+  auto issue_raw = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
+  };
+  auto put_raw = [&](int st, float4* raw) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACT) {
+      sc = *reinterpret_cast<const float4*>(p.scale + st * 16 + q * 4);
+      sh = *reinterpret_cast<const float4*>(p.shift + st * 16 + q * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = pv[j];
+      if (ACT) {
+        v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+        v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+      }
+      const bool ok = (okm >> j) & 1u;
+      raw[loff[j]] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+  };
+  const int nchunk = C >> 3, nstage = C >> 4;
+  const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
+  auto fetch_b = [&](int c, float4* bw) {
+    const float* src = Ub + (long)c * (WN_BCHUNK * 4);
+    float* dst = reinterpret_cast<float*>(bw) + wave * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 2048, dst + i * 2048, 16, 0, 0);
+  };
+  int tyl_a, tx_a;
+  wino_tile(mh, li, p.tw_shift, tyl_a, tx_a);
+  const int abase = tyl_a * RW + tx_a;
+  // frequency XI = window row RA -/+ window row RB:  0: r0 - r2   1: r1 + r2   2: r2 - r1   3: r1 - r3
+  constexpr int RA = XI == 0 ? 0 : (XI == 2 ? 2 : 1), RB = XI == 0 ? 2 : (XI == 1 ? 2 : (XI == 2 ? 1 : 3));
+  const int offA = (RA & 1) * WN_SR + (RA >> 1) * RW + abase, offB = (RB & 1) * WN_SR + (RB >> 1) * RW + abase;
+  const int bcol = XI * 4 * 128 + h * 64 + li;
+
+  f32x16 acc[8];      // [position nu][column half]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  auto compute = [&](const float4* raw, int sub, const float4* bw) {
+    const float4* rq = raw + (2 * sub + h) * WN_SQ;
+    const float4* bq = bw + bcol;
+    float4 t[4], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = rq[offA + (j & 1) * WN_SC + (j >> 1)], b = rq[offB + (j & 1) * WN_SC + (j >> 1)];
+      t[j] = XI == 1 ? f4add(a, b) : f4sub(a, b);
+    }
+    wino_htrans(t, v);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const float4 b0 = bq[nu * 128], b1 = bq[nu * 128 + 32];
+      mfma4(acc[nu * 2 + 0], v[nu], b0);
+      mfma4(acc[nu * 2 + 1], v[nu], b1);
+    }
+  };
+
+  issue_raw(0);
+  fetch_b(0, bw0);
+  put_raw(0, raw0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto step = [&](int c, auto kk) {
+    constexpr int K = decltype(kk)::value;            // c % 4
+    constexpr int sub = K & 1, sp = K >> 1;
+    const int st = c >> 1;
+    float4* const bcur = sub ? bw1 : bw0;
+    float4* const bnxt = sub ? bw0 : bw1;
+    float4* const rcur = sp ? raw1 : raw0;
+    float4* const rnxt = sp ? raw0 : raw1;
+    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(rcur, sub, bcur);
+    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  for (int c = 0; c < nchunk; c += 4) {
+    step(c, std::integral_constant<int, 0>());
+    step(c + 1, std::integral_constant<int, 1>());
+    if (c + 2 < nchunk) {
+      step(c + 2, std::integral_constant<int, 2>());
+      step(c + 3, std::integral_constant<int, 3>());
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue: the four frequencies of a tile meet through LDS
+  // H_xi[b] = (b = 0: M0 + M1 + M2, b = 1: M1 - M2 - M3);  Y[0][b] = H_0 + H_1 + H_2,  Y[1][b] = H_1 - H_2 - H_3.
+  // Wavefront xi finishes output row a = xi & 1 of column half nbo = xi >> 1.  One pass per output column b: every wavefront
+  // writes its 32 values per lane ([column half][16 rows]), then reads the three frequencies it needs.
+  float* ex = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [xi][32][64 lanes]: 32 KB per tile half
+  constexpr int a = XI & 1, nbo = XI >> 1;
+  const int cout = bn * WN_TN + nbo * 32 + li;
+  float s = 0.f, qq = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (b) __syncthreads();           // the reads of pass 0 are done
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0 * 2 + nb][r], m1 = acc[1 * 2 + nb][r], m2 = acc[2 * 2 + nb][r], m3 = acc[3 * 2 + nb][r];
+        ex[(XI * 32 + nb * 16 + r) * 64 + lane] = b == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* e0 = ex + (nbo * 16 + r) * 64 + lane;
+      const float o = a == 0 ? (e0[0 * 2048] + e0[1 * 2048]) + e0[2 * 2048] : (e0[1 * 2048] - e0[2 * 2048]) - e0[3 * 2048];
+      int tyl, tx;
+      wino_tile(mh, (r & 3) + 8 * (r >> 2) + 4 * h, p.tw_shift, tyl, tx);
+      const int y = 2 * (ty0 + tyl) + a;
+      if (y < H) {
+        p.Y[((long)(n * H + y) * W + 2 * tx + b) * p.Cout + cout] = o;
+        s += o;
+        qq += o * o;
+      }
+    }
+  }
+  if (p.partials) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(raw0);   // [tile half x output row][2][64]
+    s += __shfl_xor(s, 32, 64);
+    qq += __shfl_xor(qq, 32, 64);
+    if (h == 0) {
+      red[((mh * 2 + a) * 2 + 0) * 64 + nbo * 32 + li] = s;
+      red[((mh * 2 + a) * 2 + 1) * 64 + nbo * 32 + li] = qq;
+    }
+    __syncthreads();
+    if (tid < WN_TN) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
+      float* out = p.partials + (long)bm * 2 * p.Cout + bn * WN_TN + tid;
+      out[0] = ts;
+      out[p.Cout] = tq;
+    }
+  }
+}
+template <bool ACT>
+__device__ __forceinline__ void conv_wino_x4_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
+  switch ((threadIdx.x >> 6) & 3) {
+    case 0: conv_wino_x4_body<0, ACT>(p, raw0, raw1, bw0, bw1); break;
+    case 1: conv_wino_x4_body<1, ACT>(p, raw0, raw1, bw0, bw1); break;
+    case 2: conv_wino_x4_body<2, ACT>(p, raw0, raw1, bw0, bw1); break;
+    default: conv_wino_x4_body<3, ACT>(p, raw0, raw1, bw0, bw1); break;
+  }
+}
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_x4_kernel(WinoParams p) {
+  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
+  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
+  conv_wino_x4_entry<false>(p, raw0, raw1, bw0, bw1);
+}
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_x4_act_kernel(WinoParams p) {
+  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
+  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
+  conv_wino_x4_entry<true>(p, raw0, raw1, bw0, bw1);
+}
+
 // ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift)
 template <bool ACT>
 __device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
@@ -738,10 +938,14 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
   // ACVAE_WINO_PP: 0 (default) = conv_wino_body (both wavefronts of a SIMD in step, two weight buffers); 1 / 2 = the phase-shifted
-  // kernel (groups = waves 0-3 / 4-7, even / odd): 2.4 % faster alone on the deep layers, no difference inside the training step
+  // kernel (groups = waves 0-3 / 4-7, even / odd): 2.4 % faster alone on the deep layers, no difference inside the training step;
+  // 4 = one vertical frequency per wavefront: 2 % faster for Cin >= 256, 1-4 % slower below (its epilogue costs more)
   static const int pp = getenv("ACVAE_WINO_PP") ? atoi(getenv("ACVAE_WINO_PP")) : 0;
   p.ppmap = pp == 2 ? 1 : 0;
-  if (pp) {
+  if (pp == 4) {           // one vertical frequency per wavefront
+    if (scale) hipLaunchKernelGGL(conv_wino_x4_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(conv_wino_x4_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  } else if (pp) {
     if (scale) hipLaunchKernelGGL(conv_wino_pp_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
     else hipLaunchKernelGGL(conv_wino_pp_kernel, grid, dim3(WN_THREADS), 0, st, p);
   } else {
