@@ -237,8 +237,15 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     live |= (lv ? 1u : 0u) << j;
     okm |= (ok ? 1u : 0u) << j;
     goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;     // always a legal address
-    // items past the window write a slot nobody reads (the staging code then has no branch and can be interleaved with MFMAs)
-    loff[j] = lv ? q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1) : WN_RAWBUF - 1 - (tid & 7);
+    // Which items are zero padding (left / right pad columns, rows above / below the clip) does not change over the stages of a
+    // workgroup: their slots are zeroed ONCE in both buffers here, and afterwards these items - like the ones past the
+    // window - write a slot nobody reads.  The staging code then has neither a branch nor a mask.
+    const int slot = q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1);
+    if (lv && !ok) {
+      raw0[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+      raw1[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    loff[j] = ok ? slot : WN_RAWBUF - 1 - (tid & 7);
   }
   float4 pv[4];
   auto issue_raw = [&](int st) {
@@ -263,8 +270,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
         v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
         v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
       }
-      const bool ok = (okm >> j) & 1u;                                   // zero padding / rows of another clip
-      raw[loff[j]] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      raw[loff[j]] = v;
     }
   };
   // weight chunk c: 32 KB, already in LDS order; one LDS-DMA instruction of a wave moves 1 KB
