@@ -33,6 +33,9 @@ using namespace mfma;
 #ifndef WN_TIMING
 #define WN_TIMING 0   // 1: per-wavefront cycle sums of the main-loop phases written over the start of Y (tools/wino_timing.py)
 #endif
+#ifndef WN_PRIO
+#define WN_PRIO 0     // 1: s_setprio alternates between the two wavefronts of a SIMD inside a chunk (A/B)
+#endif
 #ifndef WN_ILV
 #define WN_ILV 0      // 1: MFMAs of two positions interleaved (A/B: tools/wino_ablate.sh)
 #endif
@@ -324,6 +327,13 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 #endif
 #pragma unroll
     for (int xl = 0; xl < 2; ++xl) {
+#if WN_PRIO
+      // the arbiter prefers the older wavefront of a SIMD (tools/wino_timing.py: 4010 against 4720 cycles per chunk, and the chunk
+      // ends when the slower one does): the younger one gets the higher priority in the first half of the chunk, the older in
+      // the second
+      if (xl == 0) { if (nh) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      else { if (nh) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#endif
       float4 t[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -9,7 +9,7 @@ cd "$ROOT/acvae_amd/csrc"
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-function"
 OBJS=$(ls *.o | grep -v conv_wino.o)
 for n in ${ABLS:-1 2 3 4 5 6 7}; do
-  DEF="-DWN_ABL=$n"; [ "$n" = "ilv" ] && DEF="-DWN_ILV=1"
+  DEF="-DWN_ABL=$n"; [ "$n" = "ilv" ] && DEF="-DWN_ILV=1"; [ "$n" = "prio" ] && DEF="-DWN_PRIO=1"
   /opt/rocm/bin/hipcc $FLAGS $DEF -c conv_wino.hip -o /tmp/conv_wino_abl$n.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libacvae_abl$n.so $OBJS /tmp/conv_wino_abl$n.o
 done
