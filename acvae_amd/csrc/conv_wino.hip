@@ -11,8 +11,8 @@
 //   * the activation window (2R+2 pixel rows x W+2 columns, 16 channels per stage) is staged ONCE, with the previous
 //     layer's BatchNorm+ReLU and the zero padding applied on the way, into four (row parity, column parity) planes, so
 //     that the 16 tiles a 16-lane LDS read group serves are 16 consecutive 16-byte slots;
-//   * every wavefront builds the Bt d B fragments of its 8 positions in registers from 12 ds_read_b128 (64 adds per
-//     32 MFMAs) - the vertical half of the transform splits cleanly over the two position halves: rows 0-2 / 1-3;
+//   * every wavefront builds the Bt d B fragments of its 8 positions in registers from 12 ds_read_b128 (64 adds, issued as
+//     32 v_pk_add_f32, per 32 MFMAs) - the vertical half of the transform splits cleanly over the two position halves: rows 0-2 / 1-3;
 //   * G g G^T is precomputed per step into the exact LDS image of a weight panel (wino_weights_kernel) and streams
 //     global -> LDS by LDS-DMA, 32 KB per 8-channel chunk;
 //   * the epilogue applies At . A in registers, the two position halves of a tile meet through LDS once per tile, and
