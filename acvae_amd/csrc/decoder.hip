@@ -462,7 +462,6 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
     const float* hprev = t ? hp_all + (long)(t - 1) * Hp : zeros;
     const long ldh = t ? (long)Tc * Hp : Hp;
     const float* cprev = t ? c_all + (long)(t - 1) * Hp : nullptr;
-    ACVAE_TRY(acvae::copy_rows(hpprev + (long)t * Hp, (long)Tc * Hp, hprev, ldh, N, Hp, sp));
     if (t == 0) ACVAE_TRY(acvae::copy_rows(rnn_p + 2 * E, ld3E, nullptr, 0, N, E, sp));  // last_z = 0
     // gates += last_z . W_ih[:, 2E:3E]^T + h . W_hh^T + b_hh
     ACVAE_TRY(gemm2(rnn_p + (long)t * 3 * E + 2 * E, ld3E, P(TP_P_WIH) + 2 * E, 3 * E, E, hprev, ldh, P(TP_P_WHH), Hp,
@@ -567,6 +566,9 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
       if (!train) ACVAE_TRY(acvae::finish_rows(seqs, Tc, unfinished, t, end_idx, N, st));
     }
   }
+  // h_{t-1} of the prior LSTM for its weight gradient (one shifted copy of hp_all after the loop instead of a copy per step)
+  ACVAE_TRY(acvae::copy_rows(hpprev, (long)Tc * Hp, nullptr, 0, N, Hp, st));
+  if (Tc > 1) ACVAE_TRY(acvae::copy_rows(hpprev + Hp, (long)Tc * Hp, hp_all, (long)Tc * Hp, N, (Tc - 1) * Hp, st));
   if (h_final) ACVAE_TRY(acvae::copy_rows(h_final, H, outputs + (long)(Tc - 1) * H, (long)Tc * H, N, H, st));
   if (hp_final) ACVAE_TRY(acvae::copy_rows(hp_final, Hp, hp_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp, st));
   if (cp_final) ACVAE_TRY(acvae::copy_rows(cp_final, Hp, c_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp, st));
