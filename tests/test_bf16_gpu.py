@@ -105,7 +105,7 @@ def test_bf16_loss_vs_oracle_at_config2_shape():
                             ("mse", mse, ores["mse"])):
         got, want = float(got.detach()), float(want.detach())
         report[name] = (got, want)
-        assert abs(got - want) <= 2e-2 * max(1.0, abs(want)), (name, got, want)
+        assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (name, got, want)   # measured 1.1e-5 (loss), <= 2e-5 each
     seq_o = ores["out"]["seqs"]
     valid = torch.arange(L - 1).unsqueeze(0) < torch.as_tensor(lens1).unsqueeze(1)
     match = float((out["seqs"].cpu()[valid] == seq_o[valid]).double().mean())
@@ -113,8 +113,8 @@ def test_bf16_loss_vs_oracle_at_config2_shape():
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
     print(f"bf16 vs fp32 oracle at B=32,T=1000: {report}; greedy token match {match:.4f}; "
           f"grad norm {float(gn):.6f} vs {float(ores['grad_norm']):.6f}")
-    assert match >= 0.90, match
-    assert abs(float(gn) - float(ores["grad_norm"])) <= 5e-2 * float(ores["grad_norm"])
+    assert match >= 0.97, match                                  # measured 0.991
+    assert abs(float(gn) - float(ores["grad_norm"])) <= 1e-2 * float(ores["grad_norm"])   # measured 3e-4
 
 
 def test_bf16_train_step_runs_and_is_deterministic():

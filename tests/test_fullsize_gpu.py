@@ -129,13 +129,17 @@ def test_inference_n5_samples_config5():
             assert bool((r[int(idx[0]):] == 2).all())
 
 
-@pytest.mark.parametrize("B,T", [(32, 1000), (5, 999), (9, 517), (3, 1601)])
+C4_FEAT_LENS = np.array([3000, 2900, 2500, 2000, 1600, 1500, 1000, 999, 640, 512, 400, 333, 160, 100, 48, 17])
+
+
+@pytest.mark.parametrize("B,T", [(32, 1000), (16, 3000), (5, 999), (9, 517), (3, 1601)])
 def test_loss_vs_oracle_at_config2_full_size(B, T):
-    """BASELINE configs[1] itself (B=32, T=1000, V=5000, E=512, 22-token captions), and the same model on batch sizes /
-    frame counts that are no multiple of any tile (ragged caption and feature lengths): one forward + loss on the HIP
-    path against the oracle on the same weights, batch, dropout masks and noise — north_star's bar, |loss diff| <= 1e-4,
-    plus token ids exact; the gradient norm (through the whole backward) within 2e-4 (5e-4 for the small odd batches,
-    where one ReLU-boundary flip weighs more)."""
+    """BASELINE configs[1] itself (B=32, T=1000, V=5000, E=512, 22-token captions), configs[3] itself (B=16, T=3000 ->
+    S=187, the ragged feature lengths of test_long_audio_config4_t3000: Winograd row blocks at H=3000/1500/750/375), and
+    the same model on batch sizes / frame counts that are no multiple of any tile (ragged caption and feature lengths):
+    one forward + loss on the HIP path against the oracle on the same weights, batch, dropout masks and noise —
+    north_star's bar, |loss diff| <= 1e-4, plus token ids exact; the gradient norm (through the whole backward) within
+    2e-4 (5e-4 for the small odd batches, where one ReLU-boundary flip weighs more)."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import acvae_oracle as O
@@ -144,6 +148,10 @@ def test_loss_vs_oracle_at_config2_full_size(B, T):
     model = build(5).train()
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     feats, caps, fl, cl = O.synthetic_batch(B, T, V, L, seed=4, ragged=True)
+    if (B, T) == (16, 3000):
+        fl = C4_FEAT_LENS.copy()
+        for b in range(B):
+            feats[b, int(fl[b]):] = 0.0
     rec = {}
     torch.manual_seed(9); random.seed(9)
     ores = O.OracleTrainer(state, V).step(feats, fl.copy(), caps, cl, 1.0, 0, record=rec, apply_update=False)
@@ -151,6 +159,10 @@ def test_loss_vs_oracle_at_config2_full_size(B, T):
     model.noise = dict(eps_q=rec["eps_q"], eps_p=rec["eps_p"])
     random.seed(9)
     out = model(feats.cuda(), fl.copy(), caps, cl, ss_ratio=1.0, dis_ratio=0)
+    if (B, T) == (16, 3000):
+        assert out["attn_weights"].shape == (16, 187, L - 1)
+        close_w = (out["attn_weights"].detach().cpu() - ores["out"]["attn_weights"]).abs().max()
+        assert float(close_w) <= 2e-5, float(close_w)
     lens1 = np.asarray(cl) - 1
     ce = LabelSmoothingLoss(V, 0.1).masked(out["logits"], caps[:, 1:].to(torch.long), lens1)
     kl = Normal_kl_loss()(out["q_means"], out["q_logs"], out["p_means"], out["p_logs"])
@@ -164,6 +176,31 @@ def test_loss_vs_oracle_at_config2_full_size(B, T):
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
     tol = 2e-4 if B >= 32 else 5e-4
     assert abs(float(gn) - float(ores["grad_norm"])) <= tol * float(ores["grad_norm"]), (float(gn), float(ores["grad_norm"]))
+
+
+def test_inference_n5_vs_oracle_config5_full_size():
+    """configs[4] at full size against the oracle (not only properties): 4 clips x 5 z-samples, T=1000, V=5000, E=512,
+    greedy decode with the prior's z every step (models/vae_model.py:880-894, runner :101-104 replication) on the same
+    eps -> token ids bit-exact, first-step logits within fp32 rounding."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import acvae_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    model = build(5).eval()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    feats, _, fl, _ = O.synthetic_batch(4, 1000, V, L, seed=6, ragged=True)
+    f5 = feats.repeat(5, 1, 1)
+    l5 = [int(x) for _ in range(5) for x in fl]                # feats.repeat tiles the batch: clip = row % 4
+    eps = torch.randn(20, 20, E, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        want = O.hybrid_forward(state, f5, np.asarray(l5), training=False, method="greedy", noise=dict(eps_p=eps))
+        model.noise = dict(eps_p=eps)
+        got = model(f5.cuda(), list(l5), method="greedy", beam_size=5)
+    assert torch.equal(got["seqs"].cpu(), want["seqs"])
+    d0 = (got["logits"][:, 0].cpu() - want["logits"][:, 0]).abs().max()
+    assert float(d0) <= 2e-5 + 1e-4 * float(want["logits"][:, 0].abs().max()), float(d0)
+    rows = got["seqs"].cpu()[0::4]
+    assert len({tuple(r.tolist()) for r in rows}) > 1          # different z -> different captions of clip 0
 
 
 def test_training_steps_do_not_leak_device_memory():

@@ -171,6 +171,11 @@ def test_conv3x3_winograd_real_block_geometry():
                                  (3, 21, 4, 512, 512), (1, 250, 16, 128, 128), (2, 125, 8, 64, 64), (5, 40, 64, 64, 64)]:
         run_conv_wino(N, H, W, Cin, Cout, True, seed=7)
         run_conv_wino(N, H, W, Cin, Cout, False, seed=8)
+    # the heights of BASELINE configs[3] (T = 3000: H = 3000 / 1500 / 750 / 375 at W = 64 / 32 / 16 / 8; the last one ends in
+    # a half-empty row block), every element against fp64
+    for (H, W) in [(3000, 64), (1500, 32), (750, 16), (375, 8)]:
+        run_conv_wino(1, H, W, 64, 64, True, seed=9)
+        run_conv_wino(1, H, W, 64, 64, False, seed=10)
     ws = ws_buf(1 << 20)
     t = torch.zeros(1 << 16, device="cuda")
     for (H, W, Cin, Cout) in [(8, 6, 64, 64), (8, 2, 64, 64), (8, 8, 24, 64), (8, 8, 64, 96)]:
