@@ -376,7 +376,7 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
                                         int E, int H, int A, int V, int Eenc, int start_idx, int end_idx, void* stream,
                                         void* aux_stream, int sample_method, float temp, const float* sample_noise,
                                         const uint8_t* emb_keep, float emb_drop_p) {
-  if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p < 1.f)) return ACVAE_EINVAL;
+  if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p <= 1.f)) return ACVAE_EINVAL;   // p = 1: nn.Dropout zeroes everything
   if (sample_method != ACVAE_SAMPLE_GREEDY &&
       ((sample_method != ACVAE_SAMPLE_GUMBEL && sample_method != ACVAE_SAMPLE_MULTINOMIAL) || !sample_noise ||
        !(temp > 0.f)))
@@ -481,7 +481,7 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
                                   ldof(cnt, 3 * E), M, E, st));
     if (emb_keep)          // the decoder's word-embedding dropout (models/decoder.py:33,184), mask [Tc][N][E]
       ACVAE_TRY(acvae::dropout_rows(rnn_d + (long)t0 * 3 * E, ld3E, 3 * E, emb_keep + (long)t0 * N * E, E, (long)N * E,
-                                    1.f / (1.f - emb_drop_p), N, cnt, E, st));
+                                    emb_drop_p < 1.f ? 1.f / (1.f - emb_drop_p) : 0.f, N, cnt, E, st));
     // z: posterior sample unless this step drew the prior (vae_model.py:800-808); one copy when no step did
     if (cnt == Tc && train && !prior_feeds_decoder) {
       ACVAE_TRY(acvae::copy_rows(rnn_d + 2 * E, 3 * E, q_z, E, R, E, st));
@@ -600,7 +600,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
                                 int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S, int E,
                                 int H, int A, int V, int Eenc, void* stream, void* aux_stream, const uint8_t* emb_keep,
                                 float emb_drop_p) {
-  if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p < 1.f)) return ACVAE_EINVAL;
+  if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p <= 1.f)) return ACVAE_EINVAL;   // p = 1: nn.Dropout zeroes everything
   DecLayout L;
   ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
   if (!params || !grads || !mem_in || !mem_lens || !lens1 || !eps_p || !dis_flags_host || !outputs || !attn_w ||
@@ -748,7 +748,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     // d(rnn_input) for the embedding and z columns
     ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, c));                    // d emb
     if (emb_keep)          // back through the word-embedding dropout
-      ACVAE_TRY(acvae::dropout_rows(drnn, (long)Tc * E, E, emb_keep, E, (long)N * E, 1.f / (1.f - emb_drop_p), N, Tc, E, c));
+      ACVAE_TRY(acvae::dropout_rows(drnn, (long)Tc * E, E, emb_keep, E, (long)N * E, emb_drop_p < 1.f ? 1.f / (1.f - emb_drop_p) : 0.f, N, Tc, E, c));
     ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, c));  // d z
     ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, c));
     ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, c));

@@ -2,6 +2,8 @@
 surface and ``VAERNNBahdanauAttnDecoder`` (:164-203).  Parameter names/shapes/initialisation follow the
 reference (``word_embeddings``, ``model`` = nn.GRU container, ``classifier``, ``attn``).  The step
 arithmetic lives in libacvae_hip.so and is driven by Hybrid_VAEModel through acvae_decode_fwd/bwd."""
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -23,14 +25,14 @@ class _ProjTableFn(torch.autograd.Function):
         E = w.shape[0]
         table = torch.empty(V, E, device=emb.device)
         _lib.call("acvae_gemm_nt", emb, D0, w, D0, b, table, E, V, E, D0, 0, _lib.current_stream())
-        ctx.owner = owner
+        ctx.owner = None if owner is None else weakref.ref(owner)   # no ctx -> model -> table cache -> ctx cycle
         ctx.save_for_backward(emb, w)
         return table
 
     @staticmethod
     def backward(ctx, d_table):
         emb, w = ctx.saved_tensors
-        owner = ctx.owner
+        owner = None if ctx.owner is None else ctx.owner()
         V, D0 = emb.shape
         E = w.shape[0]
         d_table = d_table.contiguous().float()
@@ -53,8 +55,10 @@ class _ProjTableFn(torch.autograd.Function):
             cb = _lib.call("acvae_colsum_workspace_bytes", E)
             cws = scratch_buffer(int(cb), w.device, tag="projemb_b")
             _lib.call("acvae_colsum", d_table, V, E, d_b, cws, cb, st)
-        if owner is not None and owner._grad_ready_cb is not None:
-            owner._grad_ready_cb("projemb")         # the last decode-side gradients are queued now
+        if owner is not None:
+            owner.decoder._table_cache = None       # the table (and its graph) is spent
+            if owner._grad_ready_cb is not None:
+                owner._grad_ready_cb("projemb")     # the last decode-side gradients are queued now
         return None, d_emb, d_w, d_b
 
 
@@ -105,12 +109,21 @@ class RNNDecoder(BaseDecoder):
             return we.weight
         owner = self._owner() if getattr(self, "_owner", None) is not None else None
         token = getattr(owner, "_forward_token", None)       # refreshed at every model forward (and reused by its backward)
+        # valid for ONE model forward and only while the three parameters are what they were when it was built (an
+        # optimiser step, load_state_dict or an in-place edit bumps _version); callers outside a model forward (the
+        # step-wise decoder / prior API) have no token and always rebuild
+        key = (token, we[0].weight._version, we[1].weight._version, we[1].bias._version, we[0].weight.data_ptr(),
+               we[1].weight.data_ptr(), torch.is_grad_enabled())
         hit = getattr(self, "_table_cache", None)
-        if hit is not None and owner is not None and hit[0] == token:
+        if hit is not None and token is not None and hit[0] == key:
             return hit[1]
         table = _ProjTableFn.apply(owner, we[0].weight, we[1].weight, we[1].bias)
-        self._table_cache = (token, table)
+        self._table_cache = (key, table) if token is not None else None
         return table
+
+    def train(self, mode=True):
+        self._table_cache = None
+        return super().train(mode)
 
     def init_hidden(self, bs):
         """models/decoder.py:94-98"""

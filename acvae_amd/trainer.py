@@ -13,6 +13,7 @@ backward, ``clip_grad_norm_(max_grad_norm)``, ``Adam.step`` — with the MI355X-
     reference uses plain BatchNorm2d) and rank 0's running buffers are broadcast before each forward
     (DDP's default broadcast_buffers=True).
 """
+import contextlib
 import math
 import os
 
@@ -33,9 +34,10 @@ class FlatGradExchange:
     average like torch DDP's.  Device-agnostic (RCCL on MI355X, gloo in the CPU tests).
 
     Stream contract (RCCL): a collective is ordered behind the stream that is CURRENT when it is issued, nothing else.
-    A bucket whose gradients were produced on more than one stream therefore names the other producers explicitly:
-    ``after`` is a list of events (recorded behind the last kernel that writes into the bucket on those streams) that
-    the issuing stream waits for first.  ``finish()`` orders the collectives in front of the caller's current stream.
+    Nothing here relies on which stream that happens to be: every bucket is issued from a dedicated exchange stream
+    that first waits for (a) an event recorded on the announcing stream behind the last kernel queued there - the
+    producer of the bucket - and (b) every event in ``after`` (recorded behind the last kernel that writes into the
+    bucket on any OTHER stream).  ``finish()`` orders the collectives in front of the caller's current stream.
     A bucket larger than ``max_chunk`` elements goes on the wire as several collectives (first byte sooner; the ring
     pipelines them).  ``issued`` records the (bucket, chunk) sequence: it must be identical on every rank."""
 
@@ -49,6 +51,7 @@ class FlatGradExchange:
             off += n
         assert off <= flat.numel()
         self._works, self._done, self.issued = [], set(), []
+        self._xstream = None
 
     def begin(self):
         self._works, self._done, self.issued = [], set(), []
@@ -60,17 +63,25 @@ class FlatGradExchange:
         a, b = self.slices[i]
         if b <= a:
             return
+        ctx = contextlib.nullcontext()
         if self.flat.is_cuda:
-            cur = torch.cuda.current_stream(self.flat.device)
+            dev = self.flat.device
+            produced = torch.cuda.Event()
+            produced.record(torch.cuda.current_stream(dev))       # behind the kernels the announcing node just queued
+            if self._xstream is None:
+                self._xstream = torch.cuda.Stream(dev)
+            self._xstream.wait_event(produced)
             for ev in after:
                 if ev is not None:
-                    cur.wait_event(ev)
+                    self._xstream.wait_event(ev)
+            ctx = torch.cuda.stream(self._xstream)
         k = 0
-        while a < b:
-            e = min(b, a + self.max_chunk)
-            self._works.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.issued.append((i, k))
-            a, k = e, k + 1
+        with ctx:
+            while a < b:
+                e = min(b, a + self.max_chunk)
+                self._works.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.issued.append((i, k))
+                a, k = e, k + 1
 
     def finish(self):
         for i in range(len(self.slices)):
@@ -135,7 +146,17 @@ class TrainStep:
             model._grad_ready_cb = self._on_grads_ready
             model.encoder._grad_ready_cb = self._on_grads_ready
         self._buf_work = None
+        self._decode_event = self._text_event = None
+        self._decode_deferred = self._projemb_seen = False
         self._proj_emb = isinstance(model.decoder.word_embeddings, torch.nn.Sequential)
+        # The BatchNorm-buffer broadcast issued at the end of step() is joined wherever the buffers are read outside
+        # step(): any forward of the model or of its encoder (validation right after the last training step, reference
+        # runners/pytorch_runner_vae.py:339-345) and state_dict() (checkpointing).
+        if self.world > 1:
+            join = lambda *_a, **_k: self.sync_buffers()
+            model.register_forward_pre_hook(join)
+            model.encoder.register_forward_pre_hook(join)
+            model.register_state_dict_pre_hook(join)
         if self._dist():
             dist.broadcast(self.flat_p, src=0, group=self.pg)
             if self.flat_buf is not None:
@@ -208,14 +229,28 @@ class TrainStep:
             self._decode_event = event
             if not self._proj_emb:               # with projected embeddings their gradients are still to come ("projemb")
                 self.exchange.ready(0)
-        elif tag == "projemb":
-            self.exchange.ready(0, after=(getattr(self, "_decode_event", None),))
         elif tag == "decode_deferred":
-            self._decode_event = event           # announced at "text", behind the side stream's trailing work
+            # trailing-gradient mode: the decode backward's parameter gradients are still running on the SIDE stream;
+            # `event` (main stream) does not cover them, the stream "text" fires on does
+            self._decode_event = event
+            self._decode_deferred = True
+        elif tag == "projemb":
+            # _ProjTableFn's backward: the last three decode-side gradients.  Autograd runs it after the decode backward
+            # and - the node being older than the posterior's - normally after "text" as well; bucket 0 goes out behind
+            # the decode backward (event), the side stream's trailing work and the posterior backward (text event) and
+            # the kernels just queued on the current stream.  Should it ever fire before "text" in trailing-gradient
+            # mode, nothing on this stream covers the side stream's work yet: leave the bucket to "text".
+            self._projemb_seen = True
+            if self._text_event is not None or not self._decode_deferred:
+                self.exchange.ready(0, after=(self._decode_event, self._text_event))
         elif tag == "text":
+            if torch.cuda.is_available() and self.flat_g.is_cuda:
+                self._text_event = torch.cuda.Event()
+                self._text_event.record(torch.cuda.current_stream())
             # decode-written gradients not announced yet (trailing-gradient mode): they were queued on this (side)
-            # stream or on the main stream behind `_decode_event`
-            self.exchange.ready(0, after=(getattr(self, "_decode_event", None),))
+            # stream or on the main stream behind `_decode_event`; with projected embeddings bucket 0 waits for "projemb"
+            if not self._proj_emb or self._projemb_seen:
+                self.exchange.ready(0, after=(self._decode_event,))
             self.exchange.ready(1)
         elif isinstance(tag, tuple):
             if tag[1] == self.model.encoder.N_BLOCKS:
@@ -245,7 +280,8 @@ class TrainStep:
 
     def step(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):
         self.sync_buffers()
-        self._decode_event = None
+        self._decode_event = self._text_event = None
+        self._decode_deferred = self._projemb_seen = False
         for p in self.order:
             p.grad = None                                             # optimizer.zero_grad(set_to_none=True)
         loss, parts, _ = self.forward_loss(feats, feat_lens, caps, cap_lens, ss_ratio, dis_ratio, kl_weight)

@@ -407,7 +407,8 @@ class Hybrid_VAEModel(CaptionModel):
             sample_noise = torch.empty(Tc, N, V)
         # the decoder's word-embedding nn.Dropout (models/decoder.py:33,184): one [N,1,E] Bernoulli draw per step, made
         # by decoder.forward, i.e. after the step's prior noise and disentangle coin and before sample_next_word
-        drop_p = float(self.decoder.dropoutlayer.p) if (train and self.training) else 0.0
+        drop_p = float(self.decoder.dropoutlayer.p) if self.decoder.training else 0.0   # nn.Dropout acts on decoder.training alone,
+        # also in the 2-input forward of a model left in train() (models/decoder.py:184)
         dec_keep = None
         if drop_p > 0.0 and (replay is None or replay.get("dec_keep") is None):
             dec_keep = torch.empty(Tc, N, E, dtype=torch.bool)

@@ -391,6 +391,12 @@ def sample_next_word(logits, method="greedy", temp=1, noise=None):
     return w_t.view(-1).detach().long(), logprobs.gather(1, w_t).squeeze(1), noise
 
 
+def _embed_size(state):
+    """embed_size of the decoder / prior (models/vae_model.py:676: mean_log_out = Linear(E, 2E)); with projected pretrained
+    embeddings (Sequential(Embedding, Linear)) the Embedding's width is NOT it, and the GRU's hidden size need not be."""
+    return state["mean_log_out.weight"].shape[1]
+
+
 def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_ratio=1.0, dis_ratio=0,
                    training=True, method="greedy", temp=1, max_length=MAX_LENGTH, noise=None, record=None,
                    mutate_lens=True, dec_dropout=0.0):
@@ -406,8 +412,7 @@ def hybrid_forward(state, feats, feat_lens, caps=None, cap_lens=None, *, ss_rati
         enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
     mem, mem_lens = enc["audio_embeds"], enc["audio_embeds_lens"]
     N = mem.shape[0]
-    E = state["decoder.model.weight_hh_l0"].shape[1] if "decoder.word_embeddings.weight" not in state else \
-        state["decoder.word_embeddings.weight"].shape[1]
+    E = _embed_size(state)
     H = state["decoder.model.weight_hh_l0"].shape[1]
     out: Dict[str, object] = {}
     train = caps is not None
@@ -491,8 +496,7 @@ def beam_search(state, feats, feat_lens, beam_size=3, max_length=MAX_LENGTH, eps
         enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
     mem_all, lens_all = enc["audio_embeds"], enc["audio_embeds_lens"]
     N = mem_all.shape[0]
-    E = state["decoder.model.weight_hh_l0"].shape[1] if "decoder.word_embeddings.weight" not in state else \
-        state["decoder.word_embeddings.weight"].shape[1]
+    E = _embed_size(state)
     H = state["decoder.model.weight_hh_l0"].shape[1]
     V = state["decoder.classifier.weight"].shape[0]
     seqs_out = torch.full((N, max_length), END_IDX, dtype=torch.long)
@@ -539,8 +543,7 @@ def diverse_beam_search(state, feats, feat_lens, beam_size=5, group_size=5, dive
         enc["audio_embeds"] = F.linear(enc["audio_embeds"], state["ln.weight"], state["ln.bias"])
     mem_all, lens_all = enc["audio_embeds"], enc["audio_embeds_lens"]
     N = mem_all.shape[0]
-    E = state["decoder.model.weight_hh_l0"].shape[1] if "decoder.word_embeddings.weight" not in state else \
-        state["decoder.word_embeddings.weight"].shape[1]
+    E = _embed_size(state)
     H = state["decoder.model.weight_hh_l0"].shape[1]
     V = state["decoder.classifier.weight"].shape[0]
     bdash = beam_size // group_size

@@ -11,6 +11,8 @@ Checked on every rank:
   2. after the step the flat parameter buffer is BITWISE equal on all ranks;
   3. it is BITWISE equal to the result of one un-bucketed all-reduce of the whole gradient buffer issued after the
      backward (two operands: a + b == b + a bit for bit, whatever the bucket / piece structure);
+  5. state_dict() / an evaluation forward on a rank other than 0 right after a step sees rank 0's BatchNorm buffers (the
+     asynchronous broadcast is joined by hooks, not only by the next step());
   4. with BatchNorm in evaluation mode (clips independent) the averaged gradient equals the
      gradient of ONE process on the concatenated batch.
 """
@@ -79,6 +81,20 @@ def _worker(rank, world, port, backend, q):
     flat_bucketed = ts.flat_p.cpu().numpy().copy()
     grads_avg = (ts.flat_g[:ts.n_active] * (1.0 / world)).cpu().numpy().copy()
 
+    # (5) the BatchNorm-buffer broadcast issued at the end of step() is joined by whoever reads the buffers next:
+    # state_dict() right after the last training step (no explicit ts.sync_buffers()) sees rank 0's statistics
+    assert ts._buf_work is not None
+    sd = model.state_dict()
+    assert ts._buf_work is None
+    bn_bufs = torch.cat([v.detach().float().reshape(-1).cpu() for k, v in sd.items() if "running_" in k]).numpy().copy()
+    _step(ts, model, shard)
+    model.eval()
+    model.noise = None
+    with torch.no_grad():                           # an evaluation forward right after a step joins it as well
+        model(shard[0].cuda(), shard[2].copy(), method="greedy")
+    assert ts._buf_work is None
+    model.train()
+
     # the same step with ONE all-reduce of the whole active gradient range, issued after the backward
     model2 = _model()
     ts2 = TrainStep(model2, V)
@@ -104,7 +120,7 @@ def _worker(rank, world, port, backend, q):
                torch.cat([s[4] for s in shards]), torch.cat([s[5] for s in shards], dim=1))
         _step(ts4, model4, cat)
         g_cat = ts4.flat_g[:ts4.n_active].cpu().numpy().copy()
-    q.put((rank, issued, flat_bucketed, flat_single, float(parts["loss"]), grads_avg, g_eval, g_cat))
+    q.put((rank, issued, flat_bucketed, flat_single, float(parts["loss"]), grads_avg, g_eval, g_cat, bn_bufs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -123,8 +139,10 @@ def _run(backend):
     for p in ps:
         p.join(timeout=120)
         assert p.exitcode == 0
-    issued0, flat0, single0, loss0, gavg0, geval0, gcat = res[0]
-    issued1, flat1, single1, loss1, gavg1, geval1, _ = res[1]
+    issued0, flat0, single0, loss0, gavg0, geval0, gcat, bn0 = res[0]
+    issued1, flat1, single1, loss1, gavg1, geval1, _, bn1 = res[1]
+    # 5. rank 1 read rank 0's running statistics (the shards differ, so the local ones would not be equal)
+    assert np.array_equal(bn0, bn1) and float(np.abs(bn0).max()) > 0
     # 1. same collective sequence everywhere; decode-written bucket first, shallow encoder bucket last
     assert issued0 == issued1, (issued0, issued1)
     buckets = [b for b, _ in issued0]
