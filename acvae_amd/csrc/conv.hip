@@ -18,69 +18,10 @@
 #include "conv.h"
 #include "prof.h"
 
-#ifndef ACVAE_FRAG_PREFETCH
-#define ACVAE_FRAG_PREFETCH 0
-#endif
-
 namespace {
 using namespace mfma;
 
 // ------------------------------------------------------------------ im2col loaders
-template <int NR>
-struct ConvRowLoader {  // NT A-operand: tile rows = output pixels (NR per loader thread), k = (tap, ci)
-  const float* X;
-  const float* scale;  // nullable: act = identity
-  const float* shift;
-  int H, W, C, M;
-  int ph[NR], pw[NR];
-  long pbase[NR];
-  int cq;
-  __device__ __forceinline__ void init(int row0, int lt) {
-    cq = (lt % KT) * 4;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int p = row0 + (lt / KT) + RPP * j;
-      if (p < M) {
-        pw[j] = p % W;
-        ph[j] = (p / W) % H;
-        pbase[j] = (long)p * C;
-      } else {
-        pw[j] = -100000; ph[j] = -100000; pbase[j] = 0;
-      }
-    }
-  }
-  __device__ __forceinline__ void issue(int, int kstep, int, Pending<NR>& p) const {
-    const int k0 = kstep * BK;
-    const int tap = k0 / C;            // wave-uniform: a K-step never straddles taps (32 | C)
-    const int ci = k0 - tap * C + cq;
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    const long off = (long)(dy * W + dx) * C + ci;
-    if (scale) {
-      p.sc = *reinterpret_cast<const float4*>(scale + ci);
-      p.sh = *reinterpret_cast<const float4*>(shift + ci);
-    }
-    p.mask = 0;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int hh = ph[j] + dy, ww = pw[j] + dx;
-      const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
-      p.v[j] = *reinterpret_cast<const float4*>(ok ? X + pbase[j] + off : X);   // always a legal address
-      p.mask |= (ok ? 1u : 0u) << j;
-    }
-  }
-  __device__ __forceinline__ void finish(Pending<NR>& p) const {
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      float4 v = p.v[j];
-      if (scale) {
-        v.x = fmaxf(v.x * p.sc.x + p.sh.x, 0.f); v.y = fmaxf(v.y * p.sc.y + p.sh.y, 0.f);
-        v.z = fmaxf(v.z * p.sc.z + p.sh.z, 0.f); v.w = fmaxf(v.w * p.sc.w + p.sh.w, 0.f);
-      }
-      p.v[j] = ((p.mask >> j) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-};
-
 // x / d for 0 <= x < 2^40 / d by one 64-bit multiply (mul = ceil(2^40 / d)): the pixel -> (row, column) split of the
 // weight-gradient loader runs every K-step, where two integer divisions cost more issue slots than the loads they feed
 struct FastDiv {
@@ -204,9 +145,9 @@ constexpr int CV_BMT = 128;
 constexpr int CV_ROWS = CV_BMT + 2;
 constexpr int CV_AR = 5;            // float4 slots per loader thread for the strip: 4 full passes + rows 128, 129
 // 53.8 KB for BN = 64 with LDS-DMA panels (three workgroups per CU), 74.9 KB for BN = 128 (two)
-template <int BN, bool BDMA, bool ADMA>
+template <int BN, bool BDMA>
 struct alignas(16) ConvSmem {
-  alignas(16) float a[2][CV_ROWS * (ADMA ? BK : LDS_LD)];
+  alignas(16) float a[2][CV_ROWS * LDS_LD];
   alignas(16) float b[2][BN * (BDMA ? BK : LDS_LD)];
 };
 
@@ -264,17 +205,10 @@ struct ConvStripLoader {   // strip row j <-> pixel q = row0 - 1 + j, read at ve
 // lane-linear, [BN rows][32 floats] unpadded, and the bank spread comes from an XOR swizzle of the 16-byte chunk index
 // with the row (chunk c of row r sits at position c ^ (r & 7)), applied on the SOURCE address by the loader and on the
 // read address by the matrix waves.  Needs N % BN == 0 (an LDS-DMA cannot zero-fill).
-// ADMA (needs BDMA; only when the strip carries no BatchNorm+ReLU transform: data gradients and the convolutions that
-// read a pooled activation): the activation strip goes by LDS-DMA as well, a third of it per sub-stage, into the same
-// swizzled lane-linear image [130 rows][32 floats].  A DMA cannot zero-fill, so rows outside the tensor are fetched from
-// a clamped address and the matrix waves zero the lanes whose tap leaves the image vertically (okt / okb), as they
-// already do horizontally - a tap that leaves the tensor always leaves the image one way or the other.
-template <int BN, bool BDMA, bool ADMA, class Epilogue>
+template <int BN, bool BDMA, class Epilogue>
 __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<true, BN / 32> bl, int M, int N, int C,
                                               int W, int block_m, int block_n, const Epilogue& ep,
-                                              ConvSmem<BN, BDMA, ADMA>& sm) {
-  static_assert(!ADMA || BDMA, "the strip DMA shares the weight panels' wait");
-  constexpr int NAI = (CV_ROWS + 7) / 8;   // 8-row DMA instructions per strip (17), 6 per sub-stage
+                                              ConvSmem<BN, BDMA>& sm) {
   // Matrix wavefronts 2 x 2: (64-row half, BN/2-column half).  For BN = 64 a variant whose second index split the
   // 32-channel K-step instead (every wave a 64 x 64 tile, fewer LDS fragment reads per MFMA, halves added through LDS
   // before the epilogue) measured 1353 -> 1390 us: that kernel is not bound by LDS reads (nor by occupancy: three
@@ -337,28 +271,9 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
     // An LDS-DMA is ordered for the readers only by the issuing wave's vmcnt wait followed by a barrier; hipcc places
     // that wait in front of __syncthreads() by itself, the explicit one keeps the kernel independent of that.
     auto dma_wait = [&]() { if (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-    // third `part` of the strip of group grp: strip row r <-> pixel row0 - 1 + r at vertical offset dy
-    auto fetch_a = [&](int buf, int grp, int part) {
-      const int dyi = grp / nchunk, chunk = grp - dyi * nchunk;
-      const int lw = lt >> 6, l = lt & 63;
-      const int sw = (l & 7) ^ (l >> 3);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int k = part * 6 + lw + 4 * j;
-        const int r = k * 8 + (l >> 3);
-        long q = (long)row0 - 1 + r + (long)(dyi - 1) * W;
-        q = q < 0 ? 0 : (q > (long)M - 1 ? (long)M - 1 : q);
-        const float* src = al.X + q * C + chunk * BK + sw * 4;
-        if (lw + 4 * j < 6 && k < NAI && r < CV_ROWS) __builtin_amdgcn_global_load_lds(src, &sm.a[buf][k * 8 * BK], 16, 0, 0);
-      }
-    };
-    if (ADMA) {
-      fetch_a(0, 0, 0); fetch_a(0, 0, 1); fetch_a(0, 0, 2);
-    } else {
-      al.issue(0, 0, pa);
-    }
+    al.issue(0, 0, pa);
     fetch_b(0, kstep_of(0, 0));
-    if (!ADMA) put_a(0);
+    put_a(0);
     put_b(0);
     dma_wait();
     __syncthreads();
@@ -367,9 +282,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
       for (int dxi = 0; dxi < 3; ++dxi) {
         const int s = grp * 3 + dxi;
         const int g1 = grp + 1;
-        if (ADMA) {
-          if (g1 < ngrp) fetch_a(g1 & 1, g1, dxi);   // the buffer's last readers (group grp - 1) are through
-        } else if (dxi == 0 && g1 < ngrp) {      // the next strip's loads fly for three sub-stages
+        if (dxi == 0 && g1 < ngrp) {             // the next strip's loads fly for three sub-stages
           const int dyi = g1 / nchunk;
           al.issue(dyi, g1 - dyi * nchunk, pa);
         }
@@ -378,7 +291,7 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
           put_b((s + 1) & 1);
         } else if (g1 < ngrp) {
           fetch_b((s + 1) & 1, kstep_of(g1, 0));
-          if (!ADMA) put_a(g1 & 1);
+          put_a(g1 & 1);
           put_b((s + 1) & 1);
         }
         dma_wait();
@@ -388,82 +301,31 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
   } else {
     // ------------------------------------------------------------------ matrix wavefronts
     // border masks of this lane's two tile rows: pixel p = row0 + wm*64 + i*32 + li
-    bool okl[2], okr[2], okt[2], okb[2];
+    bool okl[2], okr[2];
     // 16-byte chunk of this lane's first weight fragment in the swizzled panel row: k pair ^ (row & 7); the group index
     // g * 2 occupies other bits than lh, so it can be xor-ed in
     const int bsw = lh ^ (li & 7);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int px = row0 + wm * 64 + i * 32 + li;
-      const int w = px % W, h = (px / W) % al.H;
+      const int w = px % W;
       okl[i] = w > 0; okr[i] = w < W - 1;
-      okt[i] = h > 0; okb[i] = h < al.H - 1;
     }
     __syncthreads();
     for (int grp = 0; grp < ngrp; ++grp) {
-      const float* Ag = ADMA ? sm.a[grp & 1] + (wm * 64 + li) * BK
-                             : sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh;
-      bool vok[2] = {true, true};
-      if (ADMA) {
-        const int dyi = grp / nchunk;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) vok[i] = dyi == 0 ? okt[i] : (dyi == 2 ? okb[i] : true);
-      }
+      const float* Ag = sm.a[grp & 1] + (wm * 64 + li) * LDS_LD + 4 * lh;
 #pragma unroll
       for (int dxi = 0; dxi < 3; ++dxi) {
-        const float* As = Ag + dxi * (ADMA ? BK : LDS_LD);   // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
-        const int asw = (lh ^ ((li + dxi) & 7)) << 2;       // ADMA: swizzled chunk of this lane's first fragment
+        const float* As = Ag + dxi * LDS_LD;                 // strip row of pixel p + (dxi - 1) is (p - row0) + dxi
         const float* Bs = sm.b[(grp * 3 + dxi) & 1] + (wn * (BN / 2) + li) * (BDMA ? BK : LDS_LD) + (BDMA ? 0 : 4 * lh);
-#if ACVAE_FRAG_PREFETCH
-        // Fragments of 8-channel group g + 1 are read from LDS BEFORE the 16 MFMAs of group g are issued (two register
-        // sets): left to itself the compiler reads them just in time, and the matrix pipe then drains for the LDS round
-        // trip at every group boundary (ds_read ... s_waitcnt lgkmcnt ... v_mfma: seen in the ISA of round 1's kernel).
-        float4 afq[2][2], bfq[2][NTN];
-        auto load_frags = [&](int g, float4 (&af)[2], float4 (&bf)[NTN]) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            af[i] = ADMA ? *reinterpret_cast<const float4*>(As + i * 32 * BK + ((g << 3) ^ asw))
-                         : *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
-#pragma unroll
-          for (int j = 0; j < NTN; ++j)
-            bf[j] = BDMA ? *reinterpret_cast<const float4*>(Bs + j * 32 * BK + (((g * 2) ^ bsw) << 2))
-                         : *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + g * 8);
-        };
-        load_frags(0, afq[0], bfq[0]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          if (g + 1 < NG) load_frags(g + 1, afq[(g + 1) & 1], bfq[(g + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);        // the reads above stay above the MFMAs below
-          float4 af[2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            af[i] = afq[g & 1][i];
-            if (dxi == 0 && !okl[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (dxi == 2 && !okr[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ADMA && !vok[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-          const float4 (&bf)[NTN] = bfq[g & 1];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NTN; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-            }
-        }
-#else
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           float4 af[2], bf[NTN];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            af[i] = ADMA ? *reinterpret_cast<const float4*>(As + i * 32 * BK + ((g << 3) ^ asw))
-                         : *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
+            af[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + g * 8);
             if (dxi == 0 && !okl[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (dxi == 2 && !okr[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ADMA && !vok[i]) af[i] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int j = 0; j < NTN; ++j)
@@ -479,7 +341,6 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
             }
         }
-#endif
         __syncthreads();
       }
     }
@@ -488,27 +349,16 @@ __device__ __forceinline__ void conv_nt_block(ConvStripLoader al, PlainLoader<tr
   ep.template run<CV_BMT, BN, NTN>(acc, row0, col0, wm, wn, li, lh, M, N, &sm.a[0][0], matrix_wave);
 }
 
-template <int BN, bool BDMA, bool ADMA = false>
+template <int BN, bool BDMA>
 __global__ __launch_bounds__(nt_threads<CV_BMT>(), 2) void conv_igemm3_kernel(ConvStripLoader al,
                                                                               const float* __restrict__ Wp,
                                                                               ConvStatsEpilogue ep, int M, int Cout,
                                                                               int K) {
-  __shared__ ConvSmem<BN, BDMA, ADMA> sm;
+  __shared__ ConvSmem<BN, BDMA> sm;
   PlainLoader<true, BN / 32> bl{Wp, K, Cout, K};
   int bm, bn;
   xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  conv_nt_block<BN, BDMA, ADMA>(al, bl, M, Cout, al.C, al.W, bm, bn, ep, sm);
-}
-
-// BMT x BN tile; the A operand (im2col rows) carries the previous layer's BatchNorm+ReLU when al.scale != nullptr.
-template <int BMT, int BN>
-__global__ __launch_bounds__(nt_threads<BMT>(), (BMT / 32 + 4) / 4) void conv_igemm_kernel(
-    ConvRowLoader<BMT / 32> al, const float* __restrict__ Wp, ConvStatsEpilogue ep, int M, int Cout, int K) {
-  __shared__ NtSmem<BMT, BN> sm;
-  PlainLoader<true, BN / 32> bl{Wp, K, Cout, K};
-  int bm, bn;
-  xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  nt_block<BMT, BN>(al, bl, M, Cout, K, bm, bn, ep, sm);
+  conv_nt_block<BN, BDMA>(al, bl, M, Cout, al.C, al.W, bm, bn, ep, sm);
 }
 
 template <int WM, int WN>
@@ -528,23 +378,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   const int kb = z * k_per;
   const int ke = min(M, kb + k_per);
   tn_block<WM, WN>(al, bl, Cout, NC, kb, ke, bx, by, slab + (long)z * Cout * NC, NC, 0, sm);
-}
-
-// NC = 576 (Cin = 64): 192-column tiles (3 exactly) instead of 2.25 of the 256-wide / 4.5 of the 128-wide ones
-template <int EM>
-__global__ __launch_bounds__(256, 2) void conv_wgrad192_kernel(const float* __restrict__ dY, ConvKMajorLoader bl,
-                                                               float* __restrict__ slab, int M, int Cout, int NC,
-                                                               int k_per) {
-  __shared__ TnSmemG<2 * EM * 32, 192> sm;
-  PlainKMajorLoader<true> al{dY, Cout, Cout, M};
-  const int tiles = gridDim.x * gridDim.y;
-  const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const int xcd = b & 7, idx = b >> 3;
-  const int z = (idx / tiles) * 8 + xcd, tile = idx % tiles;
-  const int bx = tile % gridDim.x, by = tile / gridDim.x;
-  const int kb = z * k_per;
-  const int ke = min(M, kb + k_per);
-  tn_block_g<2, 2, EM, 3>(al, bl, Cout, NC, kb, ke, bx, by, slab + (long)z * Cout * NC, NC, 0, sm);
 }
 
 // ------------------------------------------------------------------ weight gradient with horizontal-tap reuse
@@ -1298,36 +1131,18 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
   if (!aligned16(X) || !aligned16(Wp) || !aligned16(Y)) return ACVAE_EALIGN;
   const int M = N * H * W, K = 9 * Cin;
   ConvStatsEpilogue ep{Y, partials, Cout};
-  // A/B switch: 0 = one tap per stage (conv_igemm_kernel), 1 = strip kernel, 2 = strip kernel + weight panels by LDS-DMA,
-  // 3 = + the activation strip by LDS-DMA where it carries no transform (measured neutral: 10 of the 14 launches
-  // qualify, each within 1 % of its register-path time, encoder backward 16.55 vs 16.54 ms - the loader waves have the
-  // slack, what bounds the kernel is the L2 -> LDS operand stream itself; not the default)
-  static const int strip = getenv("ACVAE_CONV_STRIP") ? atoi(getenv("ACVAE_CONV_STRIP")) : 2;
+  // weight panels by LDS-DMA whenever the output channels fill whole tiles (an LDS-DMA cannot zero-fill)
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
-  if (strip) {
-    ConvStripLoader al{X, scale, shift, H, W, Cin, M};
-    const int bn = Cout <= 64 ? 64 : 128;
-    const dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, bn)), block(nt_threads<CV_BMT>());
-    const bool dma = strip >= 2 && Cout % bn == 0;
-    const bool adma = dma && strip >= 3 && !scale;
-    if (bn == 64) {
-      if (adma) hipLaunchKernelGGL((conv_igemm3_kernel<64, true, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
-      else if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<64, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
-      else hipLaunchKernelGGL((conv_igemm3_kernel<64, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
-    } else {
-      if (adma) hipLaunchKernelGGL((conv_igemm3_kernel<128, true, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
-      else if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<128, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
-      else hipLaunchKernelGGL((conv_igemm3_kernel<128, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
-    }
+  ConvStripLoader al{X, scale, shift, H, W, Cin, M};
+  const int bn = Cout <= 64 ? 64 : 128;
+  const dim3 grid(cdiv(M, CV_BMT), cdiv(Cout, bn)), block(nt_threads<CV_BMT>());
+  const bool dma = Cout % bn == 0;
+  if (bn == 64) {
+    if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<64, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+    else hipLaunchKernelGGL((conv_igemm3_kernel<64, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
   } else {
-    ConvRowLoader<CONV_BMT / 32> al{X, scale, shift, H, W, Cin, M};
-    if (Cout <= 64) {
-      dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 64));
-      hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 64>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
-    } else {
-      dim3 grid(cdiv(M, CONV_BMT), cdiv(Cout, 128));
-      hipLaunchKernelGGL((conv_igemm_kernel<CONV_BMT, 128>), grid, dim3(nt_threads<CONV_BMT>()), 0, st, al, Wp, ep, M, Cout, K);
-    }
+    if (dma) hipLaunchKernelGGL((conv_igemm3_kernel<128, true>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
+    else hipLaunchKernelGGL((conv_igemm3_kernel<128, false>), grid, block, 0, st, al, Wp, ep, M, Cout, K);
   }
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();
@@ -1335,19 +1150,14 @@ int conv3x3_igemm(const float* X, const float* scale, const float* shift, const 
 }
 int conv_partials_rows(int N, int H, int W) { return cdiv((long)N * H * W, CONV_BMT); }
 
-static bool wgrad_use192(int NC) { return NC % 192 == 0 && NC % 128 != 0; }
 // Strip kernel (conv_wgrad3_kernel) whenever the input channels come in chunks of 64 (every layer but conv1): against the
-// one-tap-per-tile kernels it measured 1.62 -> 1.48 ms on the 64-output-channel layer and, with the paired LDS reads of
-// its 128-row variant, 1.335 -> 1.285 ms / 0.69 -> 0.655 ms on the wider ones.  ACVAE_WGRAD_STRIP = 0 turns it off,
-// 3 keeps it to the 64-output-channel layer (A/B).
-static bool wgrad_strip(int NC, int Cout) {
-  static const int mode = getenv("ACVAE_WGRAD_STRIP") ? atoi(getenv("ACVAE_WGRAD_STRIP")) : 1;
-  return NC % 576 == 0 && (mode == 1 || mode == 2 || (mode == 3 && Cout <= 64));
-}
+// one-tap-per-tile kernel it measured 1.62 -> 1.48 ms on the 64-output-channel layer and, with the paired LDS reads of
+// its 128-row variant, 1.335 -> 1.285 ms / 0.69 -> 0.655 ms on the wider ones.
+static bool wgrad_strip(int NC, int Cout) { (void)Cout; return NC % 576 == 0; }
 // slabs per pixel slice: the 64-row strip kernel writes the two K-halves of its wave rows separately
 static int wgrad_slabs_per_slice(int NC, int Cout) { return wgrad_strip(NC, Cout) && Cout <= 64 ? 2 : 1; }
 static int wgrad_splits(int M, int Cout, int NC) {
-  const bool narrow = Cout <= 64, w192 = wgrad_use192(NC) || wgrad_strip(NC, Cout);
+  const bool narrow = Cout <= 64, w192 = wgrad_strip(NC, Cout);
   const long tiles = w192 ? (long)cdiv(Cout, narrow ? 64 : 128) * (NC / 192)
                           : (long)cdiv(Cout, narrow ? 64 : 128) * cdiv(NC, narrow ? 256 : 128);
   // Resident workgroups per CU of the kernel variant (256 threads; from the compiler's resource report: 120 / 111 VGPRs
@@ -1359,8 +1169,7 @@ static int wgrad_splits(int M, int Cout, int NC) {
   const int maxs = cdiv(M, 16 * BKT) & ~7;
   const double t_mfma = 2.0 * (double)M * Cout * NC / 1.1e14;
   // measured: a slab costs ~6x its bytes / HBM rate
-  static const double slab_scale = getenv("ACVAE_WG_SLABSCALE") ? atof(getenv("ACVAE_WG_SLABSCALE")) : 1.0;
-  const double t_slab = slab_scale * 2.0 * (double)Cout * NC * 4.0 / 0.67e12 * wgrad_slabs_per_slice(NC, Cout);
+  const double t_slab = 2.0 * (double)Cout * NC * 4.0 / 0.67e12 * wgrad_slabs_per_slice(NC, Cout);
   int best = 8;
   double best_t = 1e30;
   for (int k = 8; k <= (maxs < 8 ? 8 : maxs) && tiles * k <= 5 * slots; k += 8) {
@@ -1395,14 +1204,6 @@ int conv3x3_wgrad(const float* dY, const float* X, const float* scale, const flo
       dim3 grid(cdiv(Cout, 128), NC / 192, s);
       hipLaunchKernelGGL((conv_wgrad3_kernel<2>), grid, dim3(256), 0, st, dY, X, scale, shift, slab, M, Cout, H, W, Cin,
                          fw, fh, k_per);
-    }
-  } else if (wgrad_use192(NC)) {
-    if (Cout <= 64) {
-      dim3 grid(cdiv(Cout, 64), NC / 192, s);
-      hipLaunchKernelGGL((conv_wgrad192_kernel<1>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
-    } else {
-      dim3 grid(cdiv(Cout, 128), NC / 192, s);
-      hipLaunchKernelGGL((conv_wgrad192_kernel<2>), grid, dim3(256), 0, st, dY, bl, slab, M, Cout, NC, k_per);
     }
   } else if (Cout <= 64) {
     dim3 grid(cdiv(Cout, 64), cdiv(NC, 256), s);

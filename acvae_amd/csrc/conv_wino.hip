@@ -27,18 +27,6 @@
 namespace {
 using namespace mfma;
 
-#ifndef WN_ABL
-#define WN_ABL 0
-#endif
-#ifndef WN_TIMING
-#define WN_TIMING 0   // 1: per-wavefront cycle sums of the main-loop phases written over the start of Y (tools/wino_timing.py)
-#endif
-#ifndef WN_PRIO
-#define WN_PRIO 0     // 1: s_setprio alternates between the two wavefronts of a SIMD inside a chunk (A/B)
-#endif
-#ifndef WN_ILV
-#define WN_ILV 0      // 1: MFMAs of two positions interleaved (A/B: tools/wino_ablate.sh)
-#endif
 constexpr int WN_THREADS = 512;
 constexpr int WN_TILES = 64;      // output tiles (2x2 pixels each) per workgroup
 constexpr int WN_TN = 64;         // output channels per workgroup
@@ -87,7 +75,6 @@ struct WinoParams {
   int tw_shift;         // TW = W/2 = 1 << tw_shift
   int R;                // tile rows per workgroup = 64 / TW
   int bpc;              // workgroups (row blocks) per clip = ceil(ceil(H/2) / R)
-  int ppmap;            // ping-pong kernels: which wavefronts form a group (0: 0-3 / 4-7, 1: even / odd)
 };
 
 // The transform adds as v_pk_add_f32: two values per VALU issue slot.  In-kernel counters and the A/B below say the SIMD's issue
@@ -196,18 +183,6 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
   }
 }
 
-// two positions interleaved: consecutive MFMAs never accumulate into the same registers
-__device__ __forceinline__ void mfma4x2(f32x16& c0, float4 a0, float4 b0, f32x16& c1, float4 a1, float4 b1) {
-  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, c1, 0, 0, 0);
-}
-
 // XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
 template <int XH, bool ACT>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
@@ -226,7 +201,6 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   const int W2 = W + 2;
   const int nitems = (2 * R + 2) * W2 * 4;
   const int q = tid & 3;
-  unsigned live = 0, okm = 0;
   long goff[4];
   int loff[4];
 #pragma unroll
@@ -237,8 +211,6 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     const int ry = px / W2, rx = px - ry * W2;
     const int y = 2 * ty0 - 1 + ry, x = rx - 1;
     const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
-    live |= (lv ? 1u : 0u) << j;
-    okm |= (ok ? 1u : 0u) << j;
     goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;     // always a legal address
     // Which items are zero padding (left / right pad columns, rows above / below the clip) does not change over the stages of a
     // workgroup: their slots are zeroed ONCE in both buffers here, and afterwards these items - like the ones past the
@@ -252,13 +224,8 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   }
   float4 pv[4];
   auto issue_raw = [&](int st) {
-#if WN_ABL == 9
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pv[j] = make_float4(1.f, 2.f, 3.f, (float)st);
-#else
 #pragma unroll
     for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
-#endif
   };
   auto put_raw = [&](int st, float4* raw) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -305,61 +272,32 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-#if WN_ABL >= 1
-  const float4 abl = *reinterpret_cast<const float4*>(p.U + lane * 4);
-#endif
   // K-step j of a chunk pairs channel c0 + j (lanes 0-31) with c0 + 4 + j (lanes 32-63): quad 2*sub + h
   auto compute = [&](const float4* raw, int sub, const float4* bw) {
     const float4* rq = raw + (2 * sub + h) * WN_SQ;
     const float4* bq = bw + bcol;
     float4 d[3][4];
-#if WN_ABL >= 1 && WN_ABL <= 4          // ablation (tools/wino_ablate.sh): no activation reads
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[a][j] = make_float4(abl.x + a, abl.y + j, abl.z, abl.w);
-    (void)rq;
-#else
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_SC + (j >> 1)];
-#endif
 #pragma unroll
     for (int xl = 0; xl < 2; ++xl) {
-#if WN_PRIO
-      // the arbiter prefers the older wavefront of a SIMD (tools/wino_timing.py: 4010 against 4720 cycles per chunk, and the chunk
-      // ends when the slower one does): the younger one gets the higher priority in the first half of the chunk, the older in
-      // the second
-      if (xl == 0) { if (nh) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-      else { if (nh) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-#endif
       float4 t[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (xl == 0) t[j] = f4sub(d[0][j], d[2][j]);                // frequency 0 (rows 0,2) / 3 (rows 1,3)
         else t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);   // frequency 1: r1 + r2 / 2: r2 - r1
       }
-      constexpr int dummy = 0; (void)dummy;
       const int xi = xl ? xi1 : xi0;
-#if WN_ABL >= 2 && WN_ABL <= 4          // no weight-fragment reads either
-      const float4 b0 = abl, b1 = abl, b2 = abl, b3 = abl;
-      (void)bq; (void)xi;
-#else
       const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
       const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
-#endif
       float4 v[4];
       wino_htrans(t, v);
-#if WN_ILV
-      mfma4x2(acc[xl * 4 + 0], v[0], b0, acc[xl * 4 + 1], v[1], b1);
-      mfma4x2(acc[xl * 4 + 2], v[2], b2, acc[xl * 4 + 3], v[3], b3);
-#else
       mfma4(acc[xl * 4 + 0], v[0], b0);
       mfma4(acc[xl * 4 + 1], v[1], b1);
       mfma4(acc[xl * 4 + 2], v[2], b2);
       mfma4(acc[xl * 4 + 3], v[3], b3);
-#endif
     }
   };
 
@@ -371,9 +309,6 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   put_raw(0, raw0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-#if WN_TIMING
-  float tsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#endif
   auto step = [&](int c, auto kk) {
     constexpr int K = decltype(kk)::value;            // c % 4
     constexpr int sub = K & 1, sp = K >> 1;
@@ -385,52 +320,20 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     // Order of the vector-memory queue in a chunk: the weight DMA first, the activation loads of the next stage behind it
     // (sched_barriers: left alone the compiler sinks those loads to the end of the chunk).  vmcnt retires in order, so at the
     // end of the chunk vmcnt(4) has seen the DMA land while the four activation loads may still fly - they have until the
-    // end of the NEXT chunk; waiting for them here as well (vmcnt(0)) cost 15 % of the kernel (tools/wino_ablate.sh).
+    // end of the NEXT chunk; waiting for them here as well (vmcnt(0)) cost 15 % of the kernel.
     const bool raw_now = sub == 0 && st + 1 < nstage;
-#if WN_TIMING
-    const long long tk0 = clock64();
-#endif
-#if WN_ABL < 3 || WN_ABL >= 6           // 3: no global traffic in the loop at all; 5: no weight DMA; 6: no activation staging
-    if (c + 1 < nchunk) fetch_b(WN_ABL == 7 ? 0 : c + 1, bnxt);              // 7: the same (cache-hot) chunk every time
-#endif
+    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);
     __builtin_amdgcn_sched_barrier(0);
-#if WN_ABL < 3 || WN_ABL == 5 || WN_ABL >= 7
     if (raw_now) issue_raw(st + 1);                        // in flight for this chunk and the next
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // staging of the next stage: into the buffer whose last readers were stage st - 1
-#if WN_TIMING
-    const long long tk1 = clock64();
-#endif
     compute(rcur, sub, bcur);
-#if WN_TIMING
-    __builtin_amdgcn_sched_barrier(0);
-    const long long tk2 = clock64();
-#endif
-    if (sub == 1 && st + 1 < nstage && (WN_ABL < 3 || WN_ABL == 5 || WN_ABL >= 7)) put_raw(st + 1, rnxt);
-#if WN_TIMING
-    __builtin_amdgcn_sched_barrier(0);
-    const long long tk3 = clock64();
-#endif
-#if WN_ABL == 4          // 4: no barrier either
-    return;
-#endif
+    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
     // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier
     if (raw_now) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if WN_TIMING
-    const long long tk4 = clock64();
-#endif
     __syncthreads();
-#if WN_TIMING
-    const long long tk5 = clock64();
-    tsum[0] += (float)(tk1 - tk0); tsum[1] += (float)(tk2 - tk1); tsum[2] += (float)(tk3 - tk2);
-    tsum[3] += (float)(tk4 - tk3); tsum[4] += (float)(tk5 - tk4);
-#endif
   };
-#if WN_TIMING
-  const long long tkernel0 = clock64();
-#endif
   for (int c = 0; c < nchunk; c += 4) {
     step(c, std::integral_constant<int, 0>());
     step(c + 1, std::integral_constant<int, 1>());
@@ -440,419 +343,10 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     }
   }
 
-#if WN_TIMING
-  const long long tkernel1 = clock64();
-#endif
   // ---------------------------------------------------------------- epilogue
   float* exb = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
   wino_epilogue<XH>(p, acc, exb + (wave & 3) * 2048, exb + ((wave & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw0), mh, nh, li, h,
                     lane, n, ty0, bm, bn);
-#if WN_TIMING
-  __syncthreads();
-  if (lane == 0) {      // [workgroup][wave][8]: dma/load issue, compute, staging, vmcnt wait, barrier, main loop, epilogue, chunks
-    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 8;
-    for (int k = 0; k < 5; ++k) o[k] = tsum[k];
-    o[5] = (float)(tkernel1 - tkernel0); o[6] = (float)(clock64() - tkernel1); o[7] = (float)nchunk;
-  }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Phase-shifted variant.  In conv_wino_body the two wavefronts of a SIMD run the same code between the same barriers; in-kernel
-// cycle counters (tools/wino_timing.py) show where a chunk's 6200 cycles go: 4430 for reads + transform + 32 MFMAs (the pipe
-// shared with the other wavefront: 4096 would be perfect), 500 to ISSUE eight vector-memory instructions (weight DMA +
-// activation loads: all eight wavefronts push 45 KB into a 64 B/clk path at the same moment and stall in order behind it),
-// 570 for the activation staging (ds_write_b128 goes at 79 B/clk), 650 at the barrier (mostly the slower wavefront of each
-// SIMD) - and nobody issues MFMAs during the 1070 cycles of memory work because both wavefronts of a SIMD do it together.
-// Here the wavefronts of group 1 do their memory work BETWEEN the two position halves of the chunk, those of group 0 at the
-// chunk boundary as before, so one group's stalls sit under the other group's MFMAs.  The weight ring is three deep (DMA two
-// chunks ahead: a DMA issued in mid-chunk has a whole chunk to land; three distinct __shared__ arrays, loop unrolled by
-// three: see the note on LDS-DMA aliasing above); the activation window keeps its two buffers, indexed at run time (no DMA
-// writes them).  ppmap picks the groups: 0: waves 0-3 / 4-7 (the two wavefronts of a SIMD: MI355X_MICROARCH.md, waves go
-// to SIMDs in cyclic order), 1: even / odd waves (A/B).
-template <int XH, bool ACT, int G>
-__device__ __forceinline__ void conv_wino_pp_body(const WinoParams& p, int vw, float4* raw, float4* bwA, float4* bwB,
-                                                  float4* bwC) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, h = lane >> 5;
-  const int mh = (vw >> 1) & 1, nh = vw >> 2;          // XH = vw & 1
-  int bm, bn;
-  xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  const int RW = wino_row_pitch(p.tw_shift), R = p.R;
-  const int n = bm / p.bpc, ty0 = (bm - n * p.bpc) * R;
-  const int H = p.H, W = p.W, C = p.C;
-
-  const int W2 = W + 2;
-  const int nitems = (2 * R + 2) * W2 * 4;
-  const int q = tid & 3;
-  unsigned okm = 0;
-  long goff[4];
-  int loff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + WN_THREADS * j;
-    const bool lv = e < nitems;
-    const int px = e >> 2;
-    const int ry = px / W2, rx = px - ry * W2;
-    const int y = 2 * ty0 - 1 + ry, x = rx - 1;
-    const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
-    okm |= (ok ? 1u : 0u) << j;
-    goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;
-    loff[j] = lv ? q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1) : WN_RAWBUF - 1 - (tid & 7);
-  }
-  float4 pv[4];
-  auto issue_raw = [&](int st) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
-  };
-  auto put_raw = [&](int st, float4* rb) {
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACT) {
-      sc = *reinterpret_cast<const float4*>(p.scale + st * 16 + q * 4);
-      sh = *reinterpret_cast<const float4*>(p.shift + st * 16 + q * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 v = pv[j];
-      if (ACT) {
-        v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
-        v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
-      }
-      const bool ok = (okm >> j) & 1u;
-      rb[loff[j]] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-    }
-  };
-  const int nchunk = C >> 3, nstage = C >> 4;
-  const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
-  auto fetch_b = [&](int c, float4* bw) {
-    const float* src = Ub + (long)c * (WN_BCHUNK * 4);
-    float* dst = reinterpret_cast<float*>(bw) + wave * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 2048, dst + i * 2048, 16, 0, 0);
-  };
-
-  int tyl_a, tx_a;
-  wino_tile(mh, li, p.tw_shift, tyl_a, tx_a);
-  const int abase = tyl_a * RW + tx_a;
-  int rowoff[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const int i = XH + a;
-    rowoff[a] = (i & 1) * WN_SR + (i >> 1) * RW + abase;
-  }
-  constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;
-  const int bcol = h * 64 + nh * 32 + li;
-
-  f32x16 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-  // one chunk in two halves (position half 0, position half 1) so that group 1 can put its memory work between them
-  float4 d[3][4];
-  auto half0 = [&](const float4* rs, int sub, const float4* bw) {
-    const float4* rq = rs + (2 * sub + h) * WN_SQ;
-    const float4* bq = bw + bcol;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_SC + (j >> 1)];
-    float4 t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = f4sub(d[0][j], d[2][j]);
-    const float4 b0 = bq[(xi0 * 4 + 0) * 128], b1 = bq[(xi0 * 4 + 1) * 128];
-    const float4 b2 = bq[(xi0 * 4 + 2) * 128], b3 = bq[(xi0 * 4 + 3) * 128];
-    float4 v[4];
-    wino_htrans(t, v);
-    mfma4(acc[0], v[0], b0);
-    mfma4(acc[1], v[1], b1);
-    mfma4(acc[2], v[2], b2);
-    mfma4(acc[3], v[3], b3);
-  };
-  auto half1 = [&](const float4* bw) {
-    const float4* bq = bw + bcol;
-    float4 t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);
-    const float4 b0 = bq[(xi1 * 4 + 0) * 128], b1 = bq[(xi1 * 4 + 1) * 128];
-    const float4 b2 = bq[(xi1 * 4 + 2) * 128], b3 = bq[(xi1 * 4 + 3) * 128];
-    float4 v[4];
-    wino_htrans(t, v);
-    mfma4(acc[4], v[0], b0);
-    mfma4(acc[5], v[1], b1);
-    mfma4(acc[6], v[2], b2);
-    mfma4(acc[7], v[3], b3);
-  };
-
-  issue_raw(0);
-  fetch_b(0, bwA);
-  if (nchunk > 1) fetch_b(1, bwB);
-  put_raw(0, raw);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  auto step = [&](int c, auto kk) {
-    constexpr int K = decltype(kk)::value;            // c % 3: weight ring position
-    float4* const bcur = K == 0 ? bwA : (K == 1 ? bwB : bwC);
-    float4* const bnx2 = K == 0 ? bwC : (K == 1 ? bwA : bwB);     // slot of chunk c + 2 = slot of chunk c - 1
-    const int st = c >> 1, sub = c & 1;
-    float4* const rcur = raw + (st & 1) * WN_RAWBUF;
-    float4* const rnxt = raw + ((st + 1) & 1) * WN_RAWBUF;
-    // the memory work of a chunk: weight DMA two chunks ahead (its slot's last readers, chunk c - 1, are behind the barrier),
-    // the next stage's activation loads (first chunk of a stage) or their staging into LDS (second chunk)
-    auto memwork = [&]() {
-      if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
-      if (c + 2 < nchunk) fetch_b(c + 2, bnx2);
-      if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);
-    };
-    if (G == 0) memwork();
-    __builtin_amdgcn_sched_barrier(0);
-    half0(rcur, sub, bcur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (G == 1) memwork();
-    __builtin_amdgcn_sched_barrier(0);
-    half1(bcur);
-    // Chunk c + 1's weights were fetched during chunk c - 1 and must have landed before the barrier; what THIS chunk issued
-    // (4 DMA instructions, 4 activation loads) may keep flying: vmcnt retires in order, so wait down to that many.
-    const int young = (c + 2 < nchunk ? 4 : 0) + (sub == 0 && st + 1 < nstage ? 4 : 0);
-    if (young == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
-  for (int c = 0; c < nchunk; c += 3) {
-    step(c, std::integral_constant<int, 0>());
-    if (c + 1 < nchunk) step(c + 1, std::integral_constant<int, 1>());
-    if (c + 2 < nchunk) step(c + 2, std::integral_constant<int, 2>());
-  }
-  __syncthreads();       // every LDS read of the main loop is done: the buffers are free for the epilogue
-  float* exb = reinterpret_cast<float*>(vw < 4 ? bwA : bwB);
-  wino_epilogue<XH>(p, acc, exb + (vw & 3) * 2048, exb + ((vw & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw), mh, nh, li, h, lane,
-                    n, ty0, bm, bn);
-}
-
-template <bool ACT>
-__device__ __forceinline__ void conv_wino_pp_entry(const WinoParams& p, float4* raw, float4* bwA, float4* bwB, float4* bwC) {
-  const int wave = threadIdx.x >> 6;
-  // role index: XH = vw & 1, tile half (vw >> 1) & 1, column half = group = vw >> 2
-  const int vw = p.ppmap ? ((wave & 1) << 2) | (wave >> 1) : wave;
-  if (vw >> 2) {
-    if (vw & 1) conv_wino_pp_body<1, ACT, 1>(p, vw, raw, bwA, bwB, bwC);
-    else conv_wino_pp_body<0, ACT, 1>(p, vw, raw, bwA, bwB, bwC);
-  } else {
-    if (vw & 1) conv_wino_pp_body<1, ACT, 0>(p, vw, raw, bwA, bwB, bwC);
-    else conv_wino_pp_body<0, ACT, 0>(p, vw, raw, bwA, bwB, bwC);
-  }
-}
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_pp_kernel(WinoParams p) {
-  __shared__ float4 raw[2 * WN_RAWBUF];
-  __shared__ float4 bwA[WN_BCHUNK], bwB[WN_BCHUNK], bwC[WN_BCHUNK];
-  conv_wino_pp_entry<false>(p, raw, bwA, bwB, bwC);
-}
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_pp_act_kernel(WinoParams p) {
-  __shared__ float4 raw[2 * WN_RAWBUF];
-  __shared__ float4 bwA[WN_BCHUNK], bwB[WN_BCHUNK], bwC[WN_BCHUNK];
-  conv_wino_pp_entry<true>(p, raw, bwA, bwB, bwC);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// One vertical frequency per wavefront (ACVAE_WINO_PP=4).  Roles: xi = wave & 3, tile half = wave >> 2; a wavefront holds the 4
-// horizontal positions of ITS frequency for 32 tiles x all 64 output channels (the same 128 accumulators).  Against the
-// position-half split of conv_wino_body a chunk needs 8 window reads instead of 12 and 16 packed adds instead of 32 per
-// wavefront (a frequency is a difference of TWO window rows) - the issue slots are what the kernel runs out of.  The price is
-// paid once per tile: the four frequencies of a tile meet through LDS in the epilogue (two passes of 64 KB).
-template <int XI, bool ACT>
-__device__ __forceinline__ void conv_wino_x4_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, h = lane >> 5;
-  const int mh = wave >> 2;
-  int bm, bn;
-  xcd_tile(gridDim.x, gridDim.y, bm, bn);
-  const int RW = wino_row_pitch(p.tw_shift), R = p.R;
-  const int n = bm / p.bpc, ty0 = (bm - n * p.bpc) * R;
-  const int H = p.H, W = p.W, C = p.C;
-  const int W2 = W + 2;
-  const int nitems = (2 * R + 2) * W2 * 4;
-  const int q = tid & 3;
-  unsigned okm = 0;
-  long goff[4];
-  int loff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + WN_THREADS * j;
-    const bool lv = e < nitems;
-    const int px = e >> 2;
-    const int ry = px / W2, rx = px - ry * W2;
-    const int y = 2 * ty0 - 1 + ry, x = rx - 1;
-    const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
-    okm |= (ok ? 1u : 0u) << j;
-    goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;
-    loff[j] = lv ? q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1) : WN_RAWBUF - 1 - (tid & 7);
-  }
-  float4 pv[4];
-  auto issue_raw = [&](int st) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
-  };
-  auto put_raw = [&](int st, float4* raw) {
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACT) {
-      sc = *reinterpret_cast<const float4*>(p.scale + st * 16 + q * 4);
-      sh = *reinterpret_cast<const float4*>(p.shift + st * 16 + q * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 v = pv[j];
-      if (ACT) {
-        v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
-        v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
-      }
-      const bool ok = (okm >> j) & 1u;
-      raw[loff[j]] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-    }
-  };
-  const int nchunk = C >> 3, nstage = C >> 4;
-  const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
-  auto fetch_b = [&](int c, float4* bw) {
-    const float* src = Ub + (long)c * (WN_BCHUNK * 4);
-    float* dst = reinterpret_cast<float*>(bw) + wave * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 2048, dst + i * 2048, 16, 0, 0);
-  };
-  int tyl_a, tx_a;
-  wino_tile(mh, li, p.tw_shift, tyl_a, tx_a);
-  const int abase = tyl_a * RW + tx_a;
-  // frequency XI = window row RA -/+ window row RB:  0: r0 - r2   1: r1 + r2   2: r2 - r1   3: r1 - r3
-  constexpr int RA = XI == 0 ? 0 : (XI == 2 ? 2 : 1), RB = XI == 0 ? 2 : (XI == 1 ? 2 : (XI == 2 ? 1 : 3));
-  const int offA = (RA & 1) * WN_SR + (RA >> 1) * RW + abase, offB = (RB & 1) * WN_SR + (RB >> 1) * RW + abase;
-  const int bcol = XI * 4 * 128 + h * 64 + li;
-
-  f32x16 acc[8];      // [position nu][column half]
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-  auto compute = [&](const float4* raw, int sub, const float4* bw) {
-    const float4* rq = raw + (2 * sub + h) * WN_SQ;
-    const float4* bq = bw + bcol;
-    float4 t[4], v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 a = rq[offA + (j & 1) * WN_SC + (j >> 1)], b = rq[offB + (j & 1) * WN_SC + (j >> 1)];
-      t[j] = XI == 1 ? f4add(a, b) : f4sub(a, b);
-    }
-    wino_htrans(t, v);
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      const float4 b0 = bq[nu * 128], b1 = bq[nu * 128 + 32];
-      mfma4(acc[nu * 2 + 0], v[nu], b0);
-      mfma4(acc[nu * 2 + 1], v[nu], b1);
-    }
-  };
-
-  issue_raw(0);
-  fetch_b(0, bw0);
-  put_raw(0, raw0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  auto step = [&](int c, auto kk) {
-    constexpr int K = decltype(kk)::value;            // c % 4
-    constexpr int sub = K & 1, sp = K >> 1;
-    const int st = c >> 1;
-    float4* const bcur = sub ? bw1 : bw0;
-    float4* const bnxt = sub ? bw0 : bw1;
-    float4* const rcur = sp ? raw1 : raw0;
-    float4* const rnxt = sp ? raw0 : raw1;
-    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (sub == 0 && st + 1 < nstage) issue_raw(st + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(rcur, sub, bcur);
-    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
-  for (int c = 0; c < nchunk; c += 4) {
-    step(c, std::integral_constant<int, 0>());
-    step(c + 1, std::integral_constant<int, 1>());
-    if (c + 2 < nchunk) {
-      step(c + 2, std::integral_constant<int, 2>());
-      step(c + 3, std::integral_constant<int, 3>());
-    }
-  }
-
-  // ---------------------------------------------------------------- epilogue: the four frequencies of a tile meet through LDS
-  // H_xi[b] = (b = 0: M0 + M1 + M2, b = 1: M1 - M2 - M3);  Y[0][b] = H_0 + H_1 + H_2,  Y[1][b] = H_1 - H_2 - H_3.
-  // Wavefront xi finishes output row a = xi & 1 of column half nbo = xi >> 1.  One pass per output column b: every wavefront
-  // writes its 32 values per lane ([column half][16 rows]), then reads the three frequencies it needs.
-  float* ex = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [xi][32][64 lanes]: 32 KB per tile half
-  constexpr int a = XI & 1, nbo = XI >> 1;
-  const int cout = bn * WN_TN + nbo * 32 + li;
-  float s = 0.f, qq = 0.f;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    if (b) __syncthreads();           // the reads of pass 0 are done
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0 * 2 + nb][r], m1 = acc[1 * 2 + nb][r], m2 = acc[2 * 2 + nb][r], m3 = acc[3 * 2 + nb][r];
-        ex[(XI * 32 + nb * 16 + r) * 64 + lane] = b == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float* e0 = ex + (nbo * 16 + r) * 64 + lane;
-      const float o = a == 0 ? (e0[0 * 2048] + e0[1 * 2048]) + e0[2 * 2048] : (e0[1 * 2048] - e0[2 * 2048]) - e0[3 * 2048];
-      int tyl, tx;
-      wino_tile(mh, (r & 3) + 8 * (r >> 2) + 4 * h, p.tw_shift, tyl, tx);
-      const int y = 2 * (ty0 + tyl) + a;
-      if (y < H) {
-        p.Y[((long)(n * H + y) * W + 2 * tx + b) * p.Cout + cout] = o;
-        s += o;
-        qq += o * o;
-      }
-    }
-  }
-  if (p.partials) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(raw0);   // [tile half x output row][2][64]
-    s += __shfl_xor(s, 32, 64);
-    qq += __shfl_xor(qq, 32, 64);
-    if (h == 0) {
-      red[((mh * 2 + a) * 2 + 0) * 64 + nbo * 32 + li] = s;
-      red[((mh * 2 + a) * 2 + 1) * 64 + nbo * 32 + li] = qq;
-    }
-    __syncthreads();
-    if (tid < WN_TN) {
-      float ts = 0.f, tq = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
-      float* out = p.partials + (long)bm * 2 * p.Cout + bn * WN_TN + tid;
-      out[0] = ts;
-      out[p.Cout] = tq;
-    }
-  }
-}
-template <bool ACT>
-__device__ __forceinline__ void conv_wino_x4_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
-  switch ((threadIdx.x >> 6) & 3) {
-    case 0: conv_wino_x4_body<0, ACT>(p, raw0, raw1, bw0, bw1); break;
-    case 1: conv_wino_x4_body<1, ACT>(p, raw0, raw1, bw0, bw1); break;
-    case 2: conv_wino_x4_body<2, ACT>(p, raw0, raw1, bw0, bw1); break;
-    default: conv_wino_x4_body<3, ACT>(p, raw0, raw1, bw0, bw1); break;
-  }
-}
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_x4_kernel(WinoParams p) {
-  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
-  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  conv_wino_x4_entry<false>(p, raw0, raw1, bw0, bw1);
-}
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_x4_act_kernel(WinoParams p) {
-  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
-  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  conv_wino_x4_entry<true>(p, raw0, raw1, bw0, bw1);
 }
 
 // ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift)
@@ -953,21 +447,8 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   p.bpc = cdiv(cdiv(H, 2), p.R);
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
-  // ACVAE_WINO_PP: 0 (default) = conv_wino_body (both wavefronts of a SIMD in step, two weight buffers); 1 / 2 = the phase-shifted
-  // kernel (groups = waves 0-3 / 4-7, even / odd): 2.4 % faster alone on the deep layers, no difference inside the training step;
-  // 4 = one vertical frequency per wavefront: 2 % faster for Cin >= 256, 1-4 % slower below (its epilogue costs more)
-  static const int pp = getenv("ACVAE_WINO_PP") ? atoi(getenv("ACVAE_WINO_PP")) : 0;
-  p.ppmap = pp == 2 ? 1 : 0;
-  if (pp == 4) {           // one vertical frequency per wavefront
-    if (scale) hipLaunchKernelGGL(conv_wino_x4_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
-    else hipLaunchKernelGGL(conv_wino_x4_kernel, grid, dim3(WN_THREADS), 0, st, p);
-  } else if (pp) {
-    if (scale) hipLaunchKernelGGL(conv_wino_pp_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
-    else hipLaunchKernelGGL(conv_wino_pp_kernel, grid, dim3(WN_THREADS), 0, st, p);
-  } else {
-    if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
-    else hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
-  }
+  if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  else hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
@@ -1198,48 +679,23 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   };
 
   // ---------------------------------------------------------------- main loop: one barrier per 16-tile stage
-#if WN_TIMING
-  float tsum[4] = {0.f, 0.f, 0.f, 0.f};
-#define WG_TICK(k) { __builtin_amdgcn_sched_barrier(0); const long long tn = clock64(); tsum[k] += (float)(tn - tprev); tprev = tn; }
-  long long tprev = clock64();
-#else
-#define WG_TICK(k)
-#endif
   if (g_begin < g_end) {
     issue(g_begin, dy0);
     put(xw0);
     __syncthreads();
-#if WN_TIMING
-    tprev = clock64();
-#endif
     for (int g = g_begin; g < g_end; g += 2) {
       if (g + 1 < g_end) issue(g + 1, dy1);              // dy1 / xw1: last read at stage g - 1, behind the barrier
-      WG_TICK(0)
       compute(xw0, dy0);
-      WG_TICK(1)
       if (g + 1 < g_end) put(xw1);
-      WG_TICK(2)
       __syncthreads();
-      WG_TICK(3)
       if (g + 1 < g_end) {
         if (g + 2 < g_end) issue(g + 2, dy0);
-        WG_TICK(0)
         compute(xw1, dy1);
-        WG_TICK(1)
         if (g + 2 < g_end) put(xw0);
-        WG_TICK(2)
         __syncthreads();
-        WG_TICK(3)
       }
     }
   }
-#if WN_TIMING
-  if (lane == 0) {     // [workgroup][wave][8] over the start of dY (read long ago): load issue, compute, staging, barrier, stages
-    float* o = const_cast<float*>(p.dY) + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
-    for (int k = 0; k < 4; ++k) o[k] = tsum[k];
-    o[4] = (float)(g_end - g_begin);
-  }
-#endif
 
   // ---------------------------------------------------------------- slab: [z][position][ci][co]
   constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;
@@ -1322,8 +778,7 @@ inline WgradPlan wino_wgrad_plan(int N, int H, int W, int Cin, int Cout) {
   g.total = N * g.spc;
   const int blocks = (Cin / 64) * (Cout / 64);
   // one workgroup per CU (100 KB of LDS, 8 wavefronts x 128 accumulators): K split so that the grid is one round of 256
-  static const int zmul = getenv("ACVAE_WGW_ZMUL") ? atoi(getenv("ACVAE_WGW_ZMUL")) : 1;     // A/B: rounds of workgroups
-  int Z = 256 * zmul / blocks;
+  int Z = 256 / blocks;
   if (Z < 1) Z = 1;
   if (Z > g.total) Z = g.total;
   g.per = (g.total + Z - 1) / Z;

@@ -187,7 +187,6 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
 #pragma unroll
       for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(&sm.b[buf][(srow + RPP * j) * LDS_LD + scol]) = pb.v[j];
     };
-#ifndef ACVAE_ABL
     al.issue(row0, 0, lt, pa);
     bl.issue(col0, 0, lt, pb);
     stash(0);
@@ -200,32 +199,6 @@ __device__ __forceinline__ void nt_block(ALoader al, BLoader bl, int M, int N, i
       }
       __syncthreads();
     }
-#else
-    // dev-only ablations of the operand fetch path (tools/ablate.sh); results are wrong by construction
-    //  1: no global loads, LDS stores kept   2: loads issued, LDS stores skipped   3: neither
-    //  4: only the B (weight) loads          5: only the A (activation) loads
-    auto fake = [&](auto& p) {
-#pragma unroll
-      for (int j = 0; j < (int)(sizeof(p.v) / sizeof(p.v[0])); ++j) p.v[j] = make_float4(1.f, 2.f, 3.f, 4.f);
-      p.mask = 0xffffffffu; p.sc = make_float4(1.f, 1.f, 1.f, 1.f); p.sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto keep = [&](auto& p) {
-#pragma unroll
-      for (int j = 0; j < (int)(sizeof(p.v) / sizeof(p.v[0])); ++j) asm volatile("" ::"v"(p.v[j].x), "v"(p.v[j].w));
-    };
-    auto step = [&](int ks) {
-      if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 4) fake(pa); else al.issue(row0, ks, lt, pa);
-      if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 5) fake(pb); else bl.issue(col0, ks, lt, pb);
-      if (ACVAE_ABL == 2) { keep(pa); keep(pb); }
-      else if (ACVAE_ABL != 3) stash(ks & 1);
-    };
-    step(0);
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-      if (ks + 1 < nk) step(ks + 1);
-      __syncthreads();
-    }
-#endif
   } else {
     // ------------------------------------------------------------------ matrix wavefronts
     __syncthreads();
@@ -369,19 +342,8 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
       *reinterpret_cast<float4*>(&sm.b[buf][k * TN_ + (tid % (TN_ / 4)) * 4]) = pb.v[it];
     }
   };
-#ifdef ACVAE_ABL
-  // dev-only ablations (tools/ablate.sh): 1/3 = no global loads, 4 = only B loads, 5 = only A loads
-  auto fake = [&](Pending<4>& p) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p.v[j] = make_float4(1.f, 2.f, 3.f, 4.f);
-    p.mask = 0xffffffffu; p.sc = make_float4(1.f, 1.f, 1.f, 1.f); p.sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-#define TN_ISSUE_A(k0_) do { if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 4) fake(pa); else al.template issue<TM>(row0, k0_, pa); } while (0)
-#define TN_ISSUE_B(k0_) do { if (ACVAE_ABL == 1 || ACVAE_ABL == 3 || ACVAE_ABL == 5) fake(pb); else bl.template issue<TN_>(col0, k0_, pb); } while (0)
-#else
 #define TN_ISSUE_A(k0_) al.template issue<TM>(row0, k0_, pa)
 #define TN_ISSUE_B(k0_) bl.template issue<TN_>(col0, k0_, pb)
-#endif
   if (nk > 0) {
     TN_ISSUE_A(k_begin);
     TN_ISSUE_B(k_begin);
@@ -431,103 +393,6 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
 
 #undef TN_ISSUE_A
 #undef TN_ISSUE_B
-
-// Same pipeline with a free wave tile: 4 wavefronts as WM x WN, each EM x EN MFMA tiles (32 x 32), for operand widths
-// that the 64 x 64 wave tile covers badly (9*64 = 576 columns = 3 x 192).  Plain tile-to-lane map (one ds_read_b32 per
-// MFMA tile and K-step): tile (i, j) of the wave at (wm, wn) holds m = wm*EM*32 + i*32 + rho, n = wn*EN*32 + j*32 + li.
-template <int TM, int TN_>
-struct alignas(16) TnSmemG {
-  alignas(16) float a[2][BKT * TM];
-  alignas(16) float b[2][BKT * TN_];
-};
-
-template <int WM, int WN, int EM, int EN, class ALoader, class BLoader>
-__device__ __forceinline__ void tn_block_g(ALoader al, BLoader bl, int M, int N, int k_begin, int k_end, int block_m,
-                                           int block_n, float* C, long ldc, int accumulate,
-                                           TnSmemG<WM * EM * 32, WN * EN * 32>& sm) {
-  static_assert(WM * WN == 4, "four wavefronts");
-  constexpr int TM = WM * EM * 32, TN_ = WN * EN * 32;
-  constexpr int AITS = tn_its<TM>(), BITS = tn_its<TN_>();
-  static_assert(AITS <= 4 && BITS <= 4, "Pending holds 4 float4");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int row0 = block_m * TM, col0 = block_n * TN_;
-  const int nk = (k_end - k_begin + BKT - 1) / BKT;
-
-  f32x16 acc[EM][EN];
-#pragma unroll
-  for (int i = 0; i < EM; ++i)
-#pragma unroll
-    for (int j = 0; j < EN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  Pending<4> pa, pb;
-  al.template init<TM>(row0);
-  bl.template init<TN_>(col0);
-  auto put = [&](float* dst, const Pending<4>& p, auto wtag) {
-    constexpr int W = decltype(wtag)::value;
-    constexpr int TPR = W / 4, RPI = 256 / TPR, ITS = tn_its<W>();
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-      const int k = tid / TPR + it * RPI;
-      if (tid < RPI * TPR && k < BKT) *reinterpret_cast<float4*>(&dst[k * W + (tid % TPR) * 4]) = p.v[it];
-    }
-  };
-  auto stash = [&](int buf) {
-    al.template finish<TM>(pa);
-    bl.template finish<TN_>(pb);
-    put(sm.a[buf], pa, std::integral_constant<int, TM>{});
-    put(sm.b[buf], pb, std::integral_constant<int, TN_>{});
-  };
-  if (nk > 0) {
-    al.template issue<TM>(row0, k_begin, pa);
-    bl.template issue<TN_>(col0, k_begin, pb);
-    stash(0);
-  }
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) {
-      al.template issue<TM>(row0, k_begin + (ks + 1) * BKT, pa);
-      bl.template issue<TN_>(col0, k_begin + (ks + 1) * BKT, pb);
-    }
-    const float* As = sm.a[cur] + lh * TM + wm * EM * 32 + li;
-    const float* Bs = sm.b[cur] + lh * TN_ + wn * EN * 32 + li;
-#pragma unroll
-    for (int kk = 0; kk < BKT / 2; ++kk) {
-      float af[EM], bf[EN];
-#pragma unroll
-      for (int i = 0; i < EM; ++i) af[i] = As[kk * 2 * TM + i * 32];
-#pragma unroll
-      for (int j = 0; j < EN; ++j) bf[j] = Bs[kk * 2 * TN_ + j * 32];
-#pragma unroll
-      for (int i = 0; i < EM; ++i)
-#pragma unroll
-        for (int j = 0; j < EN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    if (ks + 1 < nk) stash(cur ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < EM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = row0 + wm * EM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < EN; ++j) {
-        const int n = col0 + wn * EN * 32 + j * 32 + li;
-        if (n < N) {
-          float* p = C + (long)m * ldc + n;
-          float v = acc[i][j][r];
-          if (accumulate) v += *p;
-          *p = v;
-        }
-      }
-    }
-}
 
 // =================================================================================================
 // Skinny NT kernel for the serial decode steps: M <= 32 per block row (batch), one 32x32 output tile

@@ -184,18 +184,6 @@ def test_conv3x3_winograd_real_block_geometry():
                       W, Cin, Cout, S())
 
 
-def test_conv3x3_kernel_variants_behind_the_switches():
-    """ACVAE_CONV_STRIP = 0 / 1 / 3 and ACVAE_WGRAD_STRIP = 0 / 3 select the predecessor kernels (one tap per stage,
-    register-staged panels, LDS-DMA strip; one-tap-per-tile weight gradient): same element-wise bound.  The switches are
-    read once per process, hence child processes."""
-    for env in ({"ACVAE_CONV_STRIP": "0", "ACVAE_WGRAD_STRIP": "0"}, {"ACVAE_CONV_STRIP": "1", "ACVAE_WGRAD_STRIP": "3"},
-                {"ACVAE_CONV_STRIP": "3"}):
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p",
-                            "no:cacheprovider", "-k", "real_block_geometry or every_layer_shape_vs_fp64 and 128"],
-                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (env, r.stdout[-3000:] + r.stderr[-1000:])
-
-
 def run_conv_bf16(N, H, W, Cin, Cout, act, seed=0):
     """bf16-storage convolutions (BASELINE configs[2]): operands are bf16 values, so the fp64 reference on the SAME
     rounded operands differs only by the fp32 accumulation order and the final rounding of a bf16 output (2^-9)."""
