@@ -35,6 +35,7 @@ constexpr int WN_TN = 64;         // output channels per workgroup
 // 16 different 16-byte bank groups: WN_SC = 2 (mod 4) spreads the 4 pixels, WN_SQ = 4 (mod 16) the quads.
 constexpr int WN_SC = 102, WN_SR = 2 * WN_SC, WN_SQ = 420;
 constexpr int WN_BCHUNK = 16 * 2 * 64;   // float4 per weight chunk image: [position][k half][column]
+constexpr int WN_MAXC = 2048;            // input channels whose BatchNorm scale / shift fit the LDS copy of the ACT kernel
 
 // LDS: four separate arrays, not one struct with a run-time buffer index: the compiler orders an LDS-DMA against later
 // LDS reads of the SAME wave by itself and waits (vmcnt) before any read it cannot prove disjoint from the DMA's
@@ -113,6 +114,34 @@ __device__ __forceinline__ void wino_htrans(const float4 (&t)[4], float4 (&v)[4]
 #pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = make_float4(o[2 * k][0], o[2 * k][1], o[2 * k + 1][0], o[2 * k + 1][1]);
 }
+// in-place forms ("+v": the result replaces an operand, no third register set): a -= b / a += b
+__device__ __forceinline__ void pk_sub_ip(float4& a, const float4& b) {
+  f32x2 lo{a.x, a.y}, hi{a.z, a.w};
+  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3") : "+v"(lo), "+v"(hi) : "v"(f32x2{b.x, b.y}), "v"(f32x2{b.z, b.w}));
+  a = make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+__device__ __forceinline__ void pk_add_ip(float4& a, const float4& b) {
+  f32x2 lo{a.x, a.y}, hi{a.z, a.w};
+  asm(WN_PK_ADD("%0", "%0", "%2") WN_PK_ADD("%1", "%1", "%3") : "+v"(lo), "+v"(hi) : "v"(f32x2{b.x, b.y}), "v"(f32x2{b.z, b.w}));
+  a = make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+// horizontal half, three of the four results in place of their operands: v = [t0 - t2, t1 + t2, t2 - t1, t1 - t3] with
+// v0 in t0's registers, v2 in t2's, v3 in t3's and v1 in a new pair of pairs; t is dead afterwards
+__device__ __forceinline__ void wino_htrans_ip(float4 (&t)[4], float4 (&v)[4]) {
+  f32x2 a0{t[0].x, t[0].y}, a1{t[0].z, t[0].w}, c0{t[2].x, t[2].y}, c1{t[2].z, t[2].w}, e0{t[3].x, t[3].y}, e1{t[3].z, t[3].w};
+  f32x2 n0, n1;
+  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3")          // t0 - t2
+      WN_PK_ADD("%6", "%8", "%2") WN_PK_ADD("%7", "%9", "%3")          // t1 + t2
+      WN_PK_SUB("%2", "%2", "%8") WN_PK_SUB("%3", "%3", "%9")          // t2 - t1
+      WN_PK_SUB("%4", "%8", "%4") WN_PK_SUB("%5", "%9", "%5")          // t1 - t3
+      "s_nop 1"
+      : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1), "+v"(e0), "+v"(e1), "=&v"(n0), "=&v"(n1)
+      : "v"(f32x2{t[1].x, t[1].y}), "v"(f32x2{t[1].z, t[1].w}));
+  v[0] = make_float4(a0[0], a0[1], a1[0], a1[1]);
+  v[1] = make_float4(n0[0], n0[1], n1[0], n1[1]);
+  v[2] = make_float4(c0[0], c0[1], c1[0], c1[1]);
+  v[3] = make_float4(e0[0], e0[1], e1[0], e1[1]);
+}
 __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
@@ -185,7 +214,8 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
 
 // XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
 template <int XH, bool ACT>
-__device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
+__device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1,
+                                               float4* scsh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   // wavefront roles: XH = wave & 1, mh = tile half, nh = column half
@@ -201,7 +231,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   const int W2 = W + 2;
   const int nitems = (2 * R + 2) * W2 * 4;
   const int q = tid & 3;
-  long goff[4];
+  unsigned goff[4];          // element offsets into X (host side: the tensor has < 2^32 elements)
   int loff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -211,7 +241,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     const int ry = px / W2, rx = px - ry * W2;
     const int y = 2 * ty0 - 1 + ry, x = rx - 1;
     const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
-    goff[j] = ok ? ((long)(n * H + y) * W + x) * C + q * 4 : 0;     // always a legal address
+    goff[j] = ok ? (unsigned)((((long)(n * H + y) * W + x) * C) + q * 4) : 0u;     // always a legal address
     // Which items are zero padding (left / right pad columns, rows above / below the clip) does not change over the stages of a
     // workgroup: their slots are zeroed ONCE in both buffers here, and afterwards these items - like the ones past the
     // window - write a slot nobody reads.  The staging code then has neither a branch nor a mask.
@@ -227,14 +257,25 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 #pragma unroll
     for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
   };
-  auto put_raw = [&](int st, float4* raw) {
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACT) {
-      sc = *reinterpret_cast<const float4*>(p.scale + st * 16 + q * 4);
-      sh = *reinterpret_cast<const float4*>(p.shift + st * 16 + q * 4);
+  // ACT: scale / shift of all C input channels sit in LDS (scsh: [C/4] scale quads, then [C/4] shift quads) - a
+  // global load inside a filler slot would wait out its whole latency there
+  if (ACT) {
+    for (int i = tid; i < (C >> 2); i += WN_THREADS) {
+      scsh[i] = *reinterpret_cast<const float4*>(p.scale + 4 * i);
+      scsh[(C >> 2) + i] = *reinterpret_cast<const float4*>(p.shift + 4 * i);
     }
+    __syncthreads();
+  }
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto read_scsh = [&](int st) {
+    if (ACT) {
+      sc = scsh[st * 4 + q];
+      sh = scsh[(C >> 2) + st * 4 + q];
+    }
+  };
+  auto put_raw_part = [&](float4* raw, int j0) {         // items j0, j0 + 1
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = j0; j < j0 + 2; ++j) {
       float4 v = pv[j];
       if (ACT) {
         v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
@@ -243,15 +284,26 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
       raw[loff[j]] = v;
     }
   };
+  auto put_raw = [&](float4* raw) { put_raw_part(raw, 0); put_raw_part(raw, 2); };
   // weight chunk c: 32 KB, already in LDS order; one LDS-DMA instruction of a wave moves 1 KB
   const int nchunk = C >> 3;
   const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
-  auto fetch_b = [&](int c, float4* bw) {
-    const float* src = Ub + (long)c * (WN_BCHUNK * 4);
-    float* dst = reinterpret_cast<float*>(bw) + wave * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 2048, dst + i * 2048, 16, 0, 0);
+  // Issued as inline asm, not through __builtin_amdgcn_global_load_lds: hipcc orders an LDS-DMA against later LDS reads by
+  // itself, tracks at most eight DMA instructions precisely and falls back to s_waitcnt vmcnt(0) beyond that - in front of
+  // the barrier of every other chunk, where it would wait out the activation loads issued a few hundred cycles earlier.
+  // Invisible to that pass, the DMA is ordered by hand: the issuing wave's counted vmcnt wait, then the barrier.
+  // M0 = LDS destination of lane 0 (wave-uniform); lane l lands at M0 + 16 l.
+  auto dma16 = [&](const float* src, float* dst) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(src) : "memory");
   };
+  auto fetch_b_part = [&](int c, float4* bw, int half) {        // two of the chunk's four instructions of this wave
+    const float* src = Ub + (long)c * (WN_BCHUNK * 4) + half * 4096;
+    float* dst = reinterpret_cast<float*>(bw) + wave * 256 + half * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(src + i * 2048, dst + i * 2048);
+  };
+  auto fetch_b = [&](int c, float4* bw) { fetch_b_part(c, bw, 0); fetch_b_part(c, bw, 1); };
 
   // ---------------------------------------------------------------- this lane's tile and fragment addresses
   int tyl_a, tx_a;
@@ -272,74 +324,139 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // K-step j of a chunk pairs channel c0 + j (lanes 0-31) with c0 + 4 + j (lanes 32-63): quad 2*sub + h
-  auto compute = [&](const float4* raw, int sub, const float4* bw) {
-    const float4* rq = raw + (2 * sub + h) * WN_SQ;
-    const float4* bq = bw + bcol;
-    float4 d[3][4];
+  // ---------------------------------------------------------------- main loop
+  // One barrier per 8-channel chunk; per chunk a wavefront issues 8 groups of 4 MFMAs (one accumulator each) and, pinned
+  // BETWEEN the groups by sched_barriers, the work that does not need the matrix pipe: the weight DMA of the next chunk, the
+  // staging of the next stage, and - software-pipelined ACROSS the barrier - the window reads and transforms of the NEXT
+  // chunk.  Why this shape (in-kernel cycle counters of the previous form, 6184 cycles per chunk against 4096 of MFMA per
+  // SIMD): hipcc placed every LDS read just in time, so at each chunk start all eight wavefronts waited for 16 reads in
+  // front of their first MFMA, did their vector-memory issue and their staging together (nobody issuing MFMAs meanwhile),
+  // and the later wavefront of a SIMD ran its last groups alone with the same exposed waits.  Now a chunk starts with
+  // its operands in registers (v0: the horizontally transformed window of positions 0-3, t1: the vertical transform for
+  // positions 4-7; only the four weight fragments are read after the barrier), and every filler slot sits behind a group
+  // of 4 dependent MFMAs (256 cycles of pipe): the two wavefronts of a SIMD fall into alternating groups by themselves (the
+  // arbiter prefers the older one until it reaches a filler), so one's fillers run under the other's MFMAs.
+  //   raw window of stage s+1: loaded (global -> registers) in chunk (s-1, 0), written to LDS in chunk (s, 0), first read
+  //   (prefetch for chunk (s+1, 0)) in chunk (s, 1); its buffer's last readers were the prefetch reads in chunk (s-1, 0).
+  const int nstage = C >> 4;
+  const float4* const aq0 = raw0 + h * WN_SQ;        // + 2 * sub * WN_SQ + rowoff[a] + (j & 1) * WN_SC + (j >> 1)
+  const float4* const aq1 = raw1 + h * WN_SQ;
+  float4 v0[4], t1[4];
+  // window reads + vertical transform of one chunk: rows XH, XH+2 -> t0 (in place), rows XH+1 and XH (XH+2) -> t1
+  auto read_rows02 = [&](const float4* rq, float4 (&d0)[4], float4 (&d2)[4]) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int j = 0; j < 4; ++j) d0[j] = rq[rowoff[0] + (j & 1) * WN_SC + (j >> 1)];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[a][j] = rq[rowoff[a] + (j & 1) * WN_SC + (j >> 1)];
+    for (int j = 0; j < 4; ++j) d2[j] = rq[rowoff[2] + (j & 1) * WN_SC + (j >> 1)];
+  };
+  auto read_row1 = [&](const float4* rq, float4 (&d1)[4]) {
 #pragma unroll
-    for (int xl = 0; xl < 2; ++xl) {
-      float4 t[4];
+    for (int j = 0; j < 4; ++j) d1[j] = rq[rowoff[1] + (j & 1) * WN_SC + (j >> 1)];
+  };
+  // t1 = XH ? d1 - d0 : d1 + d2 (into d1);  t0 = d0 - d2 (into d0) -> v0 = horizontal transform of t0
+  auto vertical = [&](float4 (&d0)[4], float4 (&d1)[4], float4 (&d2)[4]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (xl == 0) t[j] = f4sub(d[0][j], d[2][j]);                // frequency 0 (rows 0,2) / 3 (rows 1,3)
-        else t[j] = XH ? f4sub(d[1][j], d[0][j]) : f4add(d[1][j], d[2][j]);   // frequency 1: r1 + r2 / 2: r2 - r1
-      }
-      const int xi = xl ? xi1 : xi0;
-      const float4 b0 = bq[(xi * 4 + 0) * 128], b1 = bq[(xi * 4 + 1) * 128];
-      const float4 b2 = bq[(xi * 4 + 2) * 128], b3 = bq[(xi * 4 + 3) * 128];
-      float4 v[4];
-      wino_htrans(t, v);
-      mfma4(acc[xl * 4 + 0], v[0], b0);
-      mfma4(acc[xl * 4 + 1], v[1], b1);
-      mfma4(acc[xl * 4 + 2], v[2], b2);
-      mfma4(acc[xl * 4 + 3], v[3], b3);
+    for (int j = 0; j < 4; ++j) {
+      if (XH) pk_sub_ip(d1[j], d0[j]); else pk_add_ip(d1[j], d2[j]);
+      pk_sub_ip(d0[j], d2[j]);
     }
   };
 
-  // ---------------------------------------------------------------- main loop: one barrier per 8-channel chunk,
-  // unrolled over (stage parity, chunk of the stage) so that every buffer is a compile-time object
-  const int nstage = C >> 4;
   issue_raw(0);
   fetch_b(0, bw0);
-  put_raw(0, raw0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  read_scsh(0);
+  put_raw(raw0);
+  issue_raw(nstage > 1 ? 1 : 0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __syncthreads();
+  {
+    float4 d0[4], d1[4], d2[4];
+    read_rows02(aq0, d0, d2);
+    read_row1(aq0, d1);
+    vertical(d0, d1, d2);
+    wino_htrans_ip(d0, v0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t1[j] = d1[j];
+  }
+#define WN_SB() __builtin_amdgcn_sched_barrier(0)
+  // No run-time condition anywhere in a chunk: past the last stage the staging repeats the last stage (loads that hit L2,
+  // stores into a buffer nobody reads any more).  With the activation loads under a condition, hipcc's own wait in front of
+  // the barrier (the next chunk reads what the DMA wrote) falls back from vmcnt(4) to vmcnt(0) and every other barrier
+  // waits out the whole latency of loads issued a few hundred cycles earlier; two copies of the chunk (with / without)
+  // make the register allocator carry both sets of accumulators through the join (1 KB of spills per lane).
   auto step = [&](int c, auto kk) {
     constexpr int K = decltype(kk)::value;            // c % 4
     constexpr int sub = K & 1, sp = K >> 1;
     const int st = c >> 1;
-    float4* const bcur = sub ? bw1 : bw0;
+    const float4* const bq = (sub ? bw1 : bw0) + bcol;
     float4* const bnxt = sub ? bw0 : bw1;
-    float4* const rcur = sp ? raw1 : raw0;
     float4* const rnxt = sp ? raw0 : raw1;
-    // Order of the vector-memory queue in a chunk: the weight DMA first, the activation loads of the next stage behind it
-    // (sched_barriers: left alone the compiler sinks those loads to the end of the chunk).  vmcnt retires in order, so at the
-    // end of the chunk vmcnt(4) has seen the DMA land while the four activation loads may still fly - they have until the
-    // end of the NEXT chunk; waiting for them here as well (vmcnt(0)) cost 15 % of the kernel.
-    const bool raw_now = sub == 0 && st + 1 < nstage;
-    if (c + 1 < nchunk) fetch_b(c + 1, bnxt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (raw_now) issue_raw(st + 1);                        // in flight for this chunk and the next
-    __builtin_amdgcn_sched_barrier(0);
-    // staging of the next stage: into the buffer whose last readers were stage st - 1
-    compute(rcur, sub, bcur);
-    if (sub == 1 && st + 1 < nstage) put_raw(st + 1, rnxt);
-    // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier
-    if (raw_now) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // the next chunk's window: the other half of this stage's buffer, or the first half of the next stage's
+    const float4* const nq = sub ? (sp ? aq0 : aq1) : (sp ? aq1 : aq0) + 2 * WN_SQ;
+    const int cn = c + 1 < nchunk ? c + 1 : c;          // last chunk: a harmless repeat instead of a branch
+    float4 b[4], bb[4], d0[4], d1[4], d2[4], v1[4];
+    const int st1 = st + 1 < nstage ? st + 1 : nstage - 1, st2 = st + 2 < nstage ? st + 2 : nstage - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = bq[(xi0 * 4 + k) * 128];
+    if (sub == 0) read_scsh(st1);
+    WN_SB();
+    mfma4(acc[0], v0[0], b[0]);
+    WN_SB();
+    // first chunk of a stage: the staging of stage st + 1 (loaded during the previous stage; nothing else is outstanding in
+    // the vector-memory queue here, so the compiler's vmcnt(0) in front of the stores costs nothing), then the DMA (two
+    // instructions per slot; one per slot over four slots measured 1-4 % slower), then the loads of stage st + 2 behind it
+    if (sub == 0) put_raw_part(rnxt, 0);
+    else fetch_b_part(cn, bnxt, 0);
+    WN_SB();
+    mfma4(acc[1], v0[1], b[1]);
+    WN_SB();
+    if (sub == 0) put_raw_part(rnxt, 2);
+    else fetch_b_part(cn, bnxt, 1);
+    WN_SB();
+    mfma4(acc[2], v0[2], b[2]);
+    WN_SB();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bb[k] = bq[(xi1 * 4 + k) * 128];
+    if (sub == 0) fetch_b_part(cn, bnxt, 0);
+    WN_SB();
+    mfma4(acc[3], v0[3], b[3]);
+    WN_SB();
+    wino_htrans_ip(t1, v1);
+    if (sub == 0) fetch_b_part(cn, bnxt, 1);
+    WN_SB();
+    mfma4(acc[4], v1[0], bb[0]);
+    WN_SB();
+    read_rows02(nq, d0, d2);
+    if (sub == 0) issue_raw(st2);                     // behind the DMA in the vector-memory queue; stored in chunk (st + 1, 0)
+    WN_SB();
+    mfma4(acc[5], v1[1], bb[1]);
+    WN_SB();
+    read_row1(nq, d1);
+    WN_SB();
+    mfma4(acc[6], v1[2], bb[2]);
+    WN_SB();
+    vertical(d0, d1, d2);
+    WN_SB();
+    mfma4(acc[7], v1[3], bb[3]);
+    WN_SB();
+    wino_htrans_ip(d0, v0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t1[j] = d1[j];
+    WN_SB();
+    // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier.  vmcnt retires in
+    // order: vmcnt(4) has seen the DMA land while the four loads issued behind it still fly.
+    if (sub == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
+#undef WN_SB
+  using std::integral_constant;
   for (int c = 0; c < nchunk; c += 4) {
-    step(c, std::integral_constant<int, 0>());
-    step(c + 1, std::integral_constant<int, 1>());
+    step(c, integral_constant<int, 0>());
+    step(c + 1, integral_constant<int, 1>());
     if (c + 2 < nchunk) {
-      step(c + 2, std::integral_constant<int, 2>());
-      step(c + 3, std::integral_constant<int, 3>());
+      step(c + 2, integral_constant<int, 2>());
+      step(c + 3, integral_constant<int, 3>());
     }
   }
 
@@ -351,19 +468,21 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 
 // ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift)
 template <bool ACT>
-__device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1) {
-  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT>(p, raw0, raw1, bw0, bw1);
-  else conv_wino_body<0, ACT>(p, raw0, raw1, bw0, bw1);
+__device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1,
+                                                float4* scsh) {
+  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT>(p, raw0, raw1, bw0, bw1, scsh);
+  else conv_wino_body<0, ACT>(p, raw0, raw1, bw0, bw1, scsh);
 }
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(WinoParams p) {
   __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
   __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  conv_wino_entry<false>(p, raw0, raw1, bw0, bw1);
+  conv_wino_entry<false>(p, raw0, raw1, bw0, bw1, nullptr);
 }
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_act_kernel(WinoParams p) {
   __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
   __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  conv_wino_entry<true>(p, raw0, raw1, bw0, bw1);
+  __shared__ float4 scsh[2 * WN_MAXC / 4];
+  conv_wino_entry<true>(p, raw0, raw1, bw0, bw1, scsh);
 }
 
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
@@ -415,7 +534,7 @@ namespace acvae {
 
 bool conv3x3_wino_ok(int H, int W, int Cin, int Cout) {
   if (H < 1 || W < 4 || W > 64 || (W & (W - 1)) != 0) return false;      // TW = W/2 in {2,..,32}, a power of two
-  return Cin % 16 == 0 && Cout % WN_TN == 0;
+  return Cin % 16 == 0 && Cin <= WN_MAXC && Cout % WN_TN == 0;
 }
 long conv3x3_wino_weight_floats(int Cin, int Cout) { return 16L * Cin * Cout; }
 int conv_wino_partials_rows(int N, int H, int W) { return N * cdiv(cdiv(H, 2), tile_rows_per_block(W)); }
@@ -437,6 +556,7 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
                  int H, int W, int Cin, int Cout, hipStream_t st) {
   if (!X || !U || !Y) return ACVAE_EINVAL;
   if (!conv3x3_wino_ok(H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
+  if ((long)N * H * W * Cin >= (1L << 32)) return ACVAE_EUNSUPPORTED;      // 32-bit element offsets into X
   if (!aligned16(X) || !aligned16(U) || !aligned16(Y) || (scale && (!aligned16(scale) || !aligned16(shift)))) return ACVAE_EALIGN;
   WinoParams p;
   p.X = X; p.scale = scale; p.shift = shift; p.U = U; p.Y = Y; p.partials = partials;

@@ -1,0 +1,121 @@
+"""Lab builds of conv_wino.hip (NOT part of the product): applies named source patches (ablations / scheduling variants) to
+acvae_amd/csrc/conv_wino.hip, compiles the result and links it with the product's other objects into
+tools/lab/libacvae_<name>.so; on the GPU box `python tools/lab_wino.py time <name>...` times the Winograd kernels of each
+library (ACVAE_DEV_LIB) at three layer shapes.  Results of ablations are wrong by construction.
+usage: python tools/lab_wino.py build <name>... | time <name>... | list"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "acvae_amd", "csrc")
+LAB = os.path.join(ROOT, "tools", "lab")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I" + CSRC]
+
+PRE_LOOP = "  using std::integral_constant;\n  for (int c = 0; c < nchunk; c += 4) {"
+FAKE_D = ("#pragma unroll\n    for (int j = 0; j < 4; ++j) asm volatile(\"\" : \"=v\"(DST[j].x), \"=v\"(DST[j].y), \"=v\"(DST[j].z), "
+          "\"=v\"(DST[j].w));")
+VARIANTS = {
+    "base": [],
+    "prioA": [(PRE_LOOP, "  if (wave < 4) __builtin_amdgcn_s_setprio(1);\n" + PRE_LOOP)],
+    "prioB": [(PRE_LOOP, "  if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n" + PRE_LOOP)],
+    "nodma": [("    else fetch_b_part(cn, bnxt, 0);\n", ""), ("    else fetch_b_part(cn, bnxt, 1);\n", ""),
+              ("    if (sub == 0) fetch_b_part(cn, bnxt, 0);\n", ""), ("    if (sub == 0) fetch_b_part(cn, bnxt, 1);\n", "")],
+    "noraw": [("    if (sub == 0) put_raw_part(rnxt, 0);\n    else fetch_b_part", "    if (sub != 0) fetch_b_part"),
+              ("    if (sub == 0) put_raw_part(rnxt, 2);\n    else fetch_b_part", "    if (sub != 0) fetch_b_part"),
+              ("    if (sub == 0) issue_raw(st2);", "    (void)st2;"), ("    if (sub == 0) read_scsh(st1);\n", "    (void)st1;\n")],
+    "nod": [("    read_rows02(nq, d0, d2);\n", "    (void)nq;\n" + FAKE_D.replace("DST", "d0") + "\n" + FAKE_D.replace("DST", "d2") + "\n"),
+            ("    read_row1(nq, d1);\n", FAKE_D.replace("DST", "d1") + "\n")],
+}
+# phase stamps (s_memtime): [workgroup][wave][4] = prologue, main loop, epilogue, chunks; written over the start of Y after the epilogue
+VARIANTS["stamps"] = [
+    ("  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const long long lab_t0 = clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    (PRE_LOOP, "  const long long lab_t1 = clock64();\n" + PRE_LOOP),
+    ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
+     "  const long long lab_t2 = clock64();\n  float* exb"),
+    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+     "    o[0] = (float)(lab_t1 - lab_t0); o[1] = (float)(lab_t2 - lab_t1); o[2] = (float)(clock64() - lab_t2); o[3] = (float)nchunk;\n  }\n}\n\n// ACT: the operand"),
+]
+VARIANTS["mfmaonly"] = VARIANTS["nodma"] + [("    if (sub == 0) put_raw_part(rnxt, 0);\n", ""), ("    if (sub == 0) put_raw_part(rnxt, 2);\n", ""),
+                                         ("    if (sub == 0) issue_raw(st2);", "    (void)st2;"),
+                                         ("    if (sub == 0) read_scsh(st1);\n", "    (void)st1;\n")] + VARIANTS["nod"]
+
+
+def build(name):
+    src = open(os.path.join(CSRC, "conv_wino.hip")).read()
+    for old, new in VARIANTS[name]:
+        if old not in src:
+            raise SystemExit(f"{name}: patch anchor not found:\n{old}")
+        src = src.replace(old, new)
+    os.makedirs(LAB, exist_ok=True)
+    cpp = os.path.join(LAB, f"conv_wino_{name}.hip")
+    open(cpp, "w").write(src.replace('#include "../../include/acvae_hip.h"', f'#include "{ROOT}/include/acvae_hip.h"'))
+    obj = os.path.join(LAB, f"conv_wino_{name}.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-c", cpp, "-o", obj])
+    objs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".o") and f != "conv_wino.o"]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                           os.path.join(LAB, f"libacvae_{name}.so"), obj, *objs])
+    os.remove(obj)
+
+
+def time_one():
+    import math
+    import torch
+    sys.path.insert(0, ROOT)
+    from acvae_amd import _lib
+    S = _lib.current_stream
+    out = []
+    for (H, W, Cin, Cout) in [(1000, 64, 64, 64), (500, 32, 128, 128), (125, 8, 512, 512)]:
+        N = 32
+        x = torch.randn(N, H, W, Cin, device="cuda")
+        w = torch.randn(Cout, Cin, 3, 3, device="cuda") / math.sqrt(9 * Cin)
+        sc = torch.rand(Cin, device="cuda") + 0.5; sh = torch.randn(Cin, device="cuda") * 0.3
+        y = torch.empty(N, H, W, Cout, device="cuda")
+        wsb = _lib.call("acvae_conv3x3_workspace_bytes", N, H, W, Cin, Cout)
+        ws = torch.empty(int(wsb), dtype=torch.uint8, device="cuda")
+        gamma = torch.ones(Cout, device="cuda"); beta = torch.zeros(Cout, device="cuda")
+        rm = torch.zeros(Cout, device="cuda"); rv = torch.ones(Cout, device="cuda")
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda"); bn = torch.empty(4, Cout, device="cuda")
+        dyt = torch.randn(N, H, W, Cout, device="cuda"); dx = torch.empty(N, H, W, Cin, device="cuda")
+        dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+        fns = {"fwd_act": lambda: _lib.call("acvae_conv3x3_fwd_wino", x, w, sc, sh, y, gamma, beta, rm, rv, nbt, 1, bn, ws, wsb, N, H, W, Cin, Cout, S()),
+               "dgrad": lambda: _lib.call("acvae_conv3x3_dgrad_wino", dyt, w, dx, ws, wsb, N, H, W, Cin, Cout, S()),
+               "wgrad": lambda: _lib.call("acvae_conv3x3_wgrad_wino", dyt, x, sc, sh, dw, ws, wsb, N, H, W, Cin, Cout, S())}
+        if os.environ.get("ACVAE_DEV_LIB", "").endswith("_stamps.so"):
+            for k in ("fwd_act", "dgrad"):
+                fns[k](); torch.cuda.synchronize()
+                buf = (y if k == "fwd_act" else dx).reshape(-1)
+                nwg = N * ((H + 1) // 2 + (128 // W) - 1) // (128 // W) * ((Cin if k == "dgrad" else Cout) // 64)
+                t = buf[:nwg * 32].reshape(nwg, 8, 4).double()
+                m = t.mean(dim=(0,))
+                print(f"{Cin}->{Cout}@{W} {k}: WGs {nwg} chunks {int(t[0,0,3])}; per wave (prologue, main, epilogue) cycles/100MHz-ticks: "
+                      + "; ".join(f"w{w}: {m[w,0]:.0f} {m[w,1]:.0f} {m[w,2]:.0f}" for w in (0, 4)) + f"  main/chunk {float(m[:,1].mean()/t[0,0,3]):.1f}")
+            continue
+        for k, fn in fns.items():
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            out.append(f"{Cin}->{Cout}@{W} {k} {a.elapsed_time(b) / 20 * 1e3:.0f}us")
+    print(os.environ.get("ACVAE_DEV_LIB", "product").split("_")[-1], " | ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    cmd, names = sys.argv[1], sys.argv[2:]
+    if cmd == "list":
+        print(" ".join(VARIANTS))
+    elif cmd == "build":
+        for n in names or VARIANTS:
+            build(n)
+    elif cmd == "time":
+        for n in names:
+            lib = os.path.join(LAB, f"libacvae_{n}.so")
+            subprocess.call([sys.executable, os.path.abspath(__file__), "_one"], env=dict(os.environ, ACVAE_DEV_LIB=lib))
+    elif cmd == "_one":
+        time_one()
