@@ -617,6 +617,7 @@ template <int XH, int SS>
 __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float* xw0, float* xw1, float* dy0, float* dy1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same value as a scalar (for the code behind the main loop)
   const int ah = (wave >> 1) & 1, bh = wave >> 2;       // ci half, co half of this wavefront; XH = wave & 1
   const int z = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
   const int H = p.H, W = p.W;
@@ -651,9 +652,11 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   const int WCin = W * p.Cin;
   float4 px[5];
   unsigned xok = 0;
-  auto issue = [&](int g, float* dys) {
-    const int n = g / p.spc, s = g - n * p.spc;
-    const int trow = s / p.segs, seg = s - trow * p.segs;
+  // stage g = (clip n, stage s of the clip): advanced incrementally (wave-uniform scalars; the two integer divisions per stage
+  // were a visible part of the stage's issue time)
+  const int seg_shift = p.segs == 2 ? 1 : 0;
+  auto issue_dy = [&](int n, int s, float* dys) {
+    const int trow = s >> seg_shift, seg = s & (p.segs - 1);
     const int ty0 = trow * p.RS, tx0 = seg * 16;          // first tile of the stage
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -667,6 +670,10 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
         *reinterpret_cast<float4*>(dst + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+  };
+  auto issue_x = [&](int n, int s) {
+    const int trow = s >> seg_shift, seg = s & (p.segs - 1);
+    const int ty0 = trow * p.RS, tx0 = seg * 16;
     // 32-bit element offsets (the launcher refuses tensors of 2^31 elements or more): a wave-uniform base per stage plus a
     // per-item part - no 64-bit multiplies per item
     const int xbase = ((n * H + 2 * ty0 - 1) * W + (2 * tx0 - 1)) * p.Cin + cib * 64 + quad * 4;
@@ -681,9 +688,9 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
       px[j] = *reinterpret_cast<const float4*>(p.X + off);
     }
   };
-  auto put = [&](float* xw) {
+  auto put_part = [&](float* xw, int j0, int j1) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = j0; j < j1; ++j) {
       float4 v = px[j];
       if (act) {
         v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
@@ -692,7 +699,6 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
       if (!((xok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((xlive >> j) & 1u) *reinterpret_cast<float4*>(xw + xlo[j]) = v;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of the same stage (older than the loads above) has landed
   };
 
   // ---------------------------------------------------------------- fragment addresses of this lane
@@ -782,50 +788,72 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
     acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a67[0], b56[1], acc[6], 0, 0, 0);
     acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a67[1], r1[1], acc[7], 0, 0, 0);
   };
-  auto compute = [&](const float* xw, const float* dys) {
+  // One stage = 8 tile pairs = 8 blocks of 8 MFMAs per wavefront.  Everything that does not need the matrix pipe sits
+  // BETWEEN the blocks (sched_barriers pin it there), where the other wavefront of the SIMD covers it with its own MFMAs:
+  // the next stage's gradient DMA behind block 0, its window loads behind block 1, the staging of that window (BatchNorm +
+  // ReLU + ds_write) behind blocks 4-6, after the loads have had three blocks to land.  (Before, all eight wavefronts issued
+  // their loads together in front of the stage's first MFMA and staged together behind its last: 2560 + 1420 cycles of a
+  // 15 900-cycle stage with the pipe idle - in-kernel counters of round 2.)
+#define WG_SB() __builtin_amdgcn_sched_barrier(0)
+  auto compute = [&](const float* xw, const float* dys, bool more, int nn, int ns, float* xw_n, float* dy_n) {
     Frag fa, fb;
     load(std::integral_constant<int, 0>(), xw, dys, fa);
-#define WG_PAIR(J)                                                                       \
-    load(std::integral_constant<int, J + 1>(), xw, dys, fb);                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    mm(fa);                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    if (J + 2 < 8) load(std::integral_constant<int, (J + 2 < 8 ? J + 2 : 0)>(), xw, dys, fa); \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    mm(fb);                                                                              \
-    __builtin_amdgcn_sched_barrier(0);
-    WG_PAIR(0) WG_PAIR(2) WG_PAIR(4) WG_PAIR(6)
-#undef WG_PAIR
+    load(std::integral_constant<int, 1>(), xw, dys, fb); WG_SB(); mm(fa); WG_SB();
+    if (more) issue_dy(nn, ns, dy_n);
+    WG_SB();
+    load(std::integral_constant<int, 2>(), xw, dys, fa); WG_SB(); mm(fb); WG_SB();
+    if (more) issue_x(nn, ns);
+    WG_SB();
+    load(std::integral_constant<int, 3>(), xw, dys, fb); WG_SB(); mm(fa); WG_SB();
+    load(std::integral_constant<int, 4>(), xw, dys, fa); WG_SB(); mm(fb); WG_SB();
+    load(std::integral_constant<int, 5>(), xw, dys, fb); WG_SB(); mm(fa); WG_SB();
+    if (more) put_part(xw_n, 0, 2);
+    WG_SB();
+    load(std::integral_constant<int, 6>(), xw, dys, fa); WG_SB(); mm(fb); WG_SB();
+    if (more) put_part(xw_n, 2, 4);
+    WG_SB();
+    load(std::integral_constant<int, 7>(), xw, dys, fb); WG_SB(); mm(fa); WG_SB();
+    if (more) put_part(xw_n, 4, 5);
+    WG_SB();
+    mm(fb);
+    WG_SB();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of the next stage has landed (issued seven blocks ago)
+    __syncthreads();
   };
+#undef WG_SB
 
   // ---------------------------------------------------------------- main loop: one barrier per 16-tile stage
   if (g_begin < g_end) {
-    issue(g_begin, dy0);
-    put(xw0);
+    int n = g_begin / p.spc, sidx = g_begin - n * p.spc;
+    issue_dy(n, sidx, dy0);
+    issue_x(n, sidx);
+    put_part(xw0, 0, 5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int g = g_begin; g < g_end; g += 2) {
-      if (g + 1 < g_end) issue(g + 1, dy1);              // dy1 / xw1: last read at stage g - 1, behind the barrier
-      compute(xw0, dy0);
-      if (g + 1 < g_end) put(xw1);
-      __syncthreads();
+      if (++sidx == p.spc) { sidx = 0; ++n; }
+      compute(xw0, dy0, g + 1 < g_end, n, sidx, xw1, dy1);          // dy1 / xw1: last read at stage g - 1, behind the barrier
       if (g + 1 < g_end) {
-        if (g + 2 < g_end) issue(g + 2, dy0);
-        compute(xw1, dy1);
-        if (g + 2 < g_end) put(xw0);
-        __syncthreads();
+        if (++sidx == p.spc) { sidx = 0; ++n; }
+        compute(xw1, dy1, g + 2 < g_end, n, sidx, xw0, dy0);
       }
     }
   }
 
   // ---------------------------------------------------------------- slab: [z][position][ci][co]
+  // Lane and wave coordinates are taken afresh here (lane id from mbcnt, wave index as a scalar): carried over from the top of
+  // the kernel they would be live across the main loop, which has no register to spare (hipcc spilled `lane & 32`).
   constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int li_e = lane_e & 31, kh_e = lane_e >> 5;
+  const int ah_e = (wave_s >> 1) & 1, bh_e = wave_s >> 2;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int pos = ((q >> 2) ? xi1 : xi0) * 4 + (q & 3);
-    float* out = p.slab + (((long)z * 16 + pos) * p.Cin + cib * 64 + ah * 32) * p.Cout + cob * 64 + bh * 32 + li;
+    float* out = p.slab + (((long)z * 16 + pos) * p.Cin + cib * 64 + ah_e * 32) * p.Cout + cob * 64 + bh_e * 32 + li_e;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh_e;
       out[(long)row * p.Cout] = acc[q][r];
     }
   }

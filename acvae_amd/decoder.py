@@ -112,8 +112,10 @@ class RNNDecoder(BaseDecoder):
         # valid for ONE model forward and only while the three parameters are what they were when it was built (an
         # optimiser step, load_state_dict or an in-place edit bumps _version); callers outside a model forward (the
         # step-wise decoder / prior API) have no token and always rebuild
+        # (the grad mode is NOT part of the key: the backward of that forward runs with grad mode off and must find the
+        # forward's table, whose grad_fn routes the table's gradient to the three parameters)
         key = (token, we[0].weight._version, we[1].weight._version, we[1].bias._version, we[0].weight.data_ptr(),
-               we[1].weight.data_ptr(), torch.is_grad_enabled())
+               we[1].weight.data_ptr())
         hit = getattr(self, "_table_cache", None)
         if hit is not None and token is not None and hit[0] == key:
             return hit[1]
