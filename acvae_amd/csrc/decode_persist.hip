@@ -1,0 +1,423 @@
+// A4 / A5 / A7: the teacher-forced decode loop (models/vae_model.py:700-730,792-816 with PriorRNN.forward
+// models/text_encoder.py:247-268 and VAERNNBahdanauAttnDecoder.forward models/decoder.py:175-203) as ONE persistent launch.
+//
+// The per-step form (decoder.hip) queues four dependent kernels per step and chain - 2 x 4 x 21 launches of 5-17 us each
+// for microseconds of work: every kernel pays its own start, its own first-load latency and a boundary.  Here the Tc
+// steps of both chains run inside one kernel whose workgroups keep FIXED roles and hand their results to the next role
+// through global memory:
+//
+//   decoder chain                                               prior chain
+//   D1 [A/32 + 3H/32 wgs]  qd = h.Watt_q^T, gh = h.Whh^T + b     P1 [Hp/8 wgs]  gates += z.Wih_z^T + hp.Whh^T + b, LSTM cell
+//   D2 [N wgs]             attention of clip n -> ctx, weights   P2 [E/16 wgs]  [mu, logvar] = hp.Wml^T + b, z = eps.exp(lv/2) + mu
+//   D3 [H/16 wgs]          gi += ctx.Wih_ctx^T, GRU cell -> h
+//
+// Every product is the arithmetic of gemm_skinny_kernel (one 32 x 32 tile, K dealt over 8 wavefronts in groups of 8,
+// partial tiles summed in wave order), the attention is attn_fwd_kernel's, the cells are rnn.hip's: results are
+// bit-identical to the per-step path, which stays for scheduled sampling, inference and shapes this kernel does not take
+// and is its parity check (tests/test_decode_persist_gpu.py).
+//
+// Hand-offs (cdna_hip_programming.md Guideline 16; MI355X_MICROARCH.md, Valid forms): every handed-off value is written by
+// an agent-scope atomic store (write-through, `sc1`) and read by an agent-scope atomic load (bypasses the CU's L1, which
+// no other CU's store ever refreshes); every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at
+// a barrier, ONE lane adds to the step's arrival counter; the consumer's lane 0 polls that ONE word relaxed with s_sleep,
+// then the workgroup's barrier.  No fence anywhere.  Counters are per (role, step), zeroed by the launcher's memset:
+// nothing is ever reset or reused inside the launch.  All workgroups (160 + N + ...) fit the chip at once (512 threads,
+// 34 KB of LDS: two per CU would fit); every spin is bounded and raises an abort word that ends all roles.
+#include "mfma_tile.h"
+#include "common.h"
+#include "../../include/acvae_hip.h"
+#include "decode_persist.h"
+
+namespace {
+using namespace mfma;
+
+constexpr int PD_THREADS = 512;          // 8 wavefronts, as gemm_skinny_kernel
+constexpr unsigned PD_SPIN_LIMIT = 1u << 24;   // x ~150 ns: seconds; never reached unless a role died
+
+#define PD_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), PD_RLX_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), PD_RLX_AGENT));
+}
+__device__ __forceinline__ float4 ld_sc1_4(const float* p) {       // 16-byte aligned; two 8-byte write-through-coherent loads
+  const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), PD_RLX_AGENT);
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, PD_RLX_AGENT);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                     __uint_as_float((unsigned)(b >> 32)));
+}
+
+// Lane 0 waits until *cnt >= target (relaxed polls, s_sleep between them), then the workgroup's barrier.  Returns false
+// when the launch is aborting (a bounded spin ran out somewhere): every role then leaves its loop.
+__device__ __forceinline__ bool pd_wait(const unsigned* cnt, unsigned target, unsigned* abort_word, int* s_flag) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    for (unsigned spins = 0; __hip_atomic_load(cnt, PD_RLX_AGENT) < target;) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) == 0u && (spins > PD_SPIN_LIMIT || __hip_atomic_load(abort_word, PD_RLX_AGENT) != 0u)) {
+        __hip_atomic_store(abort_word, 1u, PD_RLX_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+  __syncthreads();          // s_flag may be rewritten by the next wait
+  return ok;
+}
+// Every wave has drained its stores; one lane signals.
+__device__ __forceinline__ void pd_arrive(unsigned* cnt) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, PD_RLX_AGENT);
+}
+
+// acc += A[32 rows][K] . B[32 rows][K]^T for this wave's share of the K-groups: exactly sk_accumulate<true> (mfma_tile.h)
+// with per-lane row pointers (ap / bp point at the lane's row, + 4 * (lane >> 5)); HANDED: A was written inside this
+// launch (coherent loads), otherwise plain float4 loads.
+template <bool HANDED>
+__device__ __forceinline__ void pd_accumulate(f32x16& acc, const float* ap, const float* bp, int K, int wave) {
+  constexpr int U = 8;
+  const int Gfull = K / 8;
+  for (int g = wave; g < Gfull; g += U * SK_WAVES) {
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int gu = g + u * SK_WAVES;
+      const long off = (gu < Gfull) ? (long)gu * 8 : 0;
+      b[u] = *reinterpret_cast<const float4*>(bp + off);
+      a[u] = HANDED ? ld_sc1_4(ap + off) : *reinterpret_cast<const float4*>(ap + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = (g + u * SK_WAVES) < Gfull;
+      const float4 av = ok ? a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+}
+// the wave's accumulator tile into red[wave][row][col] (gemm_skinny_kernel's layout); sum over waves in order by the caller
+__device__ __forceinline__ void pd_stash(float (*red)[32][33], const f32x16& acc, int wave, int li, int lh) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+}
+__device__ __forceinline__ float pd_sum(float (*red)[32][33], int mm, int nn) {
+  float v = 0.f;
+#pragma unroll
+  for (int w = 0; w < SK_WAVES; ++w) v += red[w][mm][nn];
+  return v;
+}
+
+struct PdSmem {
+  float red[SK_WAVES][32][33];     // one reduction tile; D3 runs its two tiles through it one after the other
+  float keep[32][33];              // D3: the first tile's sums while the second is reduced
+  int flag;
+};
+
+// ---------------------------------------------------------------- D1: qd = h . Watt[:, :H]^T;  gh = h . Whh^T + bhh
+__device__ void role_d1(const PdParams& p, int tile, PdSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int nq = p.A / 32;
+  const bool is_q = tile < nq;
+  const int n0 = (is_q ? tile : tile - nq) * 32;
+  const float* B = is_q ? p.w_att : p.w_hh;
+  const long ldb = is_q ? (long)(p.E + p.H) : (long)p.H;
+  const float* bp = B + (long)(n0 + li) * ldb + 4 * lh;
+  const int arow = li < p.N ? li : 0;            // rows past N are never stored: they may read row 0
+  for (int t = 0; t < p.Tc; ++t) {
+    if (t > 0 && !pd_wait(p.cnt + PD_C_D3 * p.Tc + (t - 1), (unsigned)p.n_d3, p.abort_word, &sm.flag)) return;
+    const float* hprev = t ? p.outputs + (long)(t - 1) * p.H : p.zeros;
+    const long ldh = t ? (long)p.Tc * p.H : (long)p.H;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (t) pd_accumulate<true>(acc, hprev + arow * ldh + 4 * lh, bp, p.H, wave);
+    else pd_accumulate<false>(acc, hprev + arow * ldh + 4 * lh, bp, p.H, wave);
+    pd_stash(sm.red, acc, wave, li, lh);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += PD_THREADS) {
+      const int mm = e >> 5, nn = e & 31;
+      if (mm < p.N) {
+        float v = pd_sum(sm.red, mm, nn);
+        if (is_q) st_sc1(p.qd + (long)mm * p.Tc * p.A + (long)t * p.A + n0 + nn, v);
+        else st_sc1(p.gh + (long)mm * 3 * p.H + n0 + nn, v + p.b_hh[n0 + nn]);
+      }
+    }
+    pd_arrive(p.cnt + (is_q ? PD_C_D1Q : PD_C_D1H) * p.Tc + t);
+  }
+}
+
+// ---------------------------------------------------------------- D2: attention of clip n (attn_fwd_kernel<true>, 8 context groups)
+__device__ void role_d2(const PdParams& p, int n, float* smem, int* s_flag) {
+  const int S = p.S, A = p.A, E = p.E;
+  float* sc = smem;
+  float* red = smem + S;
+  float* part = smem + ((S + 16 + 3) & ~3);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* P = p.encproj + (long)n * S * A;
+  const float* Hn = p.mem + (long)n * S * E;
+  const float* v = p.att_v;
+  const int len = (int)p.mem_lens[n];
+  for (int t = 0; t < p.Tc; ++t) {
+    if (!pd_wait(p.cnt + PD_C_D1Q * p.Tc + t, (unsigned)(A / 32), p.abort_word, s_flag)) return;
+    const float* q = p.qd + (long)n * p.Tc * A + (long)t * A;
+    // ---- scores: wave per frame, lanes over A
+    for (int s = wave; s < S; s += SK_WAVES) {
+      const float* pr = P + (long)s * A;
+      float acc = 0.f;
+      for (int a = lane * 4; a < A; a += 256) {
+        const float4 pv = *reinterpret_cast<const float4*>(pr + a);
+        const float4 qv = ld_sc1_4(q + a);
+        const float4 vv = *reinterpret_cast<const float4*>(v + a);
+        acc += vv.x * tanhf(qv.x + pv.x) + vv.y * tanhf(qv.y + pv.y) + vv.z * tanhf(qv.z + pv.z) +
+               vv.w * tanhf(qv.w + pv.w);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) sc[s] = (s < len) ? acc : -1e10f;
+    }
+    __syncthreads();
+    // ---- softmax over S (S <= PD_THREADS: one element per thread, as with the 1024-thread launch of the per-step path)
+    float m = -INFINITY;
+    for (int s = threadIdx.x; s < S; s += PD_THREADS) m = fmaxf(m, sc[s]);
+    m = block_max(m, red);
+    float sum = 0.f;
+    for (int s = threadIdx.x; s < S; s += PD_THREADS) {
+      const float e = expf(sc[s] - m);
+      sc[s] = e;
+      sum += e;
+    }
+    sum = block_sum(sum, red);
+    const float inv = 1.f / sum;
+    float* wout = p.attn_w + (long)n * p.Tc * S + (long)t * S;
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += PD_THREADS) {
+      const float w = sc[s] * inv;
+      sc[s] = w;
+      wout[s] = w;
+    }
+    __syncthreads();
+    // ---- context: E/4 threads per memory row; the per-step kernel runs 1024 threads = 8 groups taking frames g, g+8, ..;
+    // here 4 thread groups play two of those each, so the partial sums and their order are the same
+    const int ev = E >> 2, GR = PD_THREADS / ev;          // real groups (E = 512: 4)
+    const int g0 = threadIdx.x / ev, e4 = (threadIdx.x - g0 * ev) * 4;
+    const int GV = 1024 / ev;                             // groups of the 1024-thread per-step launch (E = 512: 8)
+    if (g0 < GR) {
+      for (int g = g0; g < GV; g += GR) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = g; s0 < S; s0 += GV) {
+          const float4 h = *reinterpret_cast<const float4*>(Hn + (long)s0 * E + e4);
+          const float w = sc[s0];
+          acc.x += w * h.x; acc.y += w * h.y; acc.z += w * h.z; acc.w += w * h.w;
+        }
+        *reinterpret_cast<float4*>(part + (long)g * E + e4) = acc;
+      }
+    }
+    __syncthreads();
+    float* c = p.rnn_d + (long)n * p.Tc * 3 * E + (long)t * 3 * E + E;
+    for (int e = threadIdx.x; e < E; e += PD_THREADS) {
+      float acc = 0.f;
+      for (int k = 0; k < GV; ++k) acc += part[(long)k * E + e];
+      st_sc1(c + e, acc);
+    }
+    pd_arrive(p.cnt + PD_C_D2 * p.Tc + t);
+  }
+}
+
+// ---------------------------------------------------------------- D3: gi += ctx . Wih[:, E:2E]^T, GRU cell (rnn.hip gru_fwd_kernel)
+__device__ void role_d3(const PdParams& p, int slice, PdSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int H = p.H, E = p.E, u0 = slice * 16;
+  // tile 1 columns: r of units u0..u0+15 | z of the same units;  tile 2: n of the units | 16 unused columns (row 0)
+  const int row1 = li < 16 ? u0 + li : H + u0 + (li - 16);
+  const int row2 = li < 16 ? 2 * H + u0 + li : 0;
+  const float* bp1 = p.w_ih + (long)row1 * 3 * E + E + 4 * lh;
+  const float* bp2 = p.w_ih + (long)row2 * 3 * E + E + 4 * lh;
+  const int arow = li < p.N ? li : 0;
+  for (int t = 0; t < p.Tc; ++t) {
+    if (!pd_wait(p.cnt + PD_C_D2 * p.Tc + t, (unsigned)p.N, p.abort_word, &sm.flag)) return;
+    const float* ap = p.rnn_d + (long)arow * p.Tc * 3 * E + (long)t * 3 * E + E + 4 * lh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    pd_accumulate<true>(acc, ap, bp1, E, wave);
+    pd_stash(sm.red, acc, wave, li, lh);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += PD_THREADS) sm.keep[e >> 5][e & 31] = pd_sum(sm.red, e >> 5, e & 31);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    pd_accumulate<true>(acc, ap, bp2, E, wave);
+    pd_stash(sm.red, acc, wave, li, lh);
+    // gh of this step has arrived long ago as a rule (D1 ran before the attention); the wait orders the loads below
+    if (!pd_wait(p.cnt + PD_C_D1H * p.Tc + t, (unsigned)(3 * H / 32), p.abort_word, &sm.flag)) return;   // includes the barrier
+    // cell: 32 rows x 16 units = one element per thread
+    {
+      const int mm = threadIdx.x >> 4, j = threadIdx.x & 15;
+      if (mm < p.N) {
+        const int u = u0 + j;
+        const float* gi = p.gi + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
+        const float* gh = p.gh + (long)mm * 3 * H;
+        const float a_r = sm.keep[mm][j] + gi[u];               // the per-step path: v = sum; v += *p (accumulate)
+        const float a_z = sm.keep[mm][16 + j] + gi[H + u];
+        const float a_n = pd_sum(sm.red, mm, j) + gi[2 * H + u];
+        const float b_r = ld_sc1(gh + u), b_z = ld_sc1(gh + H + u), ghn = ld_sc1(gh + 2 * H + u);
+        const float h = t ? ld_sc1(p.outputs + (long)mm * p.Tc * H + (long)(t - 1) * H + u) : 0.f;
+        const float r = sigmoidf_(a_r + b_r);
+        const float z = sigmoidf_(a_z + b_z);
+        const float nn = tanhf(a_n + r * ghn);
+        const float hn = (1.f - z) * nn + z * h;
+        p.hprev_d[(long)mm * p.Tc * H + (long)t * H + u] = h;
+        float* sv = p.gru_save + (long)mm * p.Tc * 4 * H + (long)t * 4 * H;
+        sv[u] = r; sv[H + u] = z; sv[2 * H + u] = nn; sv[3 * H + u] = ghn;
+        st_sc1(p.outputs + (long)mm * p.Tc * H + (long)t * H + u, hn);
+      }
+    }
+    pd_arrive(p.cnt + PD_C_D3 * p.Tc + t);
+  }
+}
+
+// ---------------------------------------------------------------- P1: gates += z . Wih[:, 2E:3E]^T + hp . Whh^T + bhh, LSTM cell
+__device__ void role_p1(const PdParams& p, int slice, PdSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int Hp = p.E, E = p.E, u0 = slice * 8;
+  const int row = (li >> 3) * Hp + u0 + (li & 7);            // column li = (gate li / 8, unit li % 8)
+  const float* bz = p.pw_ih + (long)row * 3 * E + 2 * E + 4 * lh;
+  const float* bh = p.pw_hh + (long)row * Hp + 4 * lh;
+  const int arow = li < p.N ? li : 0;
+  for (int t = 0; t < p.Tc; ++t) {
+    if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, &sm.flag)) return;
+    const float* az = p.rnn_p + (long)arow * p.Tc * 3 * E + (long)t * 3 * E + 2 * E + 4 * lh;
+    const float* hprev = t ? p.hp_all + (long)(t - 1) * Hp : p.zeros;
+    const long ldh = t ? (long)p.Tc * Hp : (long)Hp;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (t) {
+      pd_accumulate<true>(acc, az, bz, E, wave);
+      pd_accumulate<true>(acc, hprev + arow * ldh + 4 * lh, bh, Hp, wave);
+    } else {
+      pd_accumulate<false>(acc, az, bz, E, wave);
+      pd_accumulate<false>(acc, hprev + arow * ldh + 4 * lh, bh, Hp, wave);
+    }
+    pd_stash(sm.red, acc, wave, li, lh);
+    __syncthreads();
+    if (threadIdx.x < 256) {                                   // 32 rows x 8 units
+      const int mm = threadIdx.x >> 3, j = threadIdx.x & 7;
+      if (mm < p.N) {
+        const int u = u0 + j;
+        const float* g = p.gates_p + (long)mm * p.Tc * 4 * Hp + (long)t * 4 * Hp;
+        float gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v = pd_sum(sm.red, mm, k * 8 + j);
+          v += p.pb_hh[k * Hp + u];
+          v += g[k * Hp + u];
+          gv[k] = v;
+        }
+        const float ig = sigmoidf_(gv[0]), fg = sigmoidf_(gv[1]), gg = tanhf(gv[2]), og = sigmoidf_(gv[3]);
+        const float c = t ? ld_sc1(p.c_all + (long)mm * p.Tc * Hp + (long)(t - 1) * Hp + u) : 0.f;
+        const float c2 = fg * c + ig * gg;
+        const float tc = tanhf(c2);
+        st_sc1(p.hp_all + (long)mm * p.Tc * Hp + (long)t * Hp + u, og * tc);
+        st_sc1(p.c_all + (long)mm * p.Tc * Hp + (long)t * Hp + u, c2);
+        float* s = p.lstm_save + (long)mm * p.Tc * 5 * Hp + (long)t * 5 * Hp;
+        s[u] = ig; s[Hp + u] = fg; s[2 * Hp + u] = gg; s[3 * Hp + u] = og; s[4 * Hp + u] = tc;
+      }
+    }
+    pd_arrive(p.cnt + PD_C_P1 * p.Tc + t);
+  }
+}
+
+// ---------------------------------------------------------------- P2: [mu | logvar] = hp . Wml^T + b, re-parameterisation
+__device__ void role_p2(const PdParams& p, int slice, PdSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int Hp = p.E, E = p.E, e0 = slice * 16;
+  const int row = li < 16 ? e0 + li : E + e0 + (li - 16);
+  const float* bp = p.w_ml + (long)row * Hp + 4 * lh;
+  const int arow = li < p.N ? li : 0;
+  for (int t = 0; t < p.Tc; ++t) {
+    if (!pd_wait(p.cnt + PD_C_P1 * p.Tc + t, (unsigned)p.n_p1, p.abort_word, &sm.flag)) return;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    pd_accumulate<true>(acc, p.hp_all + (long)arow * p.Tc * Hp + (long)t * Hp + 4 * lh, bp, Hp, wave);
+    pd_stash(sm.red, acc, wave, li, lh);
+    __syncthreads();
+    {
+      const int mm = threadIdx.x >> 4, j = threadIdx.x & 15;
+      if (mm < p.N) {
+        const int e = e0 + j;
+        const float mu = pd_sum(sm.red, mm, j) + p.b_ml[e];
+        const float lv = pd_sum(sm.red, mm, 16 + j) + p.b_ml[E + e];
+        const float zz = p.eps_p[(long)t * p.N * E + (long)mm * E + e] * expf(.5f * lv) + mu;
+        const long o = (long)mm * p.Tc * E + (long)t * E + e;
+        p.p_means[o] = mu; p.p_logs[o] = lv; p.p_z[o] = zz;
+        if (t + 1 < p.Tc) st_sc1(p.rnn_p + (long)mm * p.Tc * 3 * E + (long)(t + 1) * 3 * E + 2 * E + e, zz);
+      }
+    }
+    pd_arrive(p.cnt + PD_C_P2 * p.Tc + t);
+  }
+}
+
+__global__ __launch_bounds__(PD_THREADS) void decode_persist_kernel(PdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pd_smem_raw[];
+  PdSmem& sm = *reinterpret_cast<PdSmem*>(pd_smem_raw);
+  int b = blockIdx.x;
+  if (b < p.n_d1) { role_d1(p, b, sm); return; }
+  b -= p.n_d1;
+  if (b < p.N) { role_d2(p, b, reinterpret_cast<float*>(pd_smem_raw) + 4, reinterpret_cast<int*>(pd_smem_raw)); return; }
+  b -= p.N;
+  if (b < p.n_d3) { role_d3(p, b, sm); return; }
+  b -= p.n_d3;
+  if (b < p.n_p1) { role_p1(p, b, sm); return; }
+  b -= p.n_p1;
+  role_p2(p, b, sm);
+}
+
+}  // namespace
+
+namespace acvae {
+
+static int g_persist = -1;      // -1: not decided yet (environment), 0 / 1: set
+bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A) {
+  if (g_persist < 0) g_persist = (getenv("ACVAE_DECODE_PERSIST") && atoi(getenv("ACVAE_DECODE_PERSIST")) == 0) ? 0 : 1;
+  // one 32-row tile of clips; whole 32 / 16 / 8-wide slices and K-groups of 8; one score per thread in the softmax; E a
+  // power of two so that the context groups of the per-step attention kernel (1024 / (E / 4)) can be replayed exactly
+  return g_persist == 1 && N >= 1 && N <= 32 && Tc >= 1 && S >= 1 && S <= PD_THREADS && E >= 32 && E <= 2048 &&
+         (E & (E - 1)) == 0 && H % 32 == 0 && A % 32 == 0;
+}
+long decode_persist_counter_words(int Tc) { return ((long)PD_C_COUNT * Tc + 1 + 3) & ~3L; }
+
+int decode_persist_fwd(PdParams p, hipStream_t st) {
+  if (!decode_persist_ok(p.N, p.Tc, p.S, p.E, p.H, p.A)) return ACVAE_EUNSUPPORTED;
+  p.n_d1 = p.A / 32 + 3 * p.H / 32;
+  p.n_d3 = p.H / 16;
+  p.n_p1 = p.E / 8;
+  p.n_p2 = p.E / 16;
+  const long words = decode_persist_counter_words(p.Tc);
+  p.abort_word = p.cnt + (long)PD_C_COUNT * p.Tc;
+  if (hipMemsetAsync(p.cnt, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
+  const int grid = p.n_d1 + p.N + p.n_d3 + p.n_p1 + p.n_p2;
+  size_t shm = sizeof(PdSmem);
+  const size_t att = (size_t)(4 + ((p.S + 16 + 3) & ~3) + 4096) * sizeof(float);      // context partials: (1024 / (E/4)) x E
+  if (att > shm) shm = att;
+  if (shm > 64 * 1024) return ACVAE_EUNSUPPORTED;
+  hipLaunchKernelGGL(decode_persist_kernel, dim3(grid), dim3(PD_THREADS), shm, st, p);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+}  // namespace acvae
+
+extern "C" int acvae_set_decode_persist(int on) {
+  const int before = acvae::g_persist;
+  acvae::g_persist = on ? 1 : 0;
+  return before;
+}

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "conv.h"
 #include "rnn.h"
+#include "decode_persist.h"
 #include "../../include/acvae_hip.h"
 
 namespace {
@@ -142,7 +143,7 @@ struct DecLayout {
   long words, mem, encproj_d, encproj_p, qd, qp, attw_p, rnn_d, rnn_p, gru_save, hprev_d, lstm_save, c_all, hp_all,
       hpprev, lse, pool_arg, pool_hid, unfinished, saved_total;
   // fwd scratch
-  long skws, skws_p, gi_d, gh_d, gates_p, ml, h0, scratch_fwd;
+  long skws, skws_p, gi_d, gh_d, gates_p, ml, h0, pd_cnt, scratch_fwd;
   // bwd scratch
   long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a,
@@ -172,6 +173,7 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   L.skws_p = f.take(acvae_skinny_ws_floats());
   L.gi_d = f.take(R * 3 * H); L.gh_d = f.take((long)N * 3 * H); L.gates_p = f.take(R * 4 * Hp);
   L.ml = f.take((long)N * 2 * E); L.h0 = f.take((long)N * (H > Hp ? H : Hp));
+  L.pd_cnt = f.take(acvae::decode_persist_counter_words(Tc));      // arrival counters of the persistent decode loop
   L.scratch_fwd = f.off;
   Bump b;
   b.take(acvae_skinny_ws_floats());            // skinny split-K workspaces first (L.skws, L.skws_p)
@@ -546,6 +548,24 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
       ACVAE_TRY(fork.join());
       ACVAE_TRY(dec_pre(0, Tc));
       for (int t = 0; t < Tc; ++t) ACVAE_TRY(dec_step(t));
+    } else if (acvae::decode_persist_ok(N, Tc, S, E, H, A) && H == E) {
+      // independent chains, all words known: the Tc steps of both chains as ONE persistent launch (decode_persist.hip);
+      // the hoisted halves are computed as before (the prior's on the second stream), then the streams join
+      ACVAE_TRY(dec_pre(0, Tc));
+      ACVAE_TRY(acvae::copy_rows(rnn_p + 2 * E, ld3E, nullptr, 0, N, E, sp));  // last_z = 0 at step 0
+      ACVAE_TRY(fork.join());
+      PdParams pd{};
+      pd.w_att = P(TP_DEC_ATT_W); pd.w_hh = P(TP_DEC_WHH); pd.b_hh = P(TP_DEC_BHH); pd.w_ih = P(TP_DEC_WIH);
+      pd.att_v = P(TP_DEC_ATT_V);
+      pd.pw_ih = P(TP_P_WIH); pd.pw_hh = P(TP_P_WHH); pd.pb_hh = P(TP_P_BHH); pd.w_ml = P(TP_P_ML_W); pd.b_ml = P(TP_P_ML_B);
+      pd.encproj = encproj_d; pd.mem = mem; pd.mem_lens = mem_lens; pd.gi = gi_d; pd.gates_p = gates_p;
+      pd.eps_p = eps_p; pd.zeros = zeros;
+      pd.qd = qd; pd.gh = gh_d; pd.rnn_d = rnn_d; pd.attn_w = attn_w; pd.outputs = outputs; pd.gru_save = sv + L.gru_save;
+      pd.hprev_d = sv + L.hprev_d; pd.rnn_p = rnn_p; pd.hp_all = sv + L.hp_all; pd.c_all = sv + L.c_all;
+      pd.lstm_save = sv + L.lstm_save; pd.p_means = p_means; pd.p_logs = p_logs; pd.p_z = p_z;
+      pd.cnt = (unsigned*)(sc + L.pd_cnt);
+      pd.N = N; pd.Tc = Tc; pd.S = S; pd.E = E; pd.H = H; pd.A = A;
+      ACVAE_TRY(acvae::decode_persist_fwd(pd, st.s));
     } else {                              // independent chains: feed both queues step by step
       ACVAE_TRY(dec_pre(0, Tc));
       for (int t = 0; t < Tc; ++t) {

@@ -306,6 +306,13 @@ int acvae_posterior_bwd(const void* const* params, void* const* grads, const int
                         const float* d_q_means_utt, void* saved, int64_t saved_bytes, void* scratch,
                         int64_t scratch_bytes, int N, int Tc, int E, int Hq, int V, void* stream);
 
+/* The teacher-forced decode loop (all words known, no step feeds the prior's z to the decoder: acvae_decode_fwd with every
+ * ss flag set and every dis flag clear) runs as ONE persistent launch (csrc/decode_persist.hip) when N <= 32, S <= 512,
+ * E is a power of two in 32..2048 and H, A are multiples of 32; its results are bit-identical to the per-step path.
+ * on = 0 forces the per-step path (A/B, parity tests), 1 re-enables it; returns the previous setting (-1: the
+ * environment's ACVAE_DECODE_PERSIST had not been consulted yet).  Replaces nothing in the reference (scheduling only). */
+int acvae_set_decode_persist(int on);
+
 /* A4+A5+A6+A7 (+A12 when caps == NULL): the step-by-step decode of Hybrid_VAEModel
  * models/vae_model.py:700-730,792-869 with PriorRNN (text_encoder.py:247-268),
  * VAERNNBahdanauAttnDecoder (decoder.py:175-203) and greedy sample_next_word (word_model.py:173-207).

@@ -38,6 +38,26 @@ VARIANTS["stamps"] = [
      "                    lane, n, ty0, bm, bn);\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    o[0] = (float)(lab_t1 - lab_t0); o[1] = (float)(lab_t2 - lab_t1); o[2] = (float)(clock64() - lab_t2); o[3] = (float)nchunk;\n  }\n}\n\n// ACT: the operand"),
 ]
+# in-kernel clock: s_memtime (shader cycles) against s_memrealtime (100 MHz) around the main loop -> [workgroup][wave][4] =
+# cycles, 100-MHz ticks, chunks, 0 (MI355X_MICROARCH.md, DVFS give-back (6))
+VARIANTS["clock"] = [
+    (PRE_LOOP, "  const long long lab_c0 = clock64(), lab_r0 = wall_clock64();\n" + PRE_LOOP),
+    ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
+     "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n  float* exb"),
+    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+     "    o[0] = (float)(lab_c1 - lab_c0); o[1] = (float)(lab_r1 - lab_r0); o[2] = (float)nchunk; o[3] = 0.f;\n  }\n}\n\n// ACT: the operand"),
+]
+# workgroup timeline: [workgroup][wave][4] = start, end (100-MHz wall clock, low 24 bits as float), CU key (XCC id << 8 | HW_ID[15:8]), 0
+VARIANTS["timeline"] = [
+    ("      out[0] = o0;\n      out[p.Cout] = o1;\n", "      asm volatile(\"\" :: \"v\"(out), \"v\"(o0), \"v\"(o1));\n"),     # no output stores: the stamps go into Y
+    ("  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+     "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
+     "    o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = 0.f;\n  }\n}\n\n// ACT: the operand"),
+]
 VARIANTS["mfmaonly"] = VARIANTS["nodma"] + [("    if (sub == 0) put_raw_part(rnxt, 0);\n", ""), ("    if (sub == 0) put_raw_part(rnxt, 2);\n", ""),
                                          ("    if (sub == 0) issue_raw(st2);", "    (void)st2;"),
                                          ("    if (sub == 0) read_scsh(st1);\n", "    (void)st1;\n")] + VARIANTS["nod"]
@@ -83,11 +103,41 @@ def time_one():
         fns = {"fwd_act": lambda: _lib.call("acvae_conv3x3_fwd_wino", x, w, sc, sh, y, gamma, beta, rm, rv, nbt, 1, bn, ws, wsb, N, H, W, Cin, Cout, S()),
                "dgrad": lambda: _lib.call("acvae_conv3x3_dgrad_wino", dyt, w, dx, ws, wsb, N, H, W, Cin, Cout, S()),
                "wgrad": lambda: _lib.call("acvae_conv3x3_wgrad_wino", dyt, x, sc, sh, dw, ws, wsb, N, H, W, Cin, Cout, S())}
+        if os.environ.get("ACVAE_DEV_LIB", "").endswith("_timeline.so"):
+          for warm in (5, 400):
+            for _ in range(warm):
+                fns["dgrad"]()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fns["dgrad"](); b.record(); torch.cuda.synchronize()
+            nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
+            t = dx.reshape(-1)[:nwg * 32].reshape(nwg, 8, 4)[:, 0, :].double().cpu()
+            t0 = float(t[:, 0].min())
+            st, en, cu = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01, t[:, 2].long()          # microseconds
+            cus = sorted(set(cu.tolist()))
+            per = {c: sorted((float(st[i]), float(en[i])) for i in range(nwg) if int(cu[i]) == c) for c in cus}
+            counts = [len(v) for v in per.values()]
+            gaps = [b0 - a1 for v in per.values() for (a0, a1), (b0, b1) in zip(v, v[1:])]
+            durs = [e - s_ for v in per.values() for s_, e in v]
+            print(f"{Cin}->{Cout}@{W} dgrad: call {a.elapsed_time(b) * 1e3:.0f} us; {nwg} workgroups on {len(cus)} CUs ({min(counts)}..{max(counts)} per CU); "
+                  f"workgroup {sum(durs) / len(durs):.1f} us (max {max(durs):.1f}); gap between two on one CU {sum(gaps) / max(1, len(gaps)):.2f} us (max {max(gaps or [0]):.1f}); "
+                  f"last end {float(en.max()):.1f} us; main loop {float(t[:, 3].floor().mean()) * 0.01:.1f} us real per workgroup [after {warm} warm-up launches]")
+          continue
+        if os.environ.get("ACVAE_DEV_LIB", "").endswith("_clock.so"):
+            for _ in range(300):                      # the clock settles after a second or two of back-to-back launches
+                fns["dgrad"]()
+            torch.cuda.synchronize()
+            nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
+            t = dx.reshape(-1)[:nwg * 32].reshape(nwg, 8, 4).double()
+            cyc, real = t[:, :, 0].mean(), t[:, :, 1].mean()
+            print(f"{Cin}->{Cout}@{W} dgrad: main loop {float(cyc):.0f} shader cycles in {float(real) * 10:.0f} ns -> in-kernel clock "
+                  f"{float(cyc / real) * 0.1:.3f} GHz; {float(cyc / t[0, 0, 2]):.0f} cycles per chunk (4096 = MFMA-bound)")
+            continue
         if os.environ.get("ACVAE_DEV_LIB", "").endswith("_stamps.so"):
             for k in ("fwd_act", "dgrad"):
                 fns[k](); torch.cuda.synchronize()
                 buf = (y if k == "fwd_act" else dx).reshape(-1)
-                nwg = N * ((H + 1) // 2 + (128 // W) - 1) // (128 // W) * ((Cin if k == "dgrad" else Cout) // 64)
+                nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * ((Cin if k == "dgrad" else Cout) // 64)
                 t = buf[:nwg * 32].reshape(nwg, 8, 4).double()
                 m = t.mean(dim=(0,))
                 print(f"{Cin}->{Cout}@{W} {k}: WGs {nwg} chunks {int(t[0,0,3])}; per wave (prologue, main, epilogue) cycles/100MHz-ticks: "
