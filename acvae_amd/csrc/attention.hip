@@ -39,11 +39,11 @@ __global__ __launch_bounds__(ATT_THREADS_BIG) void attn_fwd_kernel(
         const float4 pv = *reinterpret_cast<const float4*>(p + a);
         const float4 qv = *reinterpret_cast<const float4*>(q + a);
         const float4 vv = *reinterpret_cast<const float4*>(v + a);
-        acc += vv.x * tanhf(qv.x + pv.x) + vv.y * tanhf(qv.y + pv.y) + vv.z * tanhf(qv.z + pv.z) +
-               vv.w * tanhf(qv.w + pv.w);
+        acc += vv.x * tanh_att(qv.x + pv.x) + vv.y * tanh_att(qv.y + pv.y) + vv.z * tanh_att(qv.z + pv.z) +
+               vv.w * tanh_att(qv.w + pv.w);
       }
     } else {
-      for (int a = lane; a < A; a += 64) acc += v[a] * tanhf(q[a] + p[a]);
+      for (int a = lane; a < A; a += 64) acc += v[a] * tanh_att(q[a] + p[a]);
     }
     acc = wave_sum(acc);
     if (lane == 0) sc[s] = (s < len) ? acc : -1e10f;  // masked_fill(mask == 0, -1e10)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_accum_kernel(
         float dqa = 0.f;
 #pragma unroll
         for (int c = 0; c < ATB_CH; ++c) {
-          const float th = tanhf(qa + pt[c][k]);
+          const float th = tanh_att(qa + pt[c][k]);
           const float g = sds[c];
           const float du = g * va[k] * (1.f - th * th);
           dPa[c][k] += du;

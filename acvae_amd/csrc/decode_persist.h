@@ -25,6 +25,7 @@ struct PdParams {
   unsigned* abort_word;            // set by the launcher (last counter word)
   int N, Tc, S, E, H, A;
   int n_d1, n_d3, n_p1, n_p2;      // set by the launcher
+  int att_resident;                // set by the launcher: the attention keeps its clip's memory on the CU
 };
 
 namespace acvae {

@@ -42,11 +42,13 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 __device__ __forceinline__ float ld_sc1(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), PD_RLX_AGENT));
 }
-__device__ __forceinline__ float4 ld_sc1_4(const float* p) {       // 16-byte aligned; two 8-byte write-through-coherent loads
-  const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), PD_RLX_AGENT);
-  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, PD_RLX_AGENT);
-  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
-                     __uint_as_float((unsigned)(b >> 32)));
+// 16 bytes of handed-off data: buffer_load_dwordx4 ... sc1 (bypasses this CU's L1, like the atomic loads; one instruction
+// instead of two 8-byte ones).  base: a wave-uniform pointer (kernel argument), idx: the lane's float index from it (< 2^29).
+typedef unsigned pd_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_sc1_4(const float* base, long idx) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+  const pd_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, 16 /* sc1 */);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
 // Lane 0 waits until *cnt >= target (relaxed polls, s_sleep between them), then the workgroup's barrier.  Returns false
@@ -76,24 +78,37 @@ __device__ __forceinline__ void pd_arrive(unsigned* cnt) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, PD_RLX_AGENT);
 }
 
-// acc += A[32 rows][K] . B[32 rows][K]^T for this wave's share of the K-groups: exactly sk_accumulate<true> (mfma_tile.h)
-// with per-lane row pointers (ap / bp point at the lane's row, + 4 * (lane >> 5)); HANDED: A was written inside this
-// launch (coherent loads), otherwise plain float4 loads.
-template <bool HANDED>
-__device__ __forceinline__ void pd_accumulate(f32x16& acc, const float* ap, const float* bp, int K, int wave) {
-  constexpr int U = 8;
+// acc += A[32 rows][K] . B[32 rows][K]^T for this wave's share of the K-groups: the arithmetic of sk_accumulate<true>
+// (mfma_tile.h: groups wave, wave + 8, .. in rising order, four MFMAs per group) with per-lane row pointers (ap / bp point at
+// the lane's row, + 4 * (lane >> 5)).  A round trip to handed-off data costs 2-3 us (write-through stores drop the line from
+// the L2s: the load goes to the memory side), so the loads are split by what they depend on: the weight fragments of the
+// first PD_U groups are fetched BEFORE the role waits for its input (pd_fetch_b), the input fragments in ONE batch behind
+// the wait (hipcc, left alone, waits for the first two groups, starts the MFMAs and fetches the rest behind a second wait).
+constexpr int PD_U = 8;
+struct PdFrag { float4 b[PD_U]; };
+__device__ __forceinline__ void pd_fetch_b(PdFrag& f, const float* bp, int K, int wave) {
   const int Gfull = K / 8;
-  for (int g = wave; g < Gfull; g += U * SK_WAVES) {
-    float4 a[U], b[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+  for (int u = 0; u < PD_U; ++u) {
+    const int gu = wave + u * SK_WAVES;
+    f.b[u] = *reinterpret_cast<const float4*>(bp + ((gu < Gfull) ? (long)gu * 8 : 0));
+  }
+}
+template <bool HANDED>
+__device__ __forceinline__ void pd_accumulate(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave) {
+  const int Gfull = K / 8;
+  for (int g = wave; g < Gfull; g += PD_U * SK_WAVES) {
+    float4 a[PD_U], b[PD_U];
+#pragma unroll
+    for (int u = 0; u < PD_U; ++u) {
       const int gu = g + u * SK_WAVES;
       const long off = (gu < Gfull) ? (long)gu * 8 : 0;
       b[u] = *reinterpret_cast<const float4*>(bp + off);
-      a[u] = HANDED ? ld_sc1_4(ap + off) : *reinterpret_cast<const float4*>(ap + off);
+      a[u] = HANDED ? ld_sc1_4(abase, aidx + off) : *reinterpret_cast<const float4*>(abase + aidx + off);
     }
+    __builtin_amdgcn_sched_barrier(0);          // every load of the batch is in flight before the first MFMA waits
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < PD_U; ++u) {
       const bool ok = (g + u * SK_WAVES) < Gfull;
       const float4 av = ok ? a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[u].x, acc, 0, 0, 0);
@@ -101,6 +116,42 @@ __device__ __forceinline__ void pd_accumulate(f32x16& acc, const float* ap, cons
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[u].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[u].w, acc, 0, 0, 0);
     }
+  }
+}
+// K <= 512: a wave's whole share is ONE batch of PD_U groups; the two halves of pd_accumulate separately, so that a role can
+// issue the input loads of one product before it waits for the input of another (P1: hp before z)
+template <bool HANDED>
+__device__ __forceinline__ void pd_load_a(float4 (&a)[PD_U], const float* abase, long aidx, int K, int wave) {
+  const int Gfull = K / 8;
+#pragma unroll
+  for (int u = 0; u < PD_U; ++u) {
+    const int gu = wave + u * SK_WAVES;
+    const long off = (gu < Gfull) ? (long)gu * 8 : 0;
+    a[u] = HANDED ? ld_sc1_4(abase, aidx + off) : *reinterpret_cast<const float4*>(abase + aidx + off);
+  }
+}
+__device__ __forceinline__ void pd_mfma(f32x16& acc, const float4 (&a)[PD_U], const PdFrag& f, int K, int wave) {
+  const int Gfull = K / 8;
+#pragma unroll
+  for (int u = 0; u < PD_U; ++u) {
+    const bool ok = (wave + u * SK_WAVES) < Gfull;
+    const float4 av = ok ? a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, f.b[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, f.b[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, f.b[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, f.b[u].w, acc, 0, 0, 0);
+  }
+}
+// one product of a role: resident weight fragments when the wave's share is one batch, else the streaming loop
+template <bool HANDED>
+__device__ __forceinline__ void pd_product(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave, const PdFrag& f) {
+  if (K <= 64 * PD_U) {
+    float4 a[PD_U];
+    pd_load_a<HANDED>(a, abase, aidx, K, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    pd_mfma(acc, a, f, K, wave);
+  } else {
+    pd_accumulate<HANDED>(acc, abase, aidx, bp, K, wave);
   }
 }
 // the wave's accumulator tile into red[wave][row][col] (gemm_skinny_kernel's layout); sum over waves in order by the caller
@@ -121,6 +172,10 @@ struct PdSmem {
   int flag;
 };
 
+// What a role can fetch without its input - its weight fragments (for K <= 512 a wave's whole share: 8 groups = 32 registers,
+// fetched ONCE and kept for all Tc steps), biases, the hoisted projections of the step - is fetched before the role waits;
+// recurrent state of the cells (h, c) stays in the registers of the thread that owns the element.
+
 // ---------------------------------------------------------------- D1: qd = h . Watt[:, :H]^T;  gh = h . Whh^T + bhh
 __device__ void role_d1(const PdParams& p, int tile, PdSmem& sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
@@ -131,6 +186,9 @@ __device__ void role_d1(const PdParams& p, int tile, PdSmem& sm) {
   const long ldb = is_q ? (long)(p.E + p.H) : (long)p.H;
   const float* bp = B + (long)(n0 + li) * ldb + 4 * lh;
   const int arow = li < p.N ? li : 0;            // rows past N are never stored: they may read row 0
+  PdFrag fb;
+  pd_fetch_b(fb, bp, p.H, wave);
+  const float bias = is_q ? 0.f : p.b_hh[n0 + (threadIdx.x & 31)];      // both outputs of a thread share the column
   for (int t = 0; t < p.Tc; ++t) {
     if (t > 0 && !pd_wait(p.cnt + PD_C_D3 * p.Tc + (t - 1), (unsigned)p.n_d3, p.abort_word, &sm.flag)) return;
     const float* hprev = t ? p.outputs + (long)(t - 1) * p.H : p.zeros;
@@ -138,46 +196,82 @@ __device__ void role_d1(const PdParams& p, int tile, PdSmem& sm) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (t) pd_accumulate<true>(acc, hprev + arow * ldh + 4 * lh, bp, p.H, wave);
-    else pd_accumulate<false>(acc, hprev + arow * ldh + 4 * lh, bp, p.H, wave);
+    if (t) pd_product<true>(acc, hprev, arow * ldh + 4 * lh, bp, p.H, wave, fb);
+    else pd_product<false>(acc, hprev, arow * ldh + 4 * lh, bp, p.H, wave, fb);
     pd_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
     for (int e = threadIdx.x; e < 1024; e += PD_THREADS) {
       const int mm = e >> 5, nn = e & 31;
       if (mm < p.N) {
-        float v = pd_sum(sm.red, mm, nn);
+        const float v = pd_sum(sm.red, mm, nn);
         if (is_q) st_sc1(p.qd + (long)mm * p.Tc * p.A + (long)t * p.A + n0 + nn, v);
-        else st_sc1(p.gh + (long)mm * 3 * p.H + n0 + nn, v + p.b_hh[n0 + nn]);
+        else st_sc1(p.gh + (long)mm * 3 * p.H + n0 + nn, v + bias);
       }
     }
     pd_arrive(p.cnt + (is_q ? PD_C_D1Q : PD_C_D1H) * p.Tc + t);
   }
 }
 
-// ---------------------------------------------------------------- D2: attention of clip n (attn_fwd_kernel<true>, 8 context groups)
+// ---------------------------------------------------------------- D2: attention of clip n (attn_fwd_kernel<true> as launched for
+// one decode step: 1024 threads = GV context groups; here 512 threads play two groups each).  RES: the clip's projected
+// memory (S x A floats) stays in LDS and its memory rows in registers for all Tc steps - per step only the 2 KB query
+// crosses the chip; otherwise (long audio: S x A x 4 bytes beyond the LDS) both stream from L2 every step.
+template <bool RES>
 __device__ void role_d2(const PdParams& p, int n, float* smem, int* s_flag) {
   const int S = p.S, A = p.A, E = p.E;
   float* sc = smem;
   float* red = smem + S;
   float* part = smem + ((S + 16 + 3) & ~3);
+  float* Pl = part + 4096;                                  // RES: [S][A]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* P = p.encproj + (long)n * S * A;
+  const float* Pg = p.encproj + (long)n * S * A;
   const float* Hn = p.mem + (long)n * S * E;
   const float* v = p.att_v;
   const int len = (int)p.mem_lens[n];
+  const int ev = E >> 2, GR = PD_THREADS / ev;          // real context groups (E = 512: 4)
+  const int g0 = threadIdx.x / ev, e4 = (threadIdx.x - g0 * ev) * 4;
+  const int GV = 1024 / ev;                             // groups of the 1024-thread per-step launch (E = 512: 8) = 2 GR
+  float4 hm[2][8];                                      // RES: memory rows of this thread's two groups, frames g, g + GV, ..
+  if (RES) {
+    for (int i = threadIdx.x * 4; i < S * A; i += PD_THREADS * 4)
+      *reinterpret_cast<float4*>(Pl + i) = *reinterpret_cast<const float4*>(Pg + i);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s0 = g0 + k2 * GR + k * GV;
+        hm[k2][k] = (g0 < GR && s0 < S) ? *reinterpret_cast<const float4*>(Hn + (long)s0 * E + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    __syncthreads();
+  }
+  const float* P = RES ? Pl : Pg;
+  // a lane's share of A: elements lane * 4 + 256 i (A <= 2048); v once, the step's query once per step (ONE round trip)
+  float4 vv[8], qv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int a = lane * 4 + 256 * i;
+    vv[i] = a < A ? *reinterpret_cast<const float4*>(v + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int t = 0; t < p.Tc; ++t) {
     if (!pd_wait(p.cnt + PD_C_D1Q * p.Tc + t, (unsigned)(A / 32), p.abort_word, s_flag)) return;
-    const float* q = p.qd + (long)n * p.Tc * A + (long)t * A;
+    const long qi = (long)n * p.Tc * A + (long)t * A;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int a = lane * 4 + 256 * i;
+      qv[i] = a < A ? ld_sc1_4(p.qd, qi + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // ---- scores: wave per frame, lanes over A
     for (int s = wave; s < S; s += SK_WAVES) {
       const float* pr = P + (long)s * A;
       float acc = 0.f;
-      for (int a = lane * 4; a < A; a += 256) {
-        const float4 pv = *reinterpret_cast<const float4*>(pr + a);
-        const float4 qv = ld_sc1_4(q + a);
-        const float4 vv = *reinterpret_cast<const float4*>(v + a);
-        acc += vv.x * tanhf(qv.x + pv.x) + vv.y * tanhf(qv.y + pv.y) + vv.z * tanhf(qv.z + pv.z) +
-               vv.w * tanhf(qv.w + pv.w);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int a = lane * 4 + 256 * i;
+        if (a < A) {
+          const float4 pv = *reinterpret_cast<const float4*>(pr + a);
+          acc += vv[i].x * tanh_att(qv[i].x + pv.x) + vv[i].y * tanh_att(qv[i].y + pv.y) + vv[i].z * tanh_att(qv[i].z + pv.z) +
+                 vv[i].w * tanh_att(qv[i].w + pv.w);
+        }
       }
       acc = wave_sum(acc);
       if (lane == 0) sc[s] = (s < len) ? acc : -1e10f;
@@ -203,18 +297,28 @@ __device__ void role_d2(const PdParams& p, int n, float* smem, int* s_flag) {
       wout[s] = w;
     }
     __syncthreads();
-    // ---- context: E/4 threads per memory row; the per-step kernel runs 1024 threads = 8 groups taking frames g, g+8, ..;
-    // here 4 thread groups play two of those each, so the partial sums and their order are the same
-    const int ev = E >> 2, GR = PD_THREADS / ev;          // real groups (E = 512: 4)
-    const int g0 = threadIdx.x / ev, e4 = (threadIdx.x - g0 * ev) * 4;
-    const int GV = 1024 / ev;                             // groups of the 1024-thread per-step launch (E = 512: 8)
+    // ---- context: group g takes frames g, g + GV, ..; partial sums meet in LDS in group order
     if (g0 < GR) {
-      for (int g = g0; g < GV; g += GR) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int g = g0 + k2 * GR;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = g; s0 < S; s0 += GV) {
-          const float4 h = *reinterpret_cast<const float4*>(Hn + (long)s0 * E + e4);
-          const float w = sc[s0];
-          acc.x += w * h.x; acc.y += w * h.y; acc.z += w * h.z; acc.w += w * h.w;
+        if (RES) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int s0 = g + k * GV;
+            if (s0 < S) {
+              const float4 h = hm[k2][k];
+              const float w = sc[s0];
+              acc.x += w * h.x; acc.y += w * h.y; acc.z += w * h.z; acc.w += w * h.w;
+            }
+          }
+        } else {
+          for (int s0 = g; s0 < S; s0 += GV) {
+            const float4 h = *reinterpret_cast<const float4*>(Hn + (long)s0 * E + e4);
+            const float w = sc[s0];
+            acc.x += w * h.x; acc.y += w * h.y; acc.z += w * h.z; acc.w += w * h.w;
+          }
         }
         *reinterpret_cast<float4*>(part + (long)g * E + e4) = acc;
       }
@@ -240,44 +344,58 @@ __device__ void role_d3(const PdParams& p, int slice, PdSmem& sm) {
   const float* bp1 = p.w_ih + (long)row1 * 3 * E + E + 4 * lh;
   const float* bp2 = p.w_ih + (long)row2 * 3 * E + E + 4 * lh;
   const int arow = li < p.N ? li : 0;
+  PdFrag fb1, fb2;
+  pd_fetch_b(fb1, bp1, E, wave);
+  pd_fetch_b(fb2, bp2, E, wave);
+  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, u = u0 + j;      // this thread's cell element (row, unit)
+  const bool mine = mm < p.N;
+  float h = 0.f;                                                          // h_{t-1}[mm][u]
   for (int t = 0; t < p.Tc; ++t) {
+    // off the critical path: the hoisted projection of this step, and gh (D1 finished it before the attention started)
+    float g_r = 0.f, g_z = 0.f, g_n = 0.f, b_r = 0.f, b_z = 0.f, ghn = 0.f;
+    if (mine) {
+      const float* gi = p.gi + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
+      g_r = gi[u]; g_z = gi[H + u]; g_n = gi[2 * H + u];
+    }
+    if (!pd_wait(p.cnt + PD_C_D1H * p.Tc + t, (unsigned)(3 * H / 32), p.abort_word, &sm.flag)) return;
+    if (mine) {
+      const float* gh = p.gh + (long)mm * 3 * H;
+      b_r = ld_sc1(gh + u); b_z = ld_sc1(gh + H + u); ghn = ld_sc1(gh + 2 * H + u);
+    }
     if (!pd_wait(p.cnt + PD_C_D2 * p.Tc + t, (unsigned)p.N, p.abort_word, &sm.flag)) return;
-    const float* ap = p.rnn_d + (long)arow * p.Tc * 3 * E + (long)t * 3 * E + E + 4 * lh;
-    f32x16 acc;
+    const long ai = (long)arow * p.Tc * 3 * E + (long)t * 3 * E + E + 4 * lh;
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    pd_accumulate<true>(acc, ap, bp1, E, wave);
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+    if (E <= 64 * PD_U) {                       // the context rows cross the chip ONCE and feed both tiles
+      float4 a[PD_U];
+      pd_load_a<true>(a, p.rnn_d, ai, E, wave);
+      __builtin_amdgcn_sched_barrier(0);
+      pd_mfma(acc, a, fb1, E, wave);
+      pd_mfma(acc2, a, fb2, E, wave);
+    } else {
+      pd_accumulate<true>(acc, p.rnn_d, ai, bp1, E, wave);
+      pd_accumulate<true>(acc2, p.rnn_d, ai, bp2, E, wave);
+    }
     pd_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
     for (int e = threadIdx.x; e < 1024; e += PD_THREADS) sm.keep[e >> 5][e & 31] = pd_sum(sm.red, e >> 5, e & 31);
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    pd_accumulate<true>(acc, ap, bp2, E, wave);
-    pd_stash(sm.red, acc, wave, li, lh);
-    // gh of this step has arrived long ago as a rule (D1 ran before the attention); the wait orders the loads below
-    if (!pd_wait(p.cnt + PD_C_D1H * p.Tc + t, (unsigned)(3 * H / 32), p.abort_word, &sm.flag)) return;   // includes the barrier
-    // cell: 32 rows x 16 units = one element per thread
-    {
-      const int mm = threadIdx.x >> 4, j = threadIdx.x & 15;
-      if (mm < p.N) {
-        const int u = u0 + j;
-        const float* gi = p.gi + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
-        const float* gh = p.gh + (long)mm * 3 * H;
-        const float a_r = sm.keep[mm][j] + gi[u];               // the per-step path: v = sum; v += *p (accumulate)
-        const float a_z = sm.keep[mm][16 + j] + gi[H + u];
-        const float a_n = pd_sum(sm.red, mm, j) + gi[2 * H + u];
-        const float b_r = ld_sc1(gh + u), b_z = ld_sc1(gh + H + u), ghn = ld_sc1(gh + 2 * H + u);
-        const float h = t ? ld_sc1(p.outputs + (long)mm * p.Tc * H + (long)(t - 1) * H + u) : 0.f;
-        const float r = sigmoidf_(a_r + b_r);
-        const float z = sigmoidf_(a_z + b_z);
-        const float nn = tanhf(a_n + r * ghn);
-        const float hn = (1.f - z) * nn + z * h;
-        p.hprev_d[(long)mm * p.Tc * H + (long)t * H + u] = h;
-        float* sv = p.gru_save + (long)mm * p.Tc * 4 * H + (long)t * 4 * H;
-        sv[u] = r; sv[H + u] = z; sv[2 * H + u] = nn; sv[3 * H + u] = ghn;
-        st_sc1(p.outputs + (long)mm * p.Tc * H + (long)t * H + u, hn);
-      }
+    pd_stash(sm.red, acc2, wave, li, lh);
+    __syncthreads();
+    if (mine) {
+      const float a_r = sm.keep[mm][j] + g_r;               // the per-step path: v = sum over waves; v += *p (accumulate)
+      const float a_z = sm.keep[mm][16 + j] + g_z;
+      const float a_n = pd_sum(sm.red, mm, j) + g_n;
+      const float r = sigmoidf_(a_r + b_r);
+      const float z = sigmoidf_(a_z + b_z);
+      const float nn = tanhf(a_n + r * ghn);
+      const float hn = (1.f - z) * nn + z * h;
+      p.hprev_d[(long)mm * p.Tc * H + (long)t * H + u] = h;
+      float* sv = p.gru_save + (long)mm * p.Tc * 4 * H + (long)t * 4 * H;
+      sv[u] = r; sv[H + u] = z; sv[2 * H + u] = nn; sv[3 * H + u] = ghn;
+      st_sc1(p.outputs + (long)mm * p.Tc * H + (long)t * H + u, hn);
+      h = hn;
     }
     pd_arrive(p.cnt + PD_C_D3 * p.Tc + t);
   }
@@ -291,45 +409,70 @@ __device__ void role_p1(const PdParams& p, int slice, PdSmem& sm) {
   const float* bz = p.pw_ih + (long)row * 3 * E + 2 * E + 4 * lh;
   const float* bh = p.pw_hh + (long)row * Hp + 4 * lh;
   const int arow = li < p.N ? li : 0;
+  PdFrag fbz, fbh;
+  pd_fetch_b(fbz, bz, E, wave);
+  pd_fetch_b(fbh, bh, Hp, wave);
+  const int mm = threadIdx.x >> 3, j = threadIdx.x & 7, u = u0 + j;      // cell element of threads 0..255
+  const bool mine = threadIdx.x < 256 && mm < p.N;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (mine)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bias[k] = p.pb_hh[k * Hp + u];
+  float c = 0.f;                                                          // c_{t-1}[mm][u]
   for (int t = 0; t < p.Tc; ++t) {
-    if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, &sm.flag)) return;
-    const float* az = p.rnn_p + (long)arow * p.Tc * 3 * E + (long)t * 3 * E + 2 * E + 4 * lh;
+    float gpre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mine) {
+      const float* g = p.gates_p + (long)mm * p.Tc * 4 * Hp + (long)t * 4 * Hp;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gpre[k] = g[k * Hp + u];
+    }
+    const long zi = (long)arow * p.Tc * 3 * E + (long)t * 3 * E + 2 * E + 4 * lh;
     const float* hprev = t ? p.hp_all + (long)(t - 1) * Hp : p.zeros;
     const long ldh = t ? (long)p.Tc * Hp : (long)Hp;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (t) {
-      pd_accumulate<true>(acc, az, bz, E, wave);
-      pd_accumulate<true>(acc, hprev + arow * ldh + 4 * lh, bh, Hp, wave);
+    if (E <= 64 * PD_U) {
+      // hp_{t-1} is complete long before z_{t-1} (P2 works from it): fetch it behind this role's own counter, then wait for z
+      float4 ah[PD_U], azv[PD_U];
+      if (t > 0 && !pd_wait(p.cnt + PD_C_P1 * p.Tc + (t - 1), (unsigned)p.n_p1, p.abort_word, &sm.flag)) return;
+      if (t) pd_load_a<true>(ah, hprev, arow * ldh + 4 * lh, Hp, wave);
+      else pd_load_a<false>(ah, hprev, arow * ldh + 4 * lh, Hp, wave);
+      if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, &sm.flag)) return;
+      if (t) pd_load_a<true>(azv, p.rnn_p, zi, E, wave);
+      else pd_load_a<false>(azv, p.rnn_p, zi, E, wave);
+      __builtin_amdgcn_sched_barrier(0);
+      pd_mfma(acc, azv, fbz, E, wave);             // the per-step path's order: the z product, then the hp product
+      pd_mfma(acc, ah, fbh, Hp, wave);
     } else {
-      pd_accumulate<false>(acc, az, bz, E, wave);
-      pd_accumulate<false>(acc, hprev + arow * ldh + 4 * lh, bh, Hp, wave);
+      if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, &sm.flag)) return;
+      if (t) {
+        pd_product<true>(acc, p.rnn_p, zi, bz, E, wave, fbz);
+        pd_product<true>(acc, hprev, arow * ldh + 4 * lh, bh, Hp, wave, fbh);
+      } else {
+        pd_product<false>(acc, p.rnn_p, zi, bz, E, wave, fbz);
+        pd_product<false>(acc, hprev, arow * ldh + 4 * lh, bh, Hp, wave, fbh);
+      }
     }
     pd_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
-    if (threadIdx.x < 256) {                                   // 32 rows x 8 units
-      const int mm = threadIdx.x >> 3, j = threadIdx.x & 7;
-      if (mm < p.N) {
-        const int u = u0 + j;
-        const float* g = p.gates_p + (long)mm * p.Tc * 4 * Hp + (long)t * 4 * Hp;
-        float gv[4];
+    if (mine) {
+      float gv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float v = pd_sum(sm.red, mm, k * 8 + j);
-          v += p.pb_hh[k * Hp + u];
-          v += g[k * Hp + u];
-          gv[k] = v;
-        }
-        const float ig = sigmoidf_(gv[0]), fg = sigmoidf_(gv[1]), gg = tanhf(gv[2]), og = sigmoidf_(gv[3]);
-        const float c = t ? ld_sc1(p.c_all + (long)mm * p.Tc * Hp + (long)(t - 1) * Hp + u) : 0.f;
-        const float c2 = fg * c + ig * gg;
-        const float tc = tanhf(c2);
-        st_sc1(p.hp_all + (long)mm * p.Tc * Hp + (long)t * Hp + u, og * tc);
-        st_sc1(p.c_all + (long)mm * p.Tc * Hp + (long)t * Hp + u, c2);
-        float* s = p.lstm_save + (long)mm * p.Tc * 5 * Hp + (long)t * 5 * Hp;
-        s[u] = ig; s[Hp + u] = fg; s[2 * Hp + u] = gg; s[3 * Hp + u] = og; s[4 * Hp + u] = tc;
+      for (int k = 0; k < 4; ++k) {
+        float v = pd_sum(sm.red, mm, k * 8 + j);
+        v += bias[k];
+        v += gpre[k];
+        gv[k] = v;
       }
+      const float ig = sigmoidf_(gv[0]), fg = sigmoidf_(gv[1]), gg = tanhf(gv[2]), og = sigmoidf_(gv[3]);
+      const float c2 = fg * c + ig * gg;
+      const float tc = tanhf(c2);
+      st_sc1(p.hp_all + (long)mm * p.Tc * Hp + (long)t * Hp + u, og * tc);
+      p.c_all[(long)mm * p.Tc * Hp + (long)t * Hp + u] = c2;
+      float* s = p.lstm_save + (long)mm * p.Tc * 5 * Hp + (long)t * 5 * Hp;
+      s[u] = ig; s[Hp + u] = fg; s[2 * Hp + u] = gg; s[3 * Hp + u] = og; s[4 * Hp + u] = tc;
+      c = c2;
     }
     pd_arrive(p.cnt + PD_C_P1 * p.Tc + t);
   }
@@ -342,25 +485,27 @@ __device__ void role_p2(const PdParams& p, int slice, PdSmem& sm) {
   const int row = li < 16 ? e0 + li : E + e0 + (li - 16);
   const float* bp = p.w_ml + (long)row * Hp + 4 * lh;
   const int arow = li < p.N ? li : 0;
+  PdFrag fb;
+  pd_fetch_b(fb, bp, Hp, wave);
+  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, e = e0 + j;
+  const bool mine = mm < p.N;
+  const float b_mu = p.b_ml[e], b_lv = p.b_ml[E + e];
   for (int t = 0; t < p.Tc; ++t) {
+    const float eps = mine ? p.eps_p[(long)t * p.N * E + (long)mm * E + e] : 0.f;
     if (!pd_wait(p.cnt + PD_C_P1 * p.Tc + t, (unsigned)p.n_p1, p.abort_word, &sm.flag)) return;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    pd_accumulate<true>(acc, p.hp_all + (long)arow * p.Tc * Hp + (long)t * Hp + 4 * lh, bp, Hp, wave);
+    pd_product<true>(acc, p.hp_all, (long)arow * p.Tc * Hp + (long)t * Hp + 4 * lh, bp, Hp, wave, fb);
     pd_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
-    {
-      const int mm = threadIdx.x >> 4, j = threadIdx.x & 15;
-      if (mm < p.N) {
-        const int e = e0 + j;
-        const float mu = pd_sum(sm.red, mm, j) + p.b_ml[e];
-        const float lv = pd_sum(sm.red, mm, 16 + j) + p.b_ml[E + e];
-        const float zz = p.eps_p[(long)t * p.N * E + (long)mm * E + e] * expf(.5f * lv) + mu;
-        const long o = (long)mm * p.Tc * E + (long)t * E + e;
-        p.p_means[o] = mu; p.p_logs[o] = lv; p.p_z[o] = zz;
-        if (t + 1 < p.Tc) st_sc1(p.rnn_p + (long)mm * p.Tc * 3 * E + (long)(t + 1) * 3 * E + 2 * E + e, zz);
-      }
+    if (mine) {
+      const float mu = pd_sum(sm.red, mm, j) + b_mu;
+      const float lv = pd_sum(sm.red, mm, 16 + j) + b_lv;
+      const float zz = eps * expf(.5f * lv) + mu;
+      const long o = (long)mm * p.Tc * E + (long)t * E + e;
+      p.p_means[o] = mu; p.p_logs[o] = lv; p.p_z[o] = zz;
+      if (t + 1 < p.Tc) st_sc1(p.rnn_p + (long)mm * p.Tc * 3 * E + (long)(t + 1) * 3 * E + 2 * E + e, zz);
     }
     pd_arrive(p.cnt + PD_C_P2 * p.Tc + t);
   }
@@ -372,7 +517,12 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persist_kernel(PdParams p) 
   int b = blockIdx.x;
   if (b < p.n_d1) { role_d1(p, b, sm); return; }
   b -= p.n_d1;
-  if (b < p.N) { role_d2(p, b, reinterpret_cast<float*>(pd_smem_raw) + 4, reinterpret_cast<int*>(pd_smem_raw)); return; }
+  if (b < p.N) {
+    float* sm2 = reinterpret_cast<float*>(pd_smem_raw) + 4;
+    int* fl = reinterpret_cast<int*>(pd_smem_raw);
+    if (p.att_resident) role_d2<true>(p, b, sm2, fl); else role_d2<false>(p, b, sm2, fl);
+    return;
+  }
   b -= p.N;
   if (b < p.n_d3) { role_d3(p, b, sm); return; }
   b -= p.n_d3;
@@ -406,9 +556,21 @@ int decode_persist_fwd(PdParams p, hipStream_t st) {
   if (hipMemsetAsync(p.cnt, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
   const int grid = p.n_d1 + p.N + p.n_d3 + p.n_p1 + p.n_p2;
   size_t shm = sizeof(PdSmem);
-  const size_t att = (size_t)(4 + ((p.S + 16 + 3) & ~3) + 4096) * sizeof(float);      // context partials: (1024 / (E/4)) x E
+  size_t att = (size_t)(4 + ((p.S + 16 + 3) & ~3) + 4096) * sizeof(float);      // context partials: (1024 / (E/4)) x E
+  // the clip's projected memory in LDS and its memory rows in registers (8 frames for each of a thread's 2 context groups)
+  const int GV = 1024 / (p.E / 4);
+  p.att_resident = (p.S <= 8 * GV && att + (size_t)p.S * p.A * sizeof(float) <= 150 * 1024) ? 1 : 0;
+  if (p.att_resident) att += (size_t)p.S * p.A * sizeof(float);
   if (att > shm) shm = att;
-  if (shm > 64 * 1024) return ACVAE_EUNSUPPORTED;
+  if (shm > 64 * 1024) {
+    static bool raised = false;               // more than 64 KB of dynamic LDS needs the attribute, once per process
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return (int)hipGetLastError();
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL(decode_persist_kernel, dim3(grid), dim3(PD_THREADS), shm, st, p);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
