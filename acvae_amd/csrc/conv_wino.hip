@@ -258,14 +258,18 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p.X + goff[j] + st * 16);
   };
   // ACT: scale / shift of all C input channels sit in LDS (scsh: [C/4] scale quads, then [C/4] shift quads) - a
-  // global load inside a filler slot would wait out its whole latency there
-  if (ACT) {
-    for (int i = tid; i < (C >> 2); i += WN_THREADS) {
-      scsh[i] = *reinterpret_cast<const float4*>(p.scale + 4 * i);
-      scsh[(C >> 2) + i] = *reinterpret_cast<const float4*>(p.shift + 4 * i);
+  // global load inside a filler slot would wait out its whole latency there.  Staged in the prologue BEHIND the first
+  // window loads and the first weight DMA, so that the three latencies run side by side (staged in front of them, every
+  // workgroup paid one more global round trip: 8000 workgroups of eight chunks on the 64-channel layer).
+  auto stage_scsh = [&]() {
+    if (ACT) {
+      for (int i = tid; i < (C >> 2); i += WN_THREADS) {
+        scsh[i] = *reinterpret_cast<const float4*>(p.scale + 4 * i);
+        scsh[(C >> 2) + i] = *reinterpret_cast<const float4*>(p.shift + 4 * i);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-  }
+  };
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   auto read_scsh = [&](int st) {
     if (ACT) {
@@ -364,6 +368,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 
   issue_raw(0);
   fetch_b(0, bw0);
+  stage_scsh();
   read_scsh(0);
   put_raw(raw0);
   issue_raw(nstage > 1 ? 1 : 0);
