@@ -28,7 +28,30 @@ struct PdParams {
   int att_resident;                // set by the launcher: the attention keeps its clip's memory on the CU
 };
 
+enum { PB_C_RA, PB_C_RB, PB_C_RC, PB_C_PA, PB_C_PB, PB_C_COUNT };
+
+// backward through time of the same loop (acvae_decode_bwd)
+struct PbParams {
+  // transposed weights (acvae_decode_bwd's scratch): [H][3H], [H+E][A], [3E][3H], [Hp][4Hp], [3E][4Hp], [Hp][2E]
+  const float *wt_dhh, *wt_datt, *wt_dih, *wt_phh, *wt_pih, *wt_pml;
+  const float* att_v;
+  // saved by the forward
+  const float *encproj, *mem, *qd, *attn_w, *gru_save, *hprev_d, *lstm_save, *c_all, *p_logs, *eps_p;
+  const int64_t* mem_lens;
+  // upstream gradients ([N, Tc, .]; the three of the prior may be NULL)
+  const float *d_out, *d_p_z, *d_p_means, *d_p_logs;
+  // written by the launch (dctx: [N, Tc, E], one slot per step)
+  float *dgi, *dgh, *dqd, *dctx, *dencproj, *dmem, *dvpart, *dgates, *dml_all, *dhp;
+  unsigned* cnt;
+  unsigned* abort_word;
+  int N, Tc, S, E, H, A;
+  int n_ra, n_rb, n_pa, n_pb;
+};
+
 namespace acvae {
+bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A);
+long decode_persist_bwd_counter_words(int Tc);
+int decode_persist_bwd(PbParams p, hipStream_t st);
 bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A);
 long decode_persist_counter_words(int Tc);
 int decode_persist_fwd(PdParams p, hipStream_t st);

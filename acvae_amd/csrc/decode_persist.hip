@@ -531,6 +531,319 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persist_kernel(PdParams p) 
   role_p2(p, b, sm);
 }
 
+
+// =====================================================================================================================
+// Backward through time of the same loop (acvae_decode_bwd's dec_bptt / prior_bptt, decoder.hip) as ONE persistent launch.
+// 512 threads per workgroup (the K range of a product is dealt over 8 wavefronts; 1024 threads leave 128 registers per
+// thread and the attention role spills); roles, t = Tc-1 .. 0:
+//
+//   decoder chain                                                     prior chain
+//   RA [H/16]  dh = dh.z + dgh[t+1].Whh + dqd[t+1].Watt_q;            PA [E/16]  [dhp | dlz] = dgates[t+1].[Whh | Wih_z];
+//              GRU cell backward -> dgi[t], dgh[t]                               re-parameterisation backward -> dml[t]
+//   RB [E/16]  dctx = dgi[t].Wih_ctx                                  PB [Hp/16] dhp += dml[t].Wml; LSTM cell backward -> dgates[t]
+//   RC [N]     attention backward of clip n: dqd[t], running sums
+//              of d encproj / d memory / dv in registers
+//
+// The dgh product of RA (three quarters of its K) does not depend on the attention: it runs while RB and RC work on the
+// step.  Same hand-off protocol as the forward launch.  Products are summed over 8 wave shares (one pass) instead of the per-step
+// path's split-K slabs and the attention sums its frames in one sweep, so results agree with that path to rounding (not
+// bit for bit); the parity test bounds the difference.
+constexpr int PB_THREADS = 512, PB_WAVES = 8;
+
+struct PbSmem {
+  float red[PB_WAVES][32][33];
+  int flag;
+};
+__device__ __forceinline__ void pb_stash(float (*red)[32][33], const f32x16& acc, int wave, int li, int lh) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+}
+__device__ __forceinline__ float pb_sum(float (*red)[32][33], int mm, int nn) {
+  float v = 0.f;
+#pragma unroll
+  for (int w = 0; w < PB_WAVES; ++w) v += red[w][mm][nn];
+  return v;
+}
+// acc += A[32 rows][K] . B[32 rows][K]^T, this wave's K-groups (wave, wave + 16, ..) in batches of eight; A handed off
+// inside the launch (coherent 16-byte loads), B = weights (plain loads)
+__device__ __forceinline__ void pb_gemm(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave) {
+  const int G = K / 8;
+  for (int g = wave; g < G; g += 8 * PB_WAVES) {
+    float4 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gu = g + u * PB_WAVES;
+      const long off = (gu < G) ? (long)gu * 8 : 0;
+      b[u] = *reinterpret_cast<const float4*>(bp + off);
+      a[u] = ld_sc1_4(abase, aidx + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = (g + u * PB_WAVES) < G;
+      const float4 av = ok ? a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- RA: dh_{t} for 16 units, GRU cell backward (rnn.hip gru_bwd_kernel)
+__device__ void role_ra(const PbParams& p, int slice, PbSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int H = p.H, A = p.A, u0 = slice * 16;
+  const int brow = li < 16 ? u0 + li : 0;                       // 16 of the tile's 32 columns are used
+  const float* b_hh = p.wt_dhh + (long)brow * 3 * H + 4 * lh;   // [H][3H]
+  const float* b_att = p.wt_datt + (long)brow * A + 4 * lh;     // [H + E][A], rows 0..H = query half
+  const int arow = li < p.N ? li : 0;
+  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, u = u0 + j;
+  const bool mine = mm < p.N;
+  float carry = 0.f;                                            // dh.z of the step before
+  for (int t = p.Tc - 1; t >= 0; --t) {
+    float v = 0.f;
+    // this step's cell inputs do not depend on the launch
+    float dout = 0.f, r = 0.f, z = 0.f, nn = 0.f, ghn = 0.f, hp = 0.f;
+    if (mine) {
+      dout = p.d_out[(long)mm * p.Tc * H + (long)t * H + u];
+      const float* sv = p.gru_save + (long)mm * p.Tc * 4 * H + (long)t * 4 * H;
+      r = sv[u]; z = sv[H + u]; nn = sv[2 * H + u]; ghn = sv[3 * H + u];
+      hp = p.hprev_d[(long)mm * p.Tc * H + (long)t * H + u];
+    }
+    if (t < p.Tc - 1) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      if (!pd_wait(p.cnt + PB_C_RA * p.Tc + (t + 1), (unsigned)p.n_ra, p.abort_word, &sm.flag)) return;
+      pb_gemm(acc, p.dgh, (long)arow * p.Tc * 3 * H + (long)(t + 1) * 3 * H + 4 * lh, b_hh, 3 * H, wave);
+      if (!pd_wait(p.cnt + PB_C_RC * p.Tc + (t + 1), (unsigned)p.N, p.abort_word, &sm.flag)) return;
+      pb_gemm(acc, p.dqd, (long)arow * p.Tc * A + (long)(t + 1) * A + 4 * lh, b_att, A, wave);
+      pb_stash(sm.red, acc, wave, li, lh);
+      __syncthreads();
+      if (mine) v = pb_sum(sm.red, mm, j);
+    }
+    if (mine) {
+      float dh = v + carry;
+      dh += dout;
+      const float dn = dh * (1.f - z);
+      const float dz = dh * (hp - nn);
+      const float dnp = dn * (1.f - nn * nn);
+      const float drp = dnp * ghn * r * (1.f - r);
+      const float dzp = dz * z * (1.f - z);
+      float* a = p.dgi + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
+      float* b = p.dgh + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
+      st_sc1(a + u, drp); st_sc1(a + H + u, dzp); st_sc1(a + 2 * H + u, dnp);
+      st_sc1(b + u, drp); st_sc1(b + H + u, dzp); st_sc1(b + 2 * H + u, dnp * r);
+      carry = dh * z;
+    }
+    pd_arrive(p.cnt + PB_C_RA * p.Tc + t);
+  }
+}
+
+// ---------------------------------------------------------------- RB: dctx = dgi[t] . Wih[:, E:2E] for 16 context columns
+__device__ void role_rb(const PbParams& p, int slice, PbSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int H = p.H, E = p.E, e0 = slice * 16;
+  const float* bp = p.wt_dih + (long)(E + (li < 16 ? e0 + li : 0)) * 3 * H + 4 * lh;       // [3E][3H]
+  const int arow = li < p.N ? li : 0;
+  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15;
+  const bool mine = mm < p.N;
+  for (int t = p.Tc - 1; t >= 0; --t) {
+    if (!pd_wait(p.cnt + PB_C_RA * p.Tc + t, (unsigned)p.n_ra, p.abort_word, &sm.flag)) return;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    pb_gemm(acc, p.dgi, (long)arow * p.Tc * 3 * H + (long)t * 3 * H + 4 * lh, bp, 3 * H, wave);
+    pb_stash(sm.red, acc, wave, li, lh);
+    __syncthreads();
+    if (mine) st_sc1(p.dctx + (long)mm * p.Tc * E + (long)t * E + e0 + j, pb_sum(sm.red, mm, j));
+    pd_arrive(p.cnt + PB_C_RB * p.Tc + t);
+  }
+}
+
+// ---------------------------------------------------------------- RC: attention backward of clip n (attention.hip: score / accum / reduce)
+// thread = channel a (A, E <= 512): the clip's projected memory in LDS, its memory rows and the running sums of d encproj for
+// all S <= 64 frames in registers.  The memory's own gradient, sum_t w[t][s] dctx[t][e], needs no recurrence: dctx is kept
+// per step and attn_dmem_kernel forms it behind the launch.
+__device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
+  const int S = p.S, A = p.A, E = p.E;
+  float* w_s = smem;                  // [64]
+  float* ds_s = smem + 64;            // [64]
+  float* dwred = smem + 128;          // [8][64]
+  float* Pl = smem + 128 + 512;       // [S][A]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int a = threadIdx.x;
+  const int len = (int)p.mem_lens[n];
+  for (int i = threadIdx.x * 4; i < S * A; i += PB_THREADS * 4)
+    *reinterpret_cast<float4*>(Pl + i) = *reinterpret_cast<const float4*>(p.encproj + (long)n * S * A + i);
+  float m[64], dPa[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    m[k] = (k < S && a < E) ? p.mem[((long)n * S + k) * E + a] : 0.f;
+    dPa[k] = 0.f;
+  }
+  const float va = a < A ? p.att_v[a] : 0.f;
+  float dva = 0.f;
+  __syncthreads();
+  for (int t = p.Tc - 1; t >= 0; --t) {
+    const float qa = a < A ? p.qd[(long)n * p.Tc * A + (long)t * A + a] : 0.f;
+    if (threadIdx.x < S) w_s[threadIdx.x] = p.attn_w[(long)n * p.Tc * S + (long)t * S + threadIdx.x];
+    if (!pd_wait(p.cnt + PB_C_RB * p.Tc + t, (unsigned)p.n_rb, p.abort_word, s_flag)) return;
+    const float dc = a < E ? ld_sc1(p.dctx + (long)n * p.Tc * E + (long)t * E + a) : 0.f;
+    // dw[s] = dctx . mem[s]: per wave partial sums
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      if (k < S) {
+        const float part = wave_sum(dc * m[k]);
+        if (lane == 0) dwred[wave * 64 + k] = part;
+      }
+    }
+    __syncthreads();
+    // dscore[s] = w[s] (dw[s] - sum_j w[j] dw[j]), 0 behind the clip's last frame: one wave
+    if (wave == 0) {
+      const int s = lane;
+      float dw = 0.f, w = 0.f;
+      if (s < S) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dw += dwred[q * 64 + s];
+        w = w_s[s];
+      }
+      const float dot = wave_sum(w * dw);
+      if (s < S) ds_s[s] = (s < len) ? w * (dw - dot) : 0.f;
+    }
+    __syncthreads();
+    float dq = 0.f;
+    if (a < A) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        if (k < S) {
+          const float g = ds_s[k];
+          const float th = tanh_att(qa + Pl[(long)k * A + a]);
+          const float du = g * va * (1.f - th * th);
+          dPa[k] += du;
+          dq += du;
+          dva += g * th;
+        }
+      }
+      st_sc1(p.dqd + (long)n * p.Tc * A + (long)t * A + a, dq);
+    }
+    pd_arrive(p.cnt + PB_C_RC * p.Tc + t);          // (its barrier also protects w_s / ds_s / dwred against the next step's writes)
+  }
+  if (a < A) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+      if (k < S) p.dencproj[((long)n * S + k) * A + a] = dPa[k];
+    p.dvpart[(long)n * A + a] = dva;
+  }
+}
+
+// ---------------------------------------------------------------- PA: [dhp | dlz] for 16 units, re-parameterisation backward
+__device__ void role_pa(const PbParams& p, int slice, PbSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int E = p.E, Hp = p.E, u0 = slice * 16;
+  // tile columns 0..15: dhp of units u0.. (rows of Whh^T), 16..31: d last_z of the same indices (rows 2E.. of Wih^T)
+  const float* bp = (li < 16 ? p.wt_phh + (long)(u0 + li) * 4 * Hp : p.wt_pih + (long)(2 * E + u0 + li - 16) * 4 * Hp) + 4 * lh;
+  const int arow = li < p.N ? li : 0;
+  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, e = u0 + j;
+  const bool mine = mm < p.N;
+  for (int t = p.Tc - 1; t >= 0; --t) {
+    const long o = (long)mm * p.Tc * E + (long)t * E + e;
+    float dpz = 0.f, dme = 0.f, dle = 0.f, lv = 0.f, eps = 0.f;
+    if (mine) {
+      if (p.d_p_z) dpz = p.d_p_z[o];
+      if (p.d_p_means) dme = p.d_p_means[o];
+      if (p.d_p_logs) dle = p.d_p_logs[o];
+      lv = p.p_logs[o];
+      eps = p.eps_p[(long)t * p.N * E + (long)mm * E + e];
+    }
+    float vhp = 0.f, vlz = 0.f;
+    if (t < p.Tc - 1) {
+      if (!pd_wait(p.cnt + PB_C_PB * p.Tc + (t + 1), (unsigned)p.n_pb, p.abort_word, &sm.flag)) return;
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      pb_gemm(acc, p.dgates, (long)arow * p.Tc * 4 * Hp + (long)(t + 1) * 4 * Hp + 4 * lh, bp, 4 * Hp, wave);
+      pb_stash(sm.red, acc, wave, li, lh);
+      __syncthreads();
+      if (mine) { vhp = pb_sum(sm.red, mm, j); vlz = pb_sum(sm.red, mm, 16 + j); }
+    }
+    if (mine) {
+      const float g = vlz + dpz;                                        // d z_t
+      float* dml = p.dml_all + (long)mm * p.Tc * 2 * E + (long)t * 2 * E;
+      st_sc1(dml + e, g + dme);
+      st_sc1(dml + E + e, g * eps * .5f * expf(.5f * lv) + dle);
+      st_sc1(p.dhp + (long)mm * Hp + e, vhp);
+    }
+    pd_arrive(p.cnt + PB_C_PA * p.Tc + t);
+  }
+}
+
+// ---------------------------------------------------------------- PB: dhp += dml[t] . Wml, LSTM cell backward (rnn.hip lstm_bwd_kernel)
+__device__ void role_pb(const PbParams& p, int slice, PbSmem& sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int E = p.E, Hp = p.E, u0 = slice * 16;
+  const float* bp = p.wt_pml + (long)(li < 16 ? u0 + li : 0) * 2 * E + 4 * lh;          // [Hp][2E]
+  const int arow = li < p.N ? li : 0;
+  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, u = u0 + j;
+  const bool mine = mm < p.N;
+  float dc_next = 0.f;
+  for (int t = p.Tc - 1; t >= 0; --t) {
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, tc = 0.f, c = 0.f;
+    if (mine) {
+      const float* s = p.lstm_save + (long)mm * p.Tc * 5 * Hp + (long)t * 5 * Hp;
+      ig = s[u]; fg = s[Hp + u]; gg = s[2 * Hp + u]; og = s[3 * Hp + u]; tc = s[4 * Hp + u];
+      c = t ? p.c_all[(long)mm * p.Tc * Hp + (long)(t - 1) * Hp + u] : 0.f;
+    }
+    if (!pd_wait(p.cnt + PB_C_PA * p.Tc + t, (unsigned)p.n_pa, p.abort_word, &sm.flag)) return;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    pb_gemm(acc, p.dml_all, (long)arow * p.Tc * 2 * E + (long)t * 2 * E + 4 * lh, bp, 2 * E, wave);
+    pb_stash(sm.red, acc, wave, li, lh);
+    __syncthreads();
+    if (mine) {
+      float d = pb_sum(sm.red, mm, j);
+      d += ld_sc1(p.dhp + (long)mm * Hp + u);
+      float dc = d * og * (1.f - tc * tc);
+      dc += dc_next;
+      float* g = p.dgates + (long)mm * p.Tc * 4 * Hp + (long)t * 4 * Hp;
+      st_sc1(g + u, dc * gg * ig * (1.f - ig));
+      st_sc1(g + Hp + u, dc * c * fg * (1.f - fg));
+      st_sc1(g + 2 * Hp + u, dc * ig * (1.f - gg * gg));
+      st_sc1(g + 3 * Hp + u, d * tc * og * (1.f - og));
+      dc_next = dc * fg;
+    }
+    pd_arrive(p.cnt + PB_C_PB * p.Tc + t);
+  }
+}
+
+// dmem[n][s][e] = sum_t w[n][t][s] dctx[n][t][e]   (the decoder attention's direct share of the memory gradient)
+__global__ void attn_dmem_kernel(const float* __restrict__ w, const float* __restrict__ dctx, float* __restrict__ dmem, int Tc,
+                                 int S, int E) {
+  const int n = blockIdx.x / S, s = blockIdx.x % S;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float acc = 0.f;
+    for (int t = Tc - 1; t >= 0; --t) acc += w[((long)n * Tc + t) * S + s] * dctx[((long)n * Tc + t) * E + e];
+    dmem[((long)n * S + s) * E + e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(PB_THREADS) void decode_persist_bwd_kernel(PbParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem_raw[];
+  PbSmem& sm = *reinterpret_cast<PbSmem*>(pb_smem_raw);
+  int b = blockIdx.x;
+  if (b < p.n_ra) { role_ra(p, b, sm); return; }
+  b -= p.n_ra;
+  if (b < p.n_rb) { role_rb(p, b, sm); return; }
+  b -= p.n_rb;
+  if (b < p.N) { role_rc(p, b, reinterpret_cast<float*>(pb_smem_raw) + 4, reinterpret_cast<int*>(pb_smem_raw)); return; }
+  b -= p.N;
+  if (b < p.n_pa) { role_pa(p, b, sm); return; }
+  b -= p.n_pa;
+  role_pb(p, b, sm);
+}
+
 }  // namespace
 
 namespace acvae {
@@ -576,6 +889,38 @@ int decode_persist_fwd(PdParams p, hipStream_t st) {
   return ACVAE_OK;
 }
 
+}  // namespace acvae
+
+namespace acvae {
+bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A) {
+  // the attention role keeps a clip's frames in 2 x 32 register slots and its channels in 512 thread columns
+  return decode_persist_ok(N, Tc, S, E, H, A) && S <= 64 && E <= 512 && A <= 512 && H % 16 == 0 && H == E &&
+         (size_t)(4 + 128 + 512 + (long)S * A) * sizeof(float) <= 150 * 1024;
+}
+long decode_persist_bwd_counter_words(int Tc) { return ((long)PB_C_COUNT * Tc + 1 + 3) & ~3L; }
+
+int decode_persist_bwd(PbParams p, hipStream_t st) {
+  if (!decode_persist_bwd_ok(p.N, p.Tc, p.S, p.E, p.H, p.A)) return ACVAE_EUNSUPPORTED;
+  p.n_ra = p.H / 16; p.n_rb = p.E / 16; p.n_pa = p.E / 16; p.n_pb = p.E / 16;
+  const long words = decode_persist_bwd_counter_words(p.Tc);
+  p.abort_word = p.cnt + (long)PB_C_COUNT * p.Tc;
+  if (hipMemsetAsync(p.cnt, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
+  const int grid = p.n_ra + p.n_rb + p.N + p.n_pa + p.n_pb;
+  size_t shm = sizeof(PbSmem);
+  const size_t att = (size_t)(4 + 128 + 512 + (long)p.S * p.A) * sizeof(float);
+  if (att > shm) shm = att;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_persist_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return (int)hipGetLastError();
+    raised = true;
+  }
+  hipLaunchKernelGGL(decode_persist_bwd_kernel, dim3(grid), dim3(PB_THREADS), shm, st, p);
+  hipLaunchKernelGGL(attn_dmem_kernel, dim3(p.N * p.S), dim3(256), 0, st, p.attn_w, p.dctx, p.dmem, p.Tc, p.S, p.E);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
 }  // namespace acvae
 
 extern "C" int acvae_set_decode_persist(int on) {

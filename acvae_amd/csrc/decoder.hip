@@ -147,7 +147,7 @@ struct DecLayout {
   // bwd scratch
   long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a,
-      dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, scratch_bwd;
+      dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, pd_cnt_b, scratch_bwd;
   // bwd scratch private to the prior chain (it may run on the second stream)
   long dencproj_p, dvpart_p, dmem_p, drnn_p, tn_p, dpart_p, attws_p;
   long attws_bytes;
@@ -214,6 +214,7 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
     int w = V; if (4 * Hp > w) w = 4 * Hp; if (3 * H > w) w = 3 * H; if (2 * E > w) w = 2 * E; if (A > w) w = A;
     L.dpart_p = b.take(2 * acvae::colsum_scratch_doubles(w));
   }
+  L.pd_cnt_b = b.take(acvae::decode_persist_bwd_counter_words(Tc));   // arrival counters of the persistent BPTT launch
   L.scratch_bwd = b.off;
   return ACVAE_OK;
 }
@@ -873,6 +874,30 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(prior_bptt(t));
     ACVAE_TRY(prior_memgrad());
     ACVAE_TRY(prior_params());
+  } else if (acvae::decode_persist_bwd_ok(N, Tc, S, E, H, A)) {
+    // independent chains: the Tc steps of both BPTT chains as ONE persistent launch on the first stream
+    // (decode_persist.hip); everything batched behind it runs as before, the prior's share on the second stream.  Of
+    // prior_begin() only the zeroing of the prior attention's memory gradient is needed (and its memsets of dhp / dc / dlz
+    // on the second stream would race with the launch, which uses dhp as a hand-off buffer).
+    ACVAE_TRY(zero(dmem_p, (long)N * S * E, sp));
+    PbParams pb{};
+    pb.wt_dhh = wt_dhh; pb.wt_datt = wt_datt; pb.wt_dih = wt_dih; pb.wt_phh = wt_phh; pb.wt_pih = wt_pih; pb.wt_pml = wt_pml;
+    pb.att_v = P(TP_DEC_ATT_V);
+    pb.encproj = sv + L.encproj_d; pb.mem = mem; pb.qd = qd; pb.attn_w = attn_w; pb.gru_save = gru_save; pb.hprev_d = hprev_d;
+    pb.lstm_save = lstm_save; pb.c_all = c_all; pb.p_logs = p_logs; pb.eps_p = eps_p; pb.mem_lens = mem_lens;
+    pb.d_out = d_out; pb.d_p_z = d_p_z; pb.d_p_means = d_p_means; pb.d_p_logs = d_p_logs;
+    pb.dgi = dgi; pb.dgh = dgh; pb.dqd = dqd; pb.dctx = drnn;      // [N, Tc, E] slots in the (later) d rnn_input buffer
+    pb.dencproj = dencproj; pb.dmem = dmem; pb.dvpart = dvpart; pb.dgates = dgates; pb.dml_all = dml_all; pb.dhp = dhp;
+    pb.cnt = (unsigned*)(sc + L.pd_cnt_b);
+    pb.N = N; pb.Tc = Tc; pb.S = S; pb.E = E; pb.H = H; pb.A = A;
+    ACVAE_TRY(acvae::decode_persist_bwd(pb, st.s));
+    ACVAE_TRY(dec_memgrad());
+    if (fork.on()) ACVAE_TRY(Fork::edge(st.s, sp.s));     // the prior's batched work reads what the launch wrote
+    ACVAE_TRY(prior_memgrad());
+    if (!defer) {
+      ACVAE_TRY(dec_params(st, tn, dpart));
+      ACVAE_TRY(prior_params());
+    }
   } else {                     // independent chains: feed both queues step by step
     ACVAE_TRY(prior_begin());
     for (int t = Tc - 1; t >= 0; --t) {

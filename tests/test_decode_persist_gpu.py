@@ -1,8 +1,8 @@
 """GPU: the persistent decode loop (csrc/decode_persist.hip: the Tc steps of the prior and decoder chains of a teacher-forced
 training forward as ONE launch with in-launch hand-offs) against the per-step path of csrc/decoder.hip, which the golden
 tests pin to the reference (models/vae_model.py:700-730,792-816).  Both run the same arithmetic in the same order, so every
-output, every tensor saved for the backward and therefore every gradient must be BIT-identical - any stale hand-off, any
-missed wait shows up as a difference.  Shapes: BASELINE configs[1] (N=32, S=62), configs[3] (N=16, S=187), ragged small
+forward output and every tensor saved for the backward must be BIT-identical - any stale hand-off, any missed wait shows
+up as a difference; the backward launch (other summation order) must agree to rounding in every gradient.  Shapes: BASELINE configs[1] (N=32, S=62), configs[3] (N=16, S=187), ragged small
 batches, repeated launches (the arrival counters are re-zeroed per launch)."""
 import random
 
@@ -80,8 +80,12 @@ def test_persistent_decode_is_bit_identical_to_the_per_step_path(B, T, V, E, L):
                 a, b = torch.cat([x.reshape(-1) for x in a]), torch.cat([x.reshape(-1) for x in b])
             assert torch.equal(a, b), (k, rep, float((a.double() - b.double()).abs().max()))
         assert set(grads) == set(ref_grads)
+        # the persistent BPTT launch sums its products over eight wave shares in one pass (the per-step path: split-K slabs)
+        # and the attention's frames in one sweep: equal to rounding, not bit for bit (measured <= 3e-6 of the tensor's max)
         for k in ref_grads:
-            assert torch.equal(ref_grads[k], grads[k]), (k, rep, float((ref_grads[k] - grads[k]).abs().max()))
+            a, b = ref_grads[k].double(), grads[k].double()
+            tol = 2e-5 * float(a.abs().max()) + 1e-9
+            assert float((a - b).abs().max()) <= tol, (k, rep, float((a - b).abs().max()), float(a.abs().max()))
     assert bool(torch.isfinite(ref_out["logits"]).all())
 
 
