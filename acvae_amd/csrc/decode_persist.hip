@@ -538,9 +538,9 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persist_kernel(PdParams p) 
 // thread and the attention role spills); roles, t = Tc-1 .. 0:
 //
 //   decoder chain                                                     prior chain
-//   RA [H/16]  dh = dh.z + dgh[t+1].Whh + dqd[t+1].Watt_q;            PA [E/16]  [dhp | dlz] = dgates[t+1].[Whh | Wih_z];
+//   RA [H/32]  dh = dh.z + dgh[t+1].Whh + dqd[t+1].Watt_q;            PA [E/16]  [dhp | dlz] = dgates[t+1].[Whh | Wih_z];
 //              GRU cell backward -> dgi[t], dgh[t]                               re-parameterisation backward -> dml[t]
-//   RB [E/16]  dctx = dgi[t].Wih_ctx                                  PB [Hp/16] dhp += dml[t].Wml; LSTM cell backward -> dgates[t]
+//   RB [E/32]  dctx = dgi[t].Wih_ctx                                  PB [Hp/32] dhp += dml[t].Wml; LSTM cell backward -> dgates[t]
 //   RC [N]     attention backward of clip n: dqd[t], running sums
 //              of d encproj / d memory / dv in registers
 //
@@ -564,91 +564,128 @@ __device__ __forceinline__ float pb_sum(float (*red)[32][33], int mm, int nn) {
   for (int w = 0; w < PB_WAVES; ++w) v += red[w][mm][nn];
   return v;
 }
-// acc += A[32 rows][K] . B[32 rows][K]^T, this wave's K-groups (wave, wave + 16, ..) in batches of eight; A handed off
-// inside the launch (coherent 16-byte loads), B = weights (plain loads)
+// acc += A[32 rows][K] . B[32 rows][K]^T, this wave's K-groups (wave, wave + 8, ..) in batches of eight, software-pipelined by
+// one batch: the loads of batch i + 1 are in flight while the MFMAs of batch i run (a batch's round trip to handed-off data is
+// 3-4 us; taken one after the other - load, wait, multiply, load - a K = 1536 product spent 15 us on it).  A handed off
+// inside the launch (coherent 16-byte loads), B = weights (plain loads).
+struct PbBatch { float4 a[8], b[8]; };
+__device__ __forceinline__ void pb_load(PbBatch& f, const float* abase, long aidx, const float* bp, int G, int g) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int gu = g + u * PB_WAVES;
+    const long off = (gu < G) ? (long)gu * 8 : 0;
+    f.b[u] = *reinterpret_cast<const float4*>(bp + off);
+    f.a[u] = ld_sc1_4(abase, aidx + off);
+  }
+}
+__device__ __forceinline__ void pb_mfma(f32x16& acc, const PbBatch& f, int G, int g) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const bool ok = (g + u * PB_WAVES) < G;
+    const float4 av = ok ? f.a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, f.b[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, f.b[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, f.b[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, f.b[u].w, acc, 0, 0, 0);
+  }
+}
+// K <= 512: the wave's whole share is one batch
+__device__ __forceinline__ void pb_gemm1(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave) {
+  const int G = K / 8;
+  PbBatch f;
+  pb_load(f, abase, aidx, bp, G, wave);
+  __builtin_amdgcn_sched_barrier(0);
+  pb_mfma(acc, f, G, wave);
+}
 __device__ __forceinline__ void pb_gemm(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave) {
   const int G = K / 8;
-  for (int g = wave; g < G; g += 8 * PB_WAVES) {
-    float4 a[8], b[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int gu = g + u * PB_WAVES;
-      const long off = (gu < G) ? (long)gu * 8 : 0;
-      b[u] = *reinterpret_cast<const float4*>(bp + off);
-      a[u] = ld_sc1_4(abase, aidx + off);
-    }
+  constexpr int STEP = 8 * PB_WAVES;
+  PbBatch f0, f1;
+  pb_load(f0, abase, aidx, bp, G, wave);
+  for (int g = wave; g < G; g += 2 * STEP) {
+    if (g + STEP < G) pb_load(f1, abase, aidx, bp, G, g + STEP);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool ok = (g + u * PB_WAVES) < G;
-      const float4 av = ok ? a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[u].w, acc, 0, 0, 0);
+    pb_mfma(acc, f0, G, g);
+    if (g + STEP < G) {
+      if (g + 2 * STEP < G) pb_load(f0, abase, aidx, bp, G, g + 2 * STEP);
+      __builtin_amdgcn_sched_barrier(0);
+      pb_mfma(acc, f1, G, g + STEP);
     }
   }
 }
 
-// ---------------------------------------------------------------- RA: dh_{t} for 16 units, GRU cell backward (rnn.hip gru_bwd_kernel)
+// ---------------------------------------------------------------- RA: dh_{t} for 32 units, GRU cell backward (rnn.hip gru_bwd_kernel)
+// (32-wide slices: every reader of a handed-off tensor pulls all of it across the chip - 196 KB of dgh per workgroup and
+// step - so fewer, full-width tiles halve that traffic at the same MFMA time per workgroup)
 __device__ void role_ra(const PbParams& p, int slice, PbSmem& sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  const int H = p.H, A = p.A, u0 = slice * 16;
-  const int brow = li < 16 ? u0 + li : 0;                       // 16 of the tile's 32 columns are used
-  const float* b_hh = p.wt_dhh + (long)brow * 3 * H + 4 * lh;   // [H][3H]
-  const float* b_att = p.wt_datt + (long)brow * A + 4 * lh;     // [H + E][A], rows 0..H = query half
+  const int H = p.H, A = p.A, u0 = slice * 32;
+  const float* b_hh = p.wt_dhh + (long)(u0 + li) * 3 * H + 4 * lh;   // [H][3H]
+  const float* b_att = p.wt_datt + (long)(u0 + li) * A + 4 * lh;     // [H + E][A], rows 0..H = query half
   const int arow = li < p.N ? li : 0;
-  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, u = u0 + j;
-  const bool mine = mm < p.N;
-  float carry = 0.f;                                            // dh.z of the step before
+  // cell elements of this thread: rows mm0 and mm0 + 16, unit u
+  const int mm0 = threadIdx.x >> 5, j = threadIdx.x & 31, u = u0 + j;
+  float carry[2] = {0.f, 0.f};                                  // dh.z of the step before
   for (int t = p.Tc - 1; t >= 0; --t) {
-    float v = 0.f;
-    // this step's cell inputs do not depend on the launch
-    float dout = 0.f, r = 0.f, z = 0.f, nn = 0.f, ghn = 0.f, hp = 0.f;
-    if (mine) {
-      dout = p.d_out[(long)mm * p.Tc * H + (long)t * H + u];
-      const float* sv = p.gru_save + (long)mm * p.Tc * 4 * H + (long)t * 4 * H;
-      r = sv[u]; z = sv[H + u]; nn = sv[2 * H + u]; ghn = sv[3 * H + u];
-      hp = p.hprev_d[(long)mm * p.Tc * H + (long)t * H + u];
-    }
-    if (t < p.Tc - 1) {
-      f32x16 acc;
+    float v[2] = {0.f, 0.f};
+    f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    if (t < p.Tc - 1) {
       if (!pd_wait(p.cnt + PB_C_RA * p.Tc + (t + 1), (unsigned)p.n_ra, p.abort_word, &sm.flag)) return;
       pb_gemm(acc, p.dgh, (long)arow * p.Tc * 3 * H + (long)(t + 1) * 3 * H + 4 * lh, b_hh, 3 * H, wave);
+    }
+    // this step's cell inputs do not depend on the launch (fetched here, behind the long product: its two batches of
+    // fragments and these would not fit the register file together)
+    float dout[2], r[2], z[2], nn[2], ghn[2], hp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = mm0 + 16 * i;
+      dout[i] = r[i] = z[i] = nn[i] = ghn[i] = hp[i] = 0.f;
+      if (mm < p.N) {
+        dout[i] = p.d_out[(long)mm * p.Tc * H + (long)t * H + u];
+        const float* sv = p.gru_save + (long)mm * p.Tc * 4 * H + (long)t * 4 * H;
+        r[i] = sv[u]; z[i] = sv[H + u]; nn[i] = sv[2 * H + u]; ghn[i] = sv[3 * H + u];
+        hp[i] = p.hprev_d[(long)mm * p.Tc * H + (long)t * H + u];
+      }
+    }
+    if (t < p.Tc - 1) {
       if (!pd_wait(p.cnt + PB_C_RC * p.Tc + (t + 1), (unsigned)p.N, p.abort_word, &sm.flag)) return;
-      pb_gemm(acc, p.dqd, (long)arow * p.Tc * A + (long)(t + 1) * A + 4 * lh, b_att, A, wave);
+      pb_gemm1(acc, p.dqd, (long)arow * p.Tc * A + (long)(t + 1) * A + 4 * lh, b_att, A, wave);   // A <= 512 (decode_persist_bwd_ok)
       pb_stash(sm.red, acc, wave, li, lh);
       __syncthreads();
-      if (mine) v = pb_sum(sm.red, mm, j);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = pb_sum(sm.red, mm0 + 16 * i, j);
     }
-    if (mine) {
-      float dh = v + carry;
-      dh += dout;
-      const float dn = dh * (1.f - z);
-      const float dz = dh * (hp - nn);
-      const float dnp = dn * (1.f - nn * nn);
-      const float drp = dnp * ghn * r * (1.f - r);
-      const float dzp = dz * z * (1.f - z);
-      float* a = p.dgi + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
-      float* b = p.dgh + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
-      st_sc1(a + u, drp); st_sc1(a + H + u, dzp); st_sc1(a + 2 * H + u, dnp);
-      st_sc1(b + u, drp); st_sc1(b + H + u, dzp); st_sc1(b + 2 * H + u, dnp * r);
-      carry = dh * z;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = mm0 + 16 * i;
+      if (mm < p.N) {
+        float dh = v[i] + carry[i];
+        dh += dout[i];
+        const float dn = dh * (1.f - z[i]);
+        const float dz = dh * (hp[i] - nn[i]);
+        const float dnp = dn * (1.f - nn[i] * nn[i]);
+        const float drp = dnp * ghn[i] * r[i] * (1.f - r[i]);
+        const float dzp = dz * z[i] * (1.f - z[i]);
+        float* a = p.dgi + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
+        float* b = p.dgh + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
+        st_sc1(a + u, drp); st_sc1(a + H + u, dzp); st_sc1(a + 2 * H + u, dnp);
+        st_sc1(b + u, drp); st_sc1(b + H + u, dzp); st_sc1(b + 2 * H + u, dnp * r[i]);
+        carry[i] = dh * z[i];
+      }
     }
     pd_arrive(p.cnt + PB_C_RA * p.Tc + t);
   }
 }
 
-// ---------------------------------------------------------------- RB: dctx = dgi[t] . Wih[:, E:2E] for 16 context columns
+// ---------------------------------------------------------------- RB: dctx = dgi[t] . Wih[:, E:2E] for 32 context columns
 __device__ void role_rb(const PbParams& p, int slice, PbSmem& sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  const int H = p.H, E = p.E, e0 = slice * 16;
-  const float* bp = p.wt_dih + (long)(E + (li < 16 ? e0 + li : 0)) * 3 * H + 4 * lh;       // [3E][3H]
+  const int H = p.H, E = p.E, e0 = slice * 32;
+  const float* bp = p.wt_dih + (long)(E + e0 + li) * 3 * H + 4 * lh;       // [3E][3H]
   const int arow = li < p.N ? li : 0;
-  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15;
-  const bool mine = mm < p.N;
+  const int mm0 = threadIdx.x >> 5, j = threadIdx.x & 31;
   for (int t = p.Tc - 1; t >= 0; --t) {
     if (!pd_wait(p.cnt + PB_C_RA * p.Tc + t, (unsigned)p.n_ra, p.abort_word, &sm.flag)) return;
     f32x16 acc;
@@ -657,7 +694,11 @@ __device__ void role_rb(const PbParams& p, int slice, PbSmem& sm) {
     pb_gemm(acc, p.dgi, (long)arow * p.Tc * 3 * H + (long)t * 3 * H + 4 * lh, bp, 3 * H, wave);
     pb_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
-    if (mine) st_sc1(p.dctx + (long)mm * p.Tc * E + (long)t * E + e0 + j, pb_sum(sm.red, mm, j));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = mm0 + 16 * i;
+      if (mm < p.N) st_sc1(p.dctx + (long)mm * p.Tc * E + (long)t * E + e0 + j, pb_sum(sm.red, mm, j));
+    }
     pd_arrive(p.cnt + PB_C_RB * p.Tc + t);
   }
 }
@@ -671,16 +712,21 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
   float* w_s = smem;                  // [64]
   float* ds_s = smem + 64;            // [64]
   float* dwred = smem + 128;          // [8][64]
-  float* Pl = smem + 128 + 512;       // [S][A]
+  float* dc_s = smem + 128 + 512;     // [512]
+  float* Pl = smem + 128 + 512 + 512; // [S][A]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int a = threadIdx.x;
   const int len = (int)p.mem_lens[n];
   for (int i = threadIdx.x * 4; i < S * A; i += PB_THREADS * 4)
     *reinterpret_cast<float4*>(Pl + i) = *reinterpret_cast<const float4*>(p.encproj + (long)n * S * A + i);
+  // dw[s] = dctx . mem[s] with lanes over the frames: thread (wave w, lane s) holds mem[s][64 w .. 64 w + 63] and sums its 64
+  // products in registers - no cross-lane reduction (62 wave-wide shuffle reductions per step cost 8 us here); the eight
+  // wave shares meet in LDS.  The running sums of d encproj stay per channel: thread a, all frames.
   float m[64], dPa[64];
 #pragma unroll
   for (int k = 0; k < 64; ++k) {
-    m[k] = (k < S && a < E) ? p.mem[((long)n * S + k) * E + a] : 0.f;
+    const int e = wave * 64 + k;
+    m[k] = (lane < S && e < E) ? p.mem[((long)n * S + lane) * E + e] : 0.f;
     dPa[k] = 0.f;
   }
   const float va = a < A ? p.att_v[a] : 0.f;
@@ -690,14 +736,16 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
     const float qa = a < A ? p.qd[(long)n * p.Tc * A + (long)t * A + a] : 0.f;
     if (threadIdx.x < S) w_s[threadIdx.x] = p.attn_w[(long)n * p.Tc * S + (long)t * S + threadIdx.x];
     if (!pd_wait(p.cnt + PB_C_RB * p.Tc + t, (unsigned)p.n_rb, p.abort_word, s_flag)) return;
-    const float dc = a < E ? ld_sc1(p.dctx + (long)n * p.Tc * E + (long)t * E + a) : 0.f;
-    // dw[s] = dctx . mem[s]: per wave partial sums
+    dc_s[a] = a < E ? ld_sc1(p.dctx + (long)n * p.Tc * E + (long)t * E + a) : 0.f;
+    __syncthreads();
+    {
+      float part = 0.f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-      if (k < S) {
-        const float part = wave_sum(dc * m[k]);
-        if (lane == 0) dwred[wave * 64 + k] = part;
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const float4 d4 = *reinterpret_cast<const float4*>(dc_s + wave * 64 + k4 * 4);      // the same address in every lane: broadcast
+        part += d4.x * m[k4 * 4] + d4.y * m[k4 * 4 + 1] + d4.z * m[k4 * 4 + 2] + d4.w * m[k4 * 4 + 3];
       }
+      dwred[wave * 64 + lane] = part;
     }
     __syncthreads();
     // dscore[s] = w[s] (dw[s] - sum_j w[j] dw[j]), 0 behind the clip's last frame: one wave
@@ -779,21 +827,25 @@ __device__ void role_pa(const PbParams& p, int slice, PbSmem& sm) {
   }
 }
 
-// ---------------------------------------------------------------- PB: dhp += dml[t] . Wml, LSTM cell backward (rnn.hip lstm_bwd_kernel)
+// ---------------------------------------------------------------- PB: dhp += dml[t] . Wml, LSTM cell backward (rnn.hip lstm_bwd_kernel), 32 units
 __device__ void role_pb(const PbParams& p, int slice, PbSmem& sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  const int E = p.E, Hp = p.E, u0 = slice * 16;
-  const float* bp = p.wt_pml + (long)(li < 16 ? u0 + li : 0) * 2 * E + 4 * lh;          // [Hp][2E]
+  const int E = p.E, Hp = p.E, u0 = slice * 32;
+  const float* bp = p.wt_pml + (long)(u0 + li) * 2 * E + 4 * lh;          // [Hp][2E]
   const int arow = li < p.N ? li : 0;
-  const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, u = u0 + j;
-  const bool mine = mm < p.N;
-  float dc_next = 0.f;
+  const int mm0 = threadIdx.x >> 5, j = threadIdx.x & 31, u = u0 + j;
+  float dc_next[2] = {0.f, 0.f};
   for (int t = p.Tc - 1; t >= 0; --t) {
-    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, tc = 0.f, c = 0.f;
-    if (mine) {
-      const float* s = p.lstm_save + (long)mm * p.Tc * 5 * Hp + (long)t * 5 * Hp;
-      ig = s[u]; fg = s[Hp + u]; gg = s[2 * Hp + u]; og = s[3 * Hp + u]; tc = s[4 * Hp + u];
-      c = t ? p.c_all[(long)mm * p.Tc * Hp + (long)(t - 1) * Hp + u] : 0.f;
+    float ig[2], fg[2], gg[2], og[2], tc[2], c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = mm0 + 16 * i;
+      ig[i] = fg[i] = gg[i] = og[i] = tc[i] = c[i] = 0.f;
+      if (mm < p.N) {
+        const float* s = p.lstm_save + (long)mm * p.Tc * 5 * Hp + (long)t * 5 * Hp;
+        ig[i] = s[u]; fg[i] = s[Hp + u]; gg[i] = s[2 * Hp + u]; og[i] = s[3 * Hp + u]; tc[i] = s[4 * Hp + u];
+        c[i] = t ? p.c_all[(long)mm * p.Tc * Hp + (long)(t - 1) * Hp + u] : 0.f;
+      }
     }
     if (!pd_wait(p.cnt + PB_C_PA * p.Tc + t, (unsigned)p.n_pa, p.abort_word, &sm.flag)) return;
     f32x16 acc;
@@ -802,17 +854,21 @@ __device__ void role_pb(const PbParams& p, int slice, PbSmem& sm) {
     pb_gemm(acc, p.dml_all, (long)arow * p.Tc * 2 * E + (long)t * 2 * E + 4 * lh, bp, 2 * E, wave);
     pb_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
-    if (mine) {
-      float d = pb_sum(sm.red, mm, j);
-      d += ld_sc1(p.dhp + (long)mm * Hp + u);
-      float dc = d * og * (1.f - tc * tc);
-      dc += dc_next;
-      float* g = p.dgates + (long)mm * p.Tc * 4 * Hp + (long)t * 4 * Hp;
-      st_sc1(g + u, dc * gg * ig * (1.f - ig));
-      st_sc1(g + Hp + u, dc * c * fg * (1.f - fg));
-      st_sc1(g + 2 * Hp + u, dc * ig * (1.f - gg * gg));
-      st_sc1(g + 3 * Hp + u, d * tc * og * (1.f - og));
-      dc_next = dc * fg;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = mm0 + 16 * i;
+      if (mm < p.N) {
+        float d = pb_sum(sm.red, mm, j);
+        d += ld_sc1(p.dhp + (long)mm * Hp + u);
+        float dc = d * og[i] * (1.f - tc[i] * tc[i]);
+        dc += dc_next[i];
+        float* g = p.dgates + (long)mm * p.Tc * 4 * Hp + (long)t * 4 * Hp;
+        st_sc1(g + u, dc * gg[i] * ig[i] * (1.f - ig[i]));
+        st_sc1(g + Hp + u, dc * c[i] * fg[i] * (1.f - fg[i]));
+        st_sc1(g + 2 * Hp + u, dc * ig[i] * (1.f - gg[i] * gg[i]));
+        st_sc1(g + 3 * Hp + u, d * tc[i] * og[i] * (1.f - og[i]));
+        dc_next[i] = dc * fg[i];
+      }
     }
     pd_arrive(p.cnt + PB_C_PB * p.Tc + t);
   }
@@ -894,20 +950,20 @@ int decode_persist_fwd(PdParams p, hipStream_t st) {
 namespace acvae {
 bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A) {
   // the attention role keeps a clip's frames in 2 x 32 register slots and its channels in 512 thread columns
-  return decode_persist_ok(N, Tc, S, E, H, A) && S <= 64 && E <= 512 && A <= 512 && H % 16 == 0 && H == E &&
-         (size_t)(4 + 128 + 512 + (long)S * A) * sizeof(float) <= 150 * 1024;
+  return decode_persist_ok(N, Tc, S, E, H, A) && S <= 64 && E <= 512 && A <= 512 && H % 32 == 0 && H == E &&
+         (size_t)(4 + 128 + 512 + 512 + (long)S * A) * sizeof(float) <= 150 * 1024;
 }
 long decode_persist_bwd_counter_words(int Tc) { return ((long)PB_C_COUNT * Tc + 1 + 3) & ~3L; }
 
 int decode_persist_bwd(PbParams p, hipStream_t st) {
   if (!decode_persist_bwd_ok(p.N, p.Tc, p.S, p.E, p.H, p.A)) return ACVAE_EUNSUPPORTED;
-  p.n_ra = p.H / 16; p.n_rb = p.E / 16; p.n_pa = p.E / 16; p.n_pb = p.E / 16;
+  p.n_ra = p.H / 32; p.n_rb = p.E / 32; p.n_pa = p.E / 16; p.n_pb = p.E / 32;
   const long words = decode_persist_bwd_counter_words(p.Tc);
   p.abort_word = p.cnt + (long)PB_C_COUNT * p.Tc;
   if (hipMemsetAsync(p.cnt, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
   const int grid = p.n_ra + p.n_rb + p.N + p.n_pa + p.n_pb;
   size_t shm = sizeof(PbSmem);
-  const size_t att = (size_t)(4 + 128 + 512 + (long)p.S * p.A) * sizeof(float);
+  const size_t att = (size_t)(4 + 128 + 512 + 512 + (long)p.S * p.A) * sizeof(float);
   if (att > shm) shm = att;
   static bool raised = false;
   if (!raised) {

@@ -64,5 +64,42 @@ def run():
     print("D3(t-1)->D1q %.2f | D1q->D2 %.2f | D2->D3 %.2f us" % ((d1q[3:] - d3[2:-1]).mean(), (d2[3:] - d1q[3:]).mean(), (d3[3:] - d2[3:]).mean()))
 
 
+def run_bwd():
+    os.environ["ACVAE_DEV_LIB"] = LIB
+    sys.path.insert(0, ROOT)
+    import numpy as np, torch, random
+    import bench
+    from acvae_amd import _lib
+    from acvae_amd.trainer import TrainStep
+    model = bench.build_model().cuda().train()
+    ts = TrainStep(model, bench.V)
+    feats, caps, fl, cl = bench.synthetic(1)
+    f = feats.cuda(); Tc = 21
+    roles = {"RA": (0, 16), "RB": (16, 32), "RC": (32, 64), "PA": (64, 96), "PB": (96, 112)}
+    nblk = 112
+    buf = torch.zeros(nblk * 32 * 8, dtype=torch.int64, device="cuda")
+    lib = _lib.lib(); lib.acvae_pd_trace.argtypes = [ctypes.c_void_p]
+    for rep in range(4):
+        random.seed(0)
+        loss, parts, _ = ts.forward_loss(f, fl.copy(), caps, cl, 1.0, 0, 0.5); torch.cuda.synchronize()
+        if rep == 3: lib.acvae_pd_trace(ctypes.c_void_p(buf.data_ptr()))
+        loss.backward(); torch.cuda.synchronize()
+    lib.acvae_pd_trace(ctypes.c_void_p(0))
+    t = buf.cpu().numpy().reshape(nblk, 32, 8)[:, :Tc, :].astype(np.float64) * 0.01
+    t0 = t[t > 0].min(); t = np.where(t > 0, t - t0, np.nan)
+    print("span %.1f us" % np.nanmax(t))
+    for name, (a, b) in roles.items():
+        x = t[a:b, 1:Tc - 1, :]
+        lastw = np.nanmax(x[:, :, :6], axis=2)
+        firstw = np.nanmin(x[:, :, :6], axis=2)
+        print(f"{name}: first wait end -> last wait end {np.nanmean(lastw - firstw):.2f}; last wait end -> before arrive {np.nanmean(x[:, :, 6] - lastw):.2f} us (slowest wg {np.nanmean(np.nanmax(x[:, :, 6] - lastw, axis=0)):.2f}); arrive {np.nanmean(x[:, :, 7] - x[:, :, 6]):.2f} us")
+    ra = np.nanmax(t[0:16, :, 7], axis=0); rb = np.nanmax(t[16:32, :, 7], axis=0); rc = np.nanmax(t[32:64, :, 7], axis=0)
+    pa = np.nanmax(t[64:96, :, 7], axis=0); pb = np.nanmax(t[96:112, :, 7], axis=0)
+    # time runs with DEcreasing t
+    print("decoder chain step period %.2f us: RC(t+1)->RA(t) %.2f | RA->RB %.2f | RB->RC %.2f" % (
+        (ra[1:-2] - ra[2:-1]).mean(), (ra[1:-2] - rc[2:-1]).mean(), (rb[1:-2] - ra[1:-2]).mean(), (rc[1:-2] - rb[1:-2]).mean()))
+    print("prior chain step period %.2f us: PB(t+1)->PA(t) %.2f | PA->PB %.2f" % ((pb[1:-2] - pb[2:-1]).mean(), (pa[1:-2] - pb[2:-1]).mean(), (pb[1:-2] - pa[1:-2]).mean()))
+
+
 if __name__ == "__main__":
-    build() if sys.argv[1] == "build" else run()
+    {"build": build, "run": run, "bwd": run_bwd}[sys.argv[1]]()
