@@ -402,8 +402,16 @@ class Hybrid_VAEModel(CaptionModel):
         temp = float(kwargs.get("temp", 1))
         V = self.vocab_size
         code = 0 if method == "greedy" else (1 if method == "gumbel" else 2)
+        # rng="device" (or model.sample_rng = "device") - opt-in, not the reference's stream: ONE draw on the CPU generator
+        # seeds a counter-based generator on the device that fills the [Tc,N,V] noise (acvae_sample_noise); same
+        # distributions, so the captions are samples of the same model, but not the words the reference would draw from
+        # this torch seed.  The default ("host") reproduces the reference's draws one for one.
+        rng = kwargs.get("rng", getattr(self, "sample_rng", "host"))
+        if rng not in ("host", "device"):
+            raise ValueError(f"rng must be 'host' or 'device', got {rng!r}")
         sample_noise = None
-        if code and (replay is None or replay.get("sample_noise") is None):
+        device_noise = bool(code) and rng == "device" and (replay is None or replay.get("sample_noise") is None)
+        if code and not device_noise and (replay is None or replay.get("sample_noise") is None):
             sample_noise = torch.empty(Tc, N, V)
         # the decoder's word-embedding nn.Dropout (models/decoder.py:33,184): one [N,1,E] Bernoulli draw per step, made
         # by decoder.forward, i.e. after the step's prior noise and disentangle coin and before sample_next_word
@@ -440,7 +448,12 @@ class Hybrid_VAEModel(CaptionModel):
             caps_d = _lib.h2d(caps, dev, torch.long).contiguous()
             lens1_d = _lib.h2d(lens1, dev, torch.long)
         sampling = {}
-        if code:
+        if device_noise:
+            seed = int(torch.randint(0, 2 ** 62, (1,)))             # after the step draws: torch.manual_seed fixes it
+            noise_d = torch.empty(Tc, N, V, device=dev, dtype=torch.float32)
+            _lib.call("acvae_sample_noise", noise_d, noise_d.numel(), code, seed, _lib.current_stream())
+            sampling["sample"] = (code, temp, noise_d)
+        elif code:
             if sample_noise is None:
                 sample_noise = torch.as_tensor(replay["sample_noise"])[:Tc]
             sampling["sample"] = (code, temp, _lib.h2d(sample_noise, dev, torch.float32).contiguous())

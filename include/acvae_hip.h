@@ -111,6 +111,11 @@ int acvae_row_logsoftmax_argmax(const float* logits, int64_t ld_n, int64_t ld_t,
 #define ACVAE_SAMPLE_GREEDY 0
 #define ACVAE_SAMPLE_GUMBEL 1
 #define ACVAE_SAMPLE_MULTINOMIAL 2
+/* n floats of sampling noise generated on the device (counter-based Philox, element i from (seed, i)): Gumbel noise for
+ * ACVAE_SAMPLE_GUMBEL, Exp(1) draws for ACVAE_SAMPLE_MULTINOMIAL - what the caller otherwise draws on the CPU generator
+ * (models/word_model.py:188-203).  Same distributions, another random stream: the opt-in fast mode of method="sample" /
+ * "gumbel"; the CPU-generator mode stays the parity default. */
+int acvae_sample_noise(float* noise, int64_t n, int method, uint64_t seed, void* stream);
 int acvae_sample_next_word(const float* logits, int64_t ld_n, int64_t ld_t, const float* noise, int64_t nz_sn,
                            int64_t nz_st, int method, float temp, int64_t* w_out, float* logprob_out, int64_t o_sn,
                            int64_t o_st, int N, int T, int V, void* stream);

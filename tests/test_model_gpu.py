@@ -701,3 +701,59 @@ def test_train_step_goldens_with_trailing_parameter_gradients():
                         "-k", "g6 or g13 or edge_shapes or checkpoint"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_device_rng_sampling_noise_distribution_and_word_frequencies():
+    """rng="device" (opt-in): acvae_sample_noise fills the noise with a counter-based generator on the GPU instead of the
+    CPU generator.  Not the reference's stream, so the checks are statistical, at significance 1e-6 (a correct generator
+    fails them once in a million seeds; the seed is fixed): (1) Kolmogorov-Smirnov of 1M draws against Gumbel(0,1) / Exp(1),
+    (2) chi-square of the words acvae_sample_next_word picks with that noise against softmax(logits) (gumbel; the temp
+    divides all scores alike) and softmax(logits / temp) (multinomial), (3) seeds and offsets give different streams and
+    the same seed the same one."""
+    from scipy import stats
+    from acvae_amd import _lib
+    n = 1 << 20
+    for code, dist in ((1, stats.gumbel_r), (2, stats.expon)):
+        z = torch.empty(n + 3, device="cuda")                      # + 3: the tail that is not a multiple of four
+        _lib.call("acvae_sample_noise", z, z.numel(), code, 1234, _lib.current_stream())
+        z2 = torch.empty_like(z)
+        _lib.call("acvae_sample_noise", z2, z2.numel(), code, 1234, _lib.current_stream())
+        assert torch.equal(z, z2)
+        _lib.call("acvae_sample_noise", z2, z2.numel(), code, 1235, _lib.current_stream())
+        assert float((z == z2).float().mean()) < 1e-3
+        zz = z.cpu().double().numpy()
+        assert np.isfinite(zz).all()
+        assert stats.kstest(zz, dist.cdf).pvalue > 1e-6, (code, stats.kstest(zz, dist.cdf))
+        assert abs(np.corrcoef(zz[:-1], zz[1:])[0, 1]) < 5e-3       # neighbours (same Philox block) uncorrelated
+    V, rows, temp = 24, 200000, 0.7
+    g = torch.Generator().manual_seed(3)
+    logits1 = torch.randn(V, generator=g) * 1.5
+    logits = logits1.expand(rows, V).contiguous().cuda()
+    for code, p in ((1, torch.softmax(logits1.double(), 0)), (2, torch.softmax(logits1.double() / temp, 0))):
+        z = torch.empty(rows, V, device="cuda")
+        _lib.call("acvae_sample_noise", z, z.numel(), code, 99, _lib.current_stream())
+        w = torch.empty(rows, dtype=torch.long, device="cuda"); lp = torch.empty(rows, device="cuda")
+        _lib.call("acvae_sample_next_word", logits, V, 0, z, V, 0, code, temp, w, lp, 1, 0, rows, 1, V, _lib.current_stream())
+        cnt = np.bincount(w.cpu().numpy(), minlength=V).astype(np.float64)
+        assert stats.chisquare(cnt, p.numpy() * rows).pvalue > 1e-6, (code, cnt, p * rows)
+        close(lp, torch.log_softmax(logits1, 0)[w.cpu()], 1e-5, 1e-5, what="logprob of the sampled word")
+
+
+def test_device_rng_forward_is_seeded_by_the_torch_generator():
+    """Hybrid_VAEModel.forward(..., method="sample", rng="device"): one CPU-generator draw seeds the device noise, so
+    torch.manual_seed still fixes the captions; another seed gives other captions; the default stays the host stream."""
+    V, E = 40, 64
+    state = O.closed_form_state(O.state_shapes(V, E, E, None, E, 512))
+    feats, _, feat_lens, _ = O.synthetic_batch(4, 96, V, 6, seed=5, ragged=False)
+    model = build_model(V, E, state)
+    model.eval()
+    outs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            outs.append(model(feats.cuda(), feat_lens.copy(), method="sample", temp=1.0, rng="device"))
+    assert torch.equal(outs[0]["seqs"], outs[1]["seqs"])
+    assert not torch.equal(outs[0]["seqs"], outs[2]["seqs"])
+    assert int(outs[0]["seqs"].min()) >= 0 and int(outs[0]["seqs"].max()) < V
+    with pytest.raises(ValueError):
+        model(feats.cuda(), feat_lens.copy(), method="sample", rng="gpu")
