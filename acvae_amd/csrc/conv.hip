@@ -768,36 +768,57 @@ __global__ __launch_bounds__(256) void conv1_first_bwd_kernel(const float* __res
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int k = 0; k < 9; ++k) dwacc[c][k] = 0.f;
-  // rows t0-1 .. t0+RB (halo rows contribute to D only)
-  for (int pix = pp; pix < (C1_RB + 2) * 64; pix += 16) {
+  // rows t0-1 .. t0+RB (halo rows contribute to D only).  The loop is latency-bound on the dY stream (one 16-B load per
+  // lane and pixel): the loads of the next four pixels are in flight while these four are reduced.
+  constexpr int C1_IT = (C1_RB + 2) * 64 / 16, C1_UN = 4;
+  static_assert(C1_IT % C1_UN == 0, "pixel loop is unrolled by four");
+  auto fetch = [&](int it, float4& g) {
+    const int pix = pp + it * 16;
     const int r = pix >> 6, w = pix & 63;
     const int t = t0 + r - 1;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool inimg = (t >= 0 && t < T && w < F);
-    if (inimg) g = load4(dY + (((long)n * T + t) * F + w) * 64 + cq * 4);
-    const float gv[4] = {g.x, g.y, g.z, g.w};
-    float d[9];
+    g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T && w < F) g = load4(dY + (((long)n * T + t) * F + w) * 64 + cq * 4);
+  };
+  float4 gq[C1_UN], gn[C1_UN];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) d[k] = gv[0] * wreg[0][k] + gv[1] * wreg[1][k] + gv[2] * wreg[2][k] + gv[3] * wreg[3][k];
-    // reduce over the 16 cout-quads (16 consecutive lanes)
+  for (int u = 0; u < C1_UN; ++u) fetch(u, gq[u]);
+  for (int it0 = 0; it0 < C1_IT; it0 += C1_UN) {
+    if (it0 + C1_UN < C1_IT) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      float v = d[k];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-      d[k] = v;
+      for (int u = 0; u < C1_UN; ++u) fetch(it0 + C1_UN + u, gn[u]);
     }
-    if (cq == 0) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) D[(r * 64 + w) * 9 + k] = d[k];
-    }
-    if (inimg && r >= 1 && r <= C1_RB) {  // own rows: weight gradient
+    for (int u = 0; u < C1_UN; ++u) {
+      const int pix = pp + (it0 + u) * 16;
+      const int r = pix >> 6, w = pix & 63;
+      const int t = t0 + r - 1;
+      const bool inimg = (t >= 0 && t < T && w < F);
+      const float gv[4] = {gq[u].x, gq[u].y, gq[u].z, gq[u].w};
+      float d[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) d[k] = gv[0] * wreg[0][k] + gv[1] * wreg[1][k] + gv[2] * wreg[2][k] + gv[3] * wreg[3][k];
+      // reduce over the 16 cout-quads (16 consecutive lanes)
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const float in = patch[(r - 1 + k / 3) * 66 + w + k % 3];
+        float v = d[k];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        d[k] = v;
+      }
+      if (cq == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dwacc[c][k] += gv[c] * in;
+        for (int k = 0; k < 9; ++k) D[(r * 64 + w) * 9 + k] = d[k];
+      }
+      if (inimg && r >= 1 && r <= C1_RB) {  // own rows: weight gradient
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float in = patch[(r - 1 + k / 3) * 66 + w + k % 3];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dwacc[c][k] += gv[c] * in;
+        }
       }
     }
+#pragma unroll
+    for (int u = 0; u < C1_UN; ++u) gq[u] = gn[u];
   }
   __syncthreads();   // D complete
   // dxin for own pixels and the per-mel reductions

@@ -289,26 +289,15 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     }
   };
   auto put_raw = [&](float4* raw) { put_raw_part(raw, 0); put_raw_part(raw, 2); };
-  // weight chunk c: 32 KB, already in LDS order; one LDS-DMA instruction of a wave moves 1 KB
+  // weight chunk c: 32 KB image [position][k half][column] of float4 (4 k-steps).  The fragments go from L2 / L1 STRAIGHT into
+  // the MFMA operand registers: lane (h, li) of a wavefront (nh) needs exactly one float4 per position and chunk, at
+  // (pos * 128 + h * 64 + nh * 32 + li) - two 512-byte runs per wave instruction.  (The previous form moved the chunk
+  // into LDS by LDS-DMA and read the fragments back: per chunk and wavefront 4 DMA instructions at 100+ issue cycles each
+  // inside a phase full of LDS reads, 8 ds_read_b128 and a barrier per chunk - 5200-5450 cycles per chunk against 4096 of
+  // MFMA, of which ~470 went away in the lab build without the DMA; tools/lab_wino.py `full` / `nodma`.)
   const int nchunk = C >> 3;
-  const float* Ub = p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4) + wave * 256 + lane * 4;
-  // Issued as inline asm, not through __builtin_amdgcn_global_load_lds: hipcc orders an LDS-DMA against later LDS reads by
-  // itself, tracks at most eight DMA instructions precisely and falls back to s_waitcnt vmcnt(0) beyond that - in front of
-  // the barrier of every other chunk, where it would wait out the activation loads issued a few hundred cycles earlier.
-  // Invisible to that pass, the DMA is ordered by hand: the issuing wave's counted vmcnt wait, then the barrier.
-  // M0 = LDS destination of lane 0 (wave-uniform); lane l lands at M0 + 16 l.
-  auto dma16 = [&](const float* src, float* dst) {
-    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(src) : "memory");
-  };
-  auto fetch_b_part = [&](int c, float4* bw, int half) {        // two of the chunk's four instructions of this wave
-    const float* src = Ub + (long)c * (WN_BCHUNK * 4) + half * 4096;
-    float* dst = reinterpret_cast<float*>(bw) + wave * 256 + half * 4096;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(src + i * 2048, dst + i * 2048);
-  };
-  auto fetch_b = [&](int c, float4* bw) { fetch_b_part(c, bw, 0); fetch_b_part(c, bw, 1); };
-
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4)), 0, 0x7fffffff, 0x00020000);
   // ---------------------------------------------------------------- this lane's tile and fragment addresses
   int tyl_a, tx_a;
   wino_tile(mh, li, p.tw_shift, tyl_a, tx_a);
@@ -320,7 +309,14 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     rowoff[a] = (i & 1) * WN_SR + (i >> 1) * RW + abase;
   }
   constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;     // vertical frequencies of local positions 0..3 / 4..7
-  const int bcol = h * 64 + nh * 32 + li;
+  const int bvoff = (h * 64 + nh * 32 + li) * 16;
+  // group g (0..7) of chunk c: local position g -> image position xi0 * 4 + g (g < 4) or xi1 * 4 + g - 4
+  auto load_b = [&](int c, int g) {
+    typedef unsigned wn_v4u __attribute__((ext_vector_type(4)));
+    const int pos = g < 4 ? xi0 * 4 + g : xi1 * 4 + (g - 4);
+    const wn_v4u v = __builtin_amdgcn_raw_buffer_load_b128(urs, bvoff, c * (WN_BCHUNK * 16) + pos * 2048, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
 
   f32x16 acc[8];
 #pragma unroll
@@ -329,23 +325,22 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   // ---------------------------------------------------------------- main loop
-  // One barrier per 8-channel chunk; per chunk a wavefront issues 8 groups of 4 MFMAs (one accumulator each) and, pinned
-  // BETWEEN the groups by sched_barriers, the work that does not need the matrix pipe: the weight DMA of the next chunk, the
-  // staging of the next stage, and - software-pipelined ACROSS the barrier - the window reads and transforms of the NEXT
-  // chunk.  Why this shape (in-kernel cycle counters of the previous form, 6184 cycles per chunk against 4096 of MFMA per
-  // SIMD): hipcc placed every LDS read just in time, so at each chunk start all eight wavefronts waited for 16 reads in
-  // front of their first MFMA, did their vector-memory issue and their staging together (nobody issuing MFMAs meanwhile),
-  // and the later wavefront of a SIMD ran its last groups alone with the same exposed waits.  Now a chunk starts with
-  // its operands in registers (v0: the horizontally transformed window of positions 0-3, t1: the vertical transform for
-  // positions 4-7; only the four weight fragments are read after the barrier), and every filler slot sits behind a group
-  // of 4 dependent MFMAs (256 cycles of pipe): the two wavefronts of a SIMD fall into alternating groups by themselves (the
-  // arbiter prefers the older one until it reaches a filler), so one's fillers run under the other's MFMAs.
+  // Per 8-channel chunk a wavefront issues 8 groups of 4 MFMAs (one accumulator each) and, pinned BETWEEN the groups by
+  // sched_barriers, the work that does not need the matrix pipe.  A chunk starts with its operands in registers: v0 (the
+  // horizontally transformed window of positions 0-3), t1 (the vertical transform for positions 4-7) - the window reads
+  // and transforms of the NEXT chunk are software-pipelined into the tail of this one - and the weight fragments in a ring
+  // of four float4 (slot g & 3 for group g): the slot a group has just used is reloaded with the fragment four groups ahead
+  // (>= 1500 cycles of flight for an L2 hit of 300-500).  Every filler slot sits behind a group of 4 dependent MFMAs (256
+  // cycles of pipe): the two wavefronts of a SIMD fall into alternating groups by themselves, one's fillers run under the
+  // other's MFMAs.  All vector-memory operations are plain loads now, so the waits are the compiler's own counted ones
+  // and ONE barrier per 16-channel stage remains (for the window buffers):
   //   raw window of stage s+1: loaded (global -> registers) in chunk (s-1, 0), written to LDS in chunk (s, 0), first read
-  //   (prefetch for chunk (s+1, 0)) in chunk (s, 1); its buffer's last readers were the prefetch reads in chunk (s-1, 0).
+  //   (prefetch for chunk (s+1, 0)) in chunk (s, 1); its buffer's last readers were the prefetch reads in chunk (s-1, 0);
+  //   the barrier at the end of chunk (s, 0) separates both pairs.
   const int nstage = C >> 4;
   const float4* const aq0 = raw0 + h * WN_SQ;        // + 2 * sub * WN_SQ + rowoff[a] + (j & 1) * WN_SC + (j >> 1)
   const float4* const aq1 = raw1 + h * WN_SQ;
-  float4 v0[4], t1[4];
+  float4 v0[4], t1[4], B[4];
   // window reads + vertical transform of one chunk: rows XH, XH+2 -> t0 (in place), rows XH+1 and XH (XH+2) -> t1
   auto read_rows02 = [&](const float4* rq, float4 (&d0)[4], float4 (&d2)[4]) {
 #pragma unroll
@@ -366,13 +361,13 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     }
   };
 
+#pragma unroll
+  for (int g = 0; g < 4; ++g) B[g] = load_b(0, g);
   issue_raw(0);
-  fetch_b(0, bw0);
   stage_scsh();
   read_scsh(0);
   put_raw(raw0);
   issue_raw(nstage > 1 ? 1 : 0);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __syncthreads();
   {
     float4 d0[4], d1[4], d2[4];
@@ -385,74 +380,65 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   }
 #define WN_SB() __builtin_amdgcn_sched_barrier(0)
   // No run-time condition anywhere in a chunk: past the last stage the staging repeats the last stage (loads that hit L2,
-  // stores into a buffer nobody reads any more).  With the activation loads under a condition, hipcc's own wait in front of
-  // the barrier (the next chunk reads what the DMA wrote) falls back from vmcnt(4) to vmcnt(0) and every other barrier
-  // waits out the whole latency of loads issued a few hundred cycles earlier; two copies of the chunk (with / without)
-  // make the register allocator carry both sets of accumulators through the join (1 KB of spills per lane).
+  // stores into a buffer nobody reads any more), past the last chunk the weight ring reloads the last chunk.  Two copies of
+  // the chunk (with / without) make the register allocator carry both sets of accumulators through the join (1 KB of
+  // spills per lane).
   auto step = [&](int c, auto kk) {
     constexpr int K = decltype(kk)::value;            // c % 4
     constexpr int sub = K & 1, sp = K >> 1;
     const int st = c >> 1;
-    const float4* const bq = (sub ? bw1 : bw0) + bcol;
-    float4* const bnxt = sub ? bw0 : bw1;
     float4* const rnxt = sp ? raw0 : raw1;
     // the next chunk's window: the other half of this stage's buffer, or the first half of the next stage's
     const float4* const nq = sub ? (sp ? aq0 : aq1) : (sp ? aq1 : aq0) + 2 * WN_SQ;
     const int cn = c + 1 < nchunk ? c + 1 : c;          // last chunk: a harmless repeat instead of a branch
-    float4 b[4], bb[4], d0[4], d1[4], d2[4], v1[4];
+    float4 d0[4], d1[4], d2[4], v1[4];
     const int st1 = st + 1 < nstage ? st + 1 : nstage - 1, st2 = st + 2 < nstage ? st + 2 : nstage - 1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] = bq[(xi0 * 4 + k) * 128];
     if (sub == 0) read_scsh(st1);
     WN_SB();
-    mfma4(acc[0], v0[0], b[0]);
+    mfma4(acc[0], v0[0], B[0]);
     WN_SB();
-    // first chunk of a stage: the staging of stage st + 1 (loaded during the previous stage; nothing else is outstanding in
-    // the vector-memory queue here, so the compiler's vmcnt(0) in front of the stores costs nothing), then the DMA (two
-    // instructions per slot; one per slot over four slots measured 1-4 % slower), then the loads of stage st + 2 behind it
+    B[0] = load_b(c, 4);
+    // first chunk of a stage: the staging of stage st + 1 (loaded during the previous stage), then the loads of stage st + 2
     if (sub == 0) put_raw_part(rnxt, 0);
-    else fetch_b_part(cn, bnxt, 0);
     WN_SB();
-    mfma4(acc[1], v0[1], b[1]);
+    mfma4(acc[1], v0[1], B[1]);
     WN_SB();
+    B[1] = load_b(c, 5);
     if (sub == 0) put_raw_part(rnxt, 2);
-    else fetch_b_part(cn, bnxt, 1);
     WN_SB();
-    mfma4(acc[2], v0[2], b[2]);
+    mfma4(acc[2], v0[2], B[2]);
     WN_SB();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bb[k] = bq[(xi1 * 4 + k) * 128];
-    if (sub == 0) fetch_b_part(cn, bnxt, 0);
+    B[2] = load_b(c, 6);
+    if (sub == 0) issue_raw(st2);                     // stored in chunk (st + 1, 0)
     WN_SB();
-    mfma4(acc[3], v0[3], b[3]);
+    mfma4(acc[3], v0[3], B[3]);
     WN_SB();
+    B[3] = load_b(c, 7);
     wino_htrans_ip(t1, v1);
-    if (sub == 0) fetch_b_part(cn, bnxt, 1);
     WN_SB();
-    mfma4(acc[4], v1[0], bb[0]);
+    mfma4(acc[4], v1[0], B[0]);
     WN_SB();
+    B[0] = load_b(cn, 0);
     read_rows02(nq, d0, d2);
-    if (sub == 0) issue_raw(st2);                     // behind the DMA in the vector-memory queue; stored in chunk (st + 1, 0)
     WN_SB();
-    mfma4(acc[5], v1[1], bb[1]);
+    mfma4(acc[5], v1[1], B[1]);
     WN_SB();
+    B[1] = load_b(cn, 1);
     read_row1(nq, d1);
     WN_SB();
-    mfma4(acc[6], v1[2], bb[2]);
+    mfma4(acc[6], v1[2], B[2]);
     WN_SB();
+    B[2] = load_b(cn, 2);
     vertical(d0, d1, d2);
     WN_SB();
-    mfma4(acc[7], v1[3], bb[3]);
+    mfma4(acc[7], v1[3], B[3]);
     WN_SB();
+    B[3] = load_b(cn, 3);
     wino_htrans_ip(d0, v0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) t1[j] = d1[j];
     WN_SB();
-    // an LDS-DMA is ordered for its readers by the issuing wave's vmcnt wait followed by a barrier.  vmcnt retires in
-    // order: vmcnt(4) has seen the DMA land while the four loads issued behind it still fly.
-    if (sub == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (sub == 0) __syncthreads();
   };
 #undef WN_SB
   using std::integral_constant;
@@ -464,6 +450,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
       step(c + 3, integral_constant<int, 3>());
     }
   }
+  __syncthreads();          // the epilogue reuses the window buffers
 
   // ---------------------------------------------------------------- epilogue
   float* exb = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array

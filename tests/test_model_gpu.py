@@ -737,6 +737,16 @@ def test_device_rng_sampling_noise_distribution_and_word_frequencies():
         cnt = np.bincount(w.cpu().numpy(), minlength=V).astype(np.float64)
         assert stats.chisquare(cnt, p.numpy() * rows).pvalue > 1e-6, (code, cnt, p * rows)
         close(lp, torch.log_softmax(logits1, 0)[w.cpu()], 1e-5, 1e-5, what="logprob of the sampled word")
+        # and against the parity mode itself: 10k words from host-drawn noise (the reference's draws) next to 10k from
+        # the device noise - a 2 x V homogeneity test of the two token histograms
+        k = 10000
+        torch.manual_seed(5)
+        zh = (-torch.log(-torch.log(torch.rand(k, V) + 1e-20) + 1e-20)) if code == 1 else torch.empty(k, V).exponential_(1)
+        wh = torch.empty(k, dtype=torch.long, device="cuda")
+        _lib.call("acvae_sample_next_word", logits, V, 0, zh.cuda(), V, 0, code, temp, wh, lp, 1, 0, k, 1, V, _lib.current_stream())
+        table = np.stack([np.bincount(wh.cpu().numpy(), minlength=V), np.bincount(w[:k].cpu().numpy(), minlength=V)])
+        table = table[:, table.sum(0) > 0]
+        assert stats.chi2_contingency(table)[1] > 1e-6, (code, table)
 
 
 def test_device_rng_forward_is_seeded_by_the_torch_generator():

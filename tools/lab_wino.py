@@ -17,13 +17,15 @@ FAKE_D = ("#pragma unroll\n    for (int j = 0; j < 4; ++j) asm volatile(\"\" : \
           "\"=v\"(DST[j].w));")
 VARIANTS = {
     "base": [],
+    "new": [],
+    "pair": [],
     "prioA": [(PRE_LOOP, "  if (wave < 4) __builtin_amdgcn_s_setprio(1);\n" + PRE_LOOP)],
     "prioB": [(PRE_LOOP, "  if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n" + PRE_LOOP)],
-    "nodma": [("    else fetch_b_part(cn, bnxt, 0);\n", ""), ("    else fetch_b_part(cn, bnxt, 1);\n", ""),
-              ("    if (sub == 0) fetch_b_part(cn, bnxt, 0);\n", ""), ("    if (sub == 0) fetch_b_part(cn, bnxt, 1);\n", "")],
-    "noraw": [("    if (sub == 0) put_raw_part(rnxt, 0);\n    else fetch_b_part", "    if (sub != 0) fetch_b_part"),
-              ("    if (sub == 0) put_raw_part(rnxt, 2);\n    else fetch_b_part", "    if (sub != 0) fetch_b_part"),
-              ("    if (sub == 0) issue_raw(st2);", "    (void)st2;"), ("    if (sub == 0) read_scsh(st1);\n", "    (void)st1;\n")],
+    "nob": [(f"    B[{i}] = load_b({c}, {g});\n", "") for (i, c, g) in
+            [(0, "c", 4), (1, "c", 5), (2, "c", 6), (3, "c", 7), (0, "cn", 0), (1, "cn", 1), (2, "cn", 2), (3, "cn", 3)]],
+    "noraw": [("    if (sub == 0) put_raw_part(rnxt, 0);\n", ""), ("    if (sub == 0) put_raw_part(rnxt, 2);\n", ""),
+              ("    if (sub == 0) issue_raw(st2);", "    (void)st2; (void)rnxt;"), ("    if (sub == 0) read_scsh(st1);\n", "    (void)st1;\n")],
+    "nobar": [("    if (sub == 0) __syncthreads();\n  };", "  };")],
     "nod": [("    read_rows02(nq, d0, d2);\n", "    (void)nq;\n" + FAKE_D.replace("DST", "d0") + "\n" + FAKE_D.replace("DST", "d2") + "\n"),
             ("    read_row1(nq, d1);\n", FAKE_D.replace("DST", "d1") + "\n")],
 }
@@ -58,9 +60,26 @@ VARIANTS["timeline"] = [
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
      "    o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = 0.f;\n  }\n}\n\n// ACT: the operand"),
 ]
-VARIANTS["mfmaonly"] = VARIANTS["nodma"] + [("    if (sub == 0) put_raw_part(rnxt, 0);\n", ""), ("    if (sub == 0) put_raw_part(rnxt, 2);\n", ""),
-                                         ("    if (sub == 0) issue_raw(st2);", "    (void)st2;"),
-                                         ("    if (sub == 0) read_scsh(st1);\n", "    (void)st1;\n")] + VARIANTS["nod"]
+# timeline + phases in one launch (output stores kept): wave 0 = start, end, CU key, chunks; wave 1 = main loop start, end (100-MHz
+# ticks, low 24 bits), main-loop shader cycles, 0
+VARIANTS["full"] = [
+    ("  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    (PRE_LOOP, "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n" + PRE_LOOP),
+    ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
+     "  const long long lab_c2 = clock64(), lab_r2 = wall_clock64();\n  float* exb"),
+    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  if (lane == 0 && wave < 2) {\n    float* o = p.lab + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 2 + wave) * 4;\n"
+     "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
+     "    if (wave == 0) { o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = (float)nchunk; }\n"
+     "    else { o[0] = (float)(lab_r1 & 0xffffff); o[1] = (float)(lab_r2 & 0xffffff); o[2] = (float)(lab_c2 - lab_c1); o[3] = 0.f; }\n  }\n}\n\n// ACT: the operand"),
+]
+VARIANTS["full"] += [
+    ("  float* partials;      // [blocks][2][Cout] or nullptr", "  float* partials;\n  float* lab;"),
+    ("p.Y = Y; p.partials = partials;", "p.Y = Y; p.partials = partials; p.lab = g_lab;"),
+    ("constexpr int WN_THREADS = 512;\n", "float* g_lab = nullptr;\nconstexpr int WN_THREADS = 512;\n"),
+]
+VARIANTS["mfmaonly"] = VARIANTS["nob"] + VARIANTS["noraw"] + VARIANTS["nod"]
 
 
 def build(name):
@@ -71,6 +90,8 @@ def build(name):
         src = src.replace(old, new)
     os.makedirs(LAB, exist_ok=True)
     cpp = os.path.join(LAB, f"conv_wino_{name}.hip")
+    if name == "full":
+        src += '\nextern "C" void acvae_lab_set(float* p) { g_lab = p; }\n'
     open(cpp, "w").write(src.replace('#include "../../include/acvae_hip.h"', f'#include "{ROOT}/include/acvae_hip.h"'))
     obj = os.path.join(LAB, f"conv_wino_{name}.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-c", cpp, "-o", obj])
@@ -123,10 +144,47 @@ def time_one():
                   f"workgroup {sum(durs) / len(durs):.1f} us (max {max(durs):.1f}); gap between two on one CU {sum(gaps) / max(1, len(gaps)):.2f} us (max {max(gaps or [0]):.1f}); "
                   f"last end {float(en.max()):.1f} us; main loop {float(t[:, 3].floor().mean()) * 0.01:.1f} us real per workgroup [after {warm} warm-up launches]")
           continue
+        if os.environ.get("ACVAE_DEV_LIB", "").endswith("_full.so"):
+            import ctypes
+            nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
+            labbuf = torch.zeros(nwg, 2, 4, device="cuda")
+            raw = ctypes.CDLL(os.environ["ACVAE_DEV_LIB"])
+            raw.acvae_lab_set.argtypes = [ctypes.c_void_p]; raw.acvae_lab_set(labbuf.data_ptr())
+            for kind in ("dgrad", "fwd_act"):
+                if kind == "fwd_act" and Cin != Cout:
+                    continue
+                for _ in range(300):
+                    fns[kind]()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(20):
+                    fns[kind]()
+                b.record(); torch.cuda.synchronize()
+                t = labbuf.double().cpu()
+                t0 = float(t[:, 0, 0].min())
+                st, en, cu = (t[:, 0, 0] - t0) * 0.01, (t[:, 0, 1] - t0) * 0.01, t[:, 0, 2].long()
+                l0, l1, cyc = (t[:, 1, 0] - t0) * 0.01, (t[:, 1, 1] - t0) * 0.01, t[:, 1, 2]
+                nch = float(t[0, 0, 3])
+                cus = sorted(set(cu.tolist()))
+                per = {c: sorted((float(st[i]), float(en[i])) for i in range(nwg) if int(cu[i]) == c) for c in cus}
+                gaps = [b0 - a1 for v in per.values() for (a0, a1), (b0, b1) in zip(v, v[1:])]
+                counts = [len(v) for v in per.values()]
+                print(f"{Cin}->{Cout}@{W} {kind}: call {a.elapsed_time(b) * 50:.0f} us (mean of 20); {nwg} workgroups on {len(cus)} CUs ({min(counts)}..{max(counts)} per CU); "
+                      f"first start..last end {float(en.max()):.1f} us; workgroup {float((en - st).mean()):.1f} us = prologue {float((l0 - st).mean()):.1f} + main loop {float((l1 - l0).mean()):.1f} "
+                      f"+ epilogue {float((en - l1).mean()):.1f}; main loop {float(cyc.mean()):.0f} cycles = {float(cyc.mean()) / nch:.0f} per chunk, clock {float((cyc / ((l1 - l0) * 1e3)).mean()):.3f} GHz; "
+                      f"gap between two on one CU {sum(gaps) / max(1, len(gaps)):.2f} us (max {max(gaps or [0]):.1f}); start spread of the first round {sorted(st.tolist())[min(len(cus), nwg) - 1]:.1f} us")
+            continue
         if os.environ.get("ACVAE_DEV_LIB", "").endswith("_clock.so"):
             for _ in range(300):                      # the clock settles after a second or two of back-to-back launches
                 fns["dgrad"]()
             torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                fns["dgrad"]()
+            b.record(); torch.cuda.synchronize()
+            print(f"   call {a.elapsed_time(b) * 50:.0f} us (mean of 20 back to back)", end="; ")
             nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
             t = dx.reshape(-1)[:nwg * 32].reshape(nwg, 8, 4).double()
             cyc, real = t[:, :, 0].mean(), t[:, :, 1].mean()
