@@ -8,6 +8,9 @@
 // tanh-dot (wave64 shuffle reduction), scores/weights staged in LDS, context by E-strided lanes so
 // every enc row is read as full 128-B lines.
 #include "common.h"
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
 #include "../../include/acvae_hip.h"
 
 namespace {
@@ -30,7 +33,43 @@ __global__ __launch_bounds__(ATT_THREADS_BIG) void attn_fwd_kernel(
   const float* q = qproj + n * q_sn + j * q_sj;
   const float* P = encproj + (long)n * S * A;
   const int len = (int)lens[n];
-  // ---- scores: wave per frame, lanes over A
+  // ---- scores: wave per frame, lanes over A.  The loop is a chain of L2 round trips (one decode step: 12 frames per wavefront),
+  // so with A = 256 / 512 the encproj rows of four frames are fetched together; the arithmetic and its order are unchanged.
+  auto scores4 = [&](auto na) {
+    constexpr int NA = decltype(na)::value;            // A = 256 NA: every lane has NA float4 of a row, no tail conditions
+    float4 qr[NA], vr[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      qr[i] = *reinterpret_cast<const float4*>(q + lane * 4 + 256 * i);
+      vr[i] = *reinterpret_cast<const float4*>(v + lane * 4 + 256 * i);
+    }
+    for (int sb = wave; sb < S; sb += 4 * nw) {
+      float4 pr[4][NA];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = sb + u * nw;
+        const float* p = P + (long)(s < S ? s : sb) * A + lane * 4;       // past the end: a row that is there
+#pragma unroll
+        for (int i = 0; i < NA; ++i) pr[u][i] = *reinterpret_cast<const float4*>(p + 256 * i);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = sb + u * nw;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          acc += vr[i].x * tanh_att(qr[i].x + pr[u][i].x) + vr[i].y * tanh_att(qr[i].y + pr[u][i].y) +
+                 vr[i].z * tanh_att(qr[i].z + pr[u][i].z) + vr[i].w * tanh_att(qr[i].w + pr[u][i].w);
+        acc = wave_sum(acc);
+        if (lane == 0 && s < S) sc[s] = (s < len) ? acc : -1e10f;  // masked_fill(mask == 0, -1e10)
+      }
+    }
+  };
+  if (VEC && A == 512) {
+    scores4(std::integral_constant<int, 2>());
+  } else if (VEC && A == 256) {
+    scores4(std::integral_constant<int, 1>());
+  } else
   for (int s = wave; s < S; s += nw) {
     const float* p = P + (long)s * A;
     float acc = 0.f;
@@ -79,10 +118,21 @@ __global__ __launch_bounds__(ATT_THREADS_BIG) void attn_fwd_kernel(
     const int g = threadIdx.x / ev, e4 = (threadIdx.x - g * ev) * 4;
     if (g < G) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s0 = g; s0 < S; s0 += G) {
-        const float4 h = *reinterpret_cast<const float4*>(Hn + (long)s0 * E + e4);
-        const float w = sc[s0];
-        acc.x += w * h.x; acc.y += w * h.y; acc.z += w * h.z; acc.w += w * h.w;
+      for (int sb = g; sb < S; sb += 8 * G) {            // eight enc rows in flight; same order of accumulation
+        float4 h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s0 = sb + u * G;
+          h[u] = *reinterpret_cast<const float4*>(Hn + (long)(s0 < S ? s0 : sb) * E + e4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s0 = sb + u * G;
+          if (s0 < S) {
+            const float w = sc[s0];
+            acc.x += w * h[u].x; acc.y += w * h[u].y; acc.z += w * h[u].z; acc.w += w * h[u].w;
+          }
+        }
       }
       *reinterpret_cast<float4*>(part + (long)g * E + e4) = acc;
     }
@@ -99,6 +149,191 @@ __global__ __launch_bounds__(ATT_THREADS_BIG) void attn_fwd_kernel(
       c[e] = acc;
     }
   }
+}
+
+// ---------------------------------------------------------------- few query rows: the frames split over workgroups
+// One decode step (step API, beam search, sampled decode) has N * Tq = 16..160 query rows: with a workgroup per row most of
+// the 256 CUs idle and each wavefront walks a dozen frames one load round trip after the other (27 us at N = 16, S = 187,
+// profiles/r02_c4_t3000.json).  Here a row's S frames are split over `nsplit` workgroups of ATS_CHUNK frames or fewer (all loads of a
+// workgroup are in flight at once) and the softmax is combined from per-split (max, sum, unnormalised context):
+//   split k: m_k = max_s score, e_s = exp(score - m_k), l_k = sum e_s, c_k = sum e_s enc_s
+//   row    : M = max m_k, L = sum_k l_k exp(m_k - M), weights_s = e_s exp(m_k - M) / L, ctx = sum_k c_k exp(m_k - M) / L
+// The workgroup that arrives last at the row's counter does the combine, reading the splits in index order: the result does
+// not depend on which one that is.  The partials travel as write-through stores / L1-bypassing loads (relaxed agent-scope
+// atomics: sc1), ordered by s_waitcnt vmcnt(0) + barrier + the counter's atomic - no L2 write-back / invalidate.
+constexpr int ATS_THREADS = 256;
+constexpr int ATS_CHUNK = 16;           // frames per split: four per wavefront
+#define ATS_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ void ats_st(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), ATS_RLX_AGENT);
+}
+__device__ __forceinline__ float ats_ld(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), ATS_RLX_AGENT));
+}
+
+__global__ __launch_bounds__(ATS_THREADS) void attn_fwd_split_kernel(
+    const float* __restrict__ qproj, long q_sn, long q_sj, const float* __restrict__ encproj,
+    const float* __restrict__ enc, const int64_t* __restrict__ lens, const float* __restrict__ v,
+    float* __restrict__ ctx, long c_sn, long c_sj, float* __restrict__ weights, long w_sn, long w_sj, int Tq, int S,
+    int A, int E, int nsplit, float* __restrict__ part, unsigned* __restrict__ cnt) {
+  extern __shared__ float smem[];            // [ATS_CHUNK] e_s | [16] reduction scratch | [nsplit] factors | [G][E] context partials
+  float* sc = smem;
+  float* red = smem + ATS_CHUNK;
+  float* fac = red + 16;
+  float* cpart = fac + ((nsplit + 3) & ~3);
+  __shared__ int s_last;
+  const int row = blockIdx.x / nsplit, sp = blockIdx.x - row * nsplit;
+  const int n = row / Tq, j = row - n * Tq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = sp * ATS_CHUNK, ns = min(ATS_CHUNK, S - s0);
+  const float* q = qproj + n * q_sn + j * q_sj;
+  const float* P = encproj + ((long)n * S + s0) * A;
+  const float* Hn = enc + ((long)n * S + s0) * E;
+  const int len = (int)lens[n];
+  // context operands first: they depend on nothing (E/4 threads per frame, G frames at a time), at most ATS_CHUNK / G in flight
+  const int ev = E >> 2, G = ATS_THREADS / ev;
+  const int g = tid / ev, e4 = (tid - g * ev) * 4;
+  constexpr int HMAX = 8;                    // frames per thread group kept in registers (G >= 2: E <= 512)
+  float4 hreg[HMAX];
+  const bool hregs = g < G && ATS_CHUNK <= HMAX * G;
+  if (hregs) {
+#pragma unroll
+    for (int i = 0; i < HMAX; ++i) {
+      const int s = g + i * G;
+      hreg[i] = s < ns ? *reinterpret_cast<const float4*>(Hn + (long)s * E + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // ---- scores of this split: wave per frame, two frames per pass
+  for (int s = wave; s < ns; s += 8) {
+    const bool two = s + 4 < ns;
+    const float* p0 = P + (long)s * A;
+    const float* p1 = P + (long)(two ? s + 4 : s) * A;
+    float a0 = 0.f, a1 = 0.f;
+    for (int a = lane * 4; a < A; a += 256) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p0 + a);
+      const float4 x1 = *reinterpret_cast<const float4*>(p1 + a);
+      const float4 qv = *reinterpret_cast<const float4*>(q + a);
+      const float4 vv = *reinterpret_cast<const float4*>(v + a);
+      a0 += vv.x * tanh_att(qv.x + x0.x) + vv.y * tanh_att(qv.y + x0.y) + vv.z * tanh_att(qv.z + x0.z) +
+            vv.w * tanh_att(qv.w + x0.w);
+      a1 += vv.x * tanh_att(qv.x + x1.x) + vv.y * tanh_att(qv.y + x1.y) + vv.z * tanh_att(qv.z + x1.z) +
+            vv.w * tanh_att(qv.w + x1.w);
+    }
+    a0 = row16_sum(a0);                                  // four DPP adds, then two LDS-pipe shuffles across the rows
+    a1 = row16_sum(a1);
+    a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64);
+    a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
+    if (lane == 0) {
+      sc[s] = (s0 + s < len) ? a0 : -1e10f;            // masked_fill(mask == 0, -1e10)
+      if (two) sc[s + 4] = (s0 + s + 4 < len) ? a1 : -1e10f;
+    }
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int s = 0; s < ns; ++s) m = fmaxf(m, sc[s]);     // ns <= 16 LDS broadcasts: cheaper than a block reduction
+  float l = 0.f;
+  for (int s = 0; s < ns; ++s) l += expf(sc[s] - m);
+  __syncthreads();
+  if (tid < ns) sc[tid] = expf(sc[tid] - m);
+  __syncthreads();
+  float* wout = weights + n * w_sn + j * w_sj + s0;
+  if (tid < ns) ats_st(wout + tid, sc[tid]);
+  // ---- unnormalised context of this split
+  if (g < G) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hregs) {
+#pragma unroll
+      for (int i = 0; i < HMAX; ++i) {
+        const int s = g + i * G;
+        const float w = s < ns ? sc[s] : 0.f;
+        acc.x += w * hreg[i].x; acc.y += w * hreg[i].y; acc.z += w * hreg[i].z; acc.w += w * hreg[i].w;
+      }
+    } else {
+      for (int s = g; s < ns; s += G) {
+        const float4 h = *reinterpret_cast<const float4*>(Hn + (long)s * E + e4);
+        const float w = sc[s];
+        acc.x += w * h.x; acc.y += w * h.y; acc.z += w * h.z; acc.w += w * h.w;
+      }
+    }
+    *reinterpret_cast<float4*>(cpart + (long)g * E + e4) = acc;
+  }
+  __syncthreads();
+  float* mine = part + ((long)row * nsplit + sp) * (E + 4);
+  for (int e = tid; e < E; e += ATS_THREADS) {
+    float acc = 0.f;
+    for (int k = 0; k < G; ++k) acc += cpart[(long)k * E + e];
+    ats_st(mine + e, acc);
+  }
+  if (tid == 0) { ats_st(mine + E, m); ats_st(mine + E + 1, l); }
+  // ---- arrive; the last workgroup of the row combines
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(cnt + row, 1u, ATS_RLX_AGENT) == (unsigned)(nsplit - 1);
+  __syncthreads();
+  if (!s_last) return;
+  // Everything the combine reads is fetched in ONE round trip (the stores above were write-through, so these loads go to the
+  // memory side: ~1-2 us each way): thread k < nsplit takes (m_k, l_k), the first E/4 threads the context partials of up to
+  // ATS_KB splits as float4 (registers), every thread its share of the e_s.
+  const float* rowpart = part + (long)row * nsplit * (E + 4);
+  float* wrow = weights + n * w_sn + j * w_sj;
+  float* mk = cpart;                 // [nsplit] maxima, then [nsplit] sums (cpart is free again)
+  float* lk = cpart + nsplit;
+  constexpr int ATS_KB = 12;
+  float4 pk[ATS_KB];
+  const bool cth = tid < ev;
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowpart), 0, 0x7fffffff, 0x00020000);
+  auto ld4 = [&](int k) {
+    typedef unsigned ats_v4u __attribute__((ext_vector_type(4)));
+    const ats_v4u r = __builtin_amdgcn_raw_buffer_load_b128(prs, (k * (E + 4) + tid * 4) * 4, 0, 16 /* sc1 */);
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+  };
+  if (cth) {
+#pragma unroll
+    for (int kk = 0; kk < ATS_KB; ++kk) pk[kk] = kk < nsplit ? ld4(kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float es[2];
+  es[0] = tid < S ? ats_ld(wrow + tid) : 0.f;
+  es[1] = tid + ATS_THREADS < S ? ats_ld(wrow + tid + ATS_THREADS) : 0.f;
+  for (int k = tid; k < nsplit; k += ATS_THREADS) {
+    mk[k] = ats_ld(rowpart + (long)k * (E + 4) + E);
+    lk[k] = ats_ld(rowpart + (long)k * (E + 4) + E + 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float M = -INFINITY;
+    for (int k = 0; k < nsplit; ++k) M = fmaxf(M, mk[k]);
+    float L = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+      const float f = expf(mk[k] - M);
+      fac[k] = f;
+      L += lk[k] * f;
+    }
+    const float inv = 1.f / L;
+    for (int k = 0; k < nsplit; ++k) fac[k] *= inv;
+    __hip_atomic_store(cnt + row, 0u, ATS_RLX_AGENT);        // ready for the next launch on this stream
+  }
+  __syncthreads();
+  if (cth) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kk = 0; kk < ATS_KB; ++kk) {
+      const float f = kk < nsplit ? fac[kk] : 0.f;
+      acc.x += f * pk[kk].x; acc.y += f * pk[kk].y; acc.z += f * pk[kk].z; acc.w += f * pk[kk].w;
+    }
+    for (int k0 = ATS_KB; k0 < nsplit; k0 += ATS_KB) {        // S > 192: further batches, one round trip each
+#pragma unroll
+      for (int kk = 0; kk < ATS_KB; ++kk) pk[kk] = k0 + kk < nsplit ? ld4(k0 + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int kk = 0; kk < ATS_KB; ++kk) {
+        const float f = k0 + kk < nsplit ? fac[k0 + kk] : 0.f;
+        acc.x += f * pk[kk].x; acc.y += f * pk[kk].y; acc.z += f * pk[kk].z; acc.w += f * pk[kk].w;
+      }
+    }
+    *reinterpret_cast<float4*>(ctx + n * c_sn + j * c_sj + tid * 4) = acc;
+  }
+  if (tid < S) wrow[tid] = es[0] * fac[tid / ATS_CHUNK];
+  if (tid + ATS_THREADS < S) wrow[tid + ATS_THREADS] = es[1] * fac[(tid + ATS_THREADS) / ATS_CHUNK];
+  for (int s2 = tid + 2 * ATS_THREADS; s2 < S; s2 += ATS_THREADS) wrow[s2] = ats_ld(wrow + s2) * fac[s2 / ATS_CHUNK];
 }
 
 // Backward in three launches (all deterministic, no atomics):
@@ -255,7 +490,37 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ dq_part, const 
   }
 }
 
+// Scratch of the split kernel, one per HIP stream (calls on different streams run side by side: the prior chain and the
+// decoder chain of a decode step): [rows][nsplit][E + 4] partials (context, max, sum, pad) and a counter per row, zero between launches (the
+// combining workgroup resets it).  Grown on demand; hipFree synchronises the device, so nothing still reads the old one.
+struct AttnSplitScratch { float* part = nullptr; unsigned* cnt = nullptr; size_t part_floats = 0; long rows = 0; };
+bool g_attn_split = true;
+AttnSplitScratch* attn_split_scratch(hipStream_t st, long rows, int nsplit, int E) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, AttnSplitScratch> reg;
+  std::lock_guard<std::mutex> lock(mu);
+  AttnSplitScratch& sc = reg[st];
+  const size_t need = (size_t)rows * nsplit * (E + 4);
+  if (need > sc.part_floats) {
+    if (sc.part) (void)hipFree(sc.part);
+    sc.part = nullptr; sc.part_floats = 0;
+    if (hipMalloc(&sc.part, need * sizeof(float)) != hipSuccess) return nullptr;
+    sc.part_floats = need;
+  }
+  if (rows > sc.rows) {
+    if (sc.cnt) (void)hipFree(sc.cnt);
+    sc.cnt = nullptr; sc.rows = 0;
+    const long nr = rows < 256 ? 256 : rows;
+    if (hipMalloc(&sc.cnt, nr * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(sc.cnt, 0, nr * sizeof(unsigned)) != hipSuccess) return nullptr;
+    sc.rows = nr;
+  }
+  return &sc;
+}
+
 }  // namespace
+
+extern "C" int acvae_set_attn_split(int on) { const int was = g_attn_split ? 1 : 0; g_attn_split = on != 0; return was; }
 
 extern "C" int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, const float* encproj, const float* enc,
                               const int64_t* lens, const float* v, float* ctx, int64_t c_sn, int64_t c_sj,
@@ -268,6 +533,21 @@ extern "C" int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, co
     return ACVAE_EALIGN;
   const int threads = (long)N * Tq < 256 ? ATT_THREADS_BIG : ATT_THREADS;
   const bool vec = (A & 3) == 0 && (E & 3) == 0 && E / 4 <= threads && aligned16(enc);
+  // few rows and more than one chunk of frames: split S over workgroups (see attn_fwd_split_kernel)
+  const int nsplit = (S + ATS_CHUNK - 1) / ATS_CHUNK;
+  if (g_attn_split && vec && (long)N * Tq * 2 <= 256 && nsplit >= 2 && nsplit <= 512 && E / 4 <= ATS_THREADS && aligned16(ctx) &&
+      (c_sn & 3) == 0 && (c_sj & 3) == 0) {
+    AttnSplitScratch* sc = attn_split_scratch((hipStream_t)stream, (long)N * Tq, nsplit, E);
+    if (!sc) return ACVAE_EWORKSPACE;
+    const int G = ATS_THREADS / (E / 4);
+    const size_t shm = (size_t)(ATS_CHUNK + 16 + ((nsplit + 3) & ~3) + (long)G * E) * sizeof(float);
+    if (shm <= 64 * 1024) {
+      hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(N * Tq * nsplit), dim3(ATS_THREADS), shm, (hipStream_t)stream, qproj, q_sn,
+                         q_sj, encproj, enc, lens, v, ctx, c_sn, c_sj, weights, w_sn, w_sj, Tq, S, A, E, nsplit, sc->part, sc->cnt);
+      ACVAE_LAUNCH_CHECK();
+      return ACVAE_OK;
+    }
+  }
   const int groups = vec ? threads / (E / 4) : 0;
   const size_t shm = (size_t)(((S + 16 + 3) & ~3) + (long)groups * E) * sizeof(float);
   if (shm > 64 * 1024) return ACVAE_EUNSUPPORTED;

@@ -56,6 +56,19 @@ __device__ __forceinline__ void store4(bf16_t* p, float4 v) {
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const bf16_t* p) { return (float)*p; }
 
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), total in every lane of the row: four v_add_f32 with a DPP
+// operand (xor 1, xor 2 inside the quad, then half-mirror / mirror: the partner quad / half holds one value in all its
+// lanes by then, so the result is bit-identical to the xor butterfly) - VALU only, where __shfl_xor is a ds_bpermute_b32
+// on the LDS pipe.
+__device__ __forceinline__ float row16_sum(float v) {
+#define ACVAE_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+  ACVAE_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  ACVAE_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  ACVAE_DPP_ADD(0x141);   // row_half_mirror
+  ACVAE_DPP_ADD(0x140);   // row_mirror
+#undef ACVAE_DPP_ADD
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

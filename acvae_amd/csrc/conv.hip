@@ -799,11 +799,7 @@ __global__ __launch_bounds__(256) void conv1_first_bwd_kernel(const float* __res
       for (int k = 0; k < 9; ++k) d[k] = gv[0] * wreg[0][k] + gv[1] * wreg[1][k] + gv[2] * wreg[2][k] + gv[3] * wreg[3][k];
       // reduce over the 16 cout-quads (16 consecutive lanes)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        float v = d[k];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-        d[k] = v;
-      }
+      for (int k = 0; k < 9; ++k) d[k] = row16_sum(d[k]);
       if (cq == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) D[(r * 64 + w) * 9 + k] = d[k];

@@ -54,6 +54,10 @@ int acvae_transpose(const float* in, int64_t ld_in, float* out, int64_t ld_out, 
  * batch-major [N,Tc,.] buffers).  score = v . tanh(qproj + encproj), positions s >= lens[n] get
  * -1e10 before the softmax (attn_model.py:41), ctx = sum_s w_s h_enc[n,s].
  * ------------------------------------------------------------------------------------------- */
+/* acvae_attn_fwd with N * Tq <= 128 query rows and S > 16 splits the frames of a row over workgroups (one decode step of the
+ * step API / beam search / sampled decode; results equal to the one-workgroup form up to the summation order of the softmax
+ * denominator and the context).  0 switches that form off (tests, A/B timing). */
+int acvae_set_attn_split(int on);
 int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, const float* encproj, const float* enc,
                    const int64_t* lens, const float* v, float* ctx, int64_t c_sn, int64_t c_sj, float* weights,
                    int64_t w_sn, int64_t w_sj, int N, int Tq, int S, int A, int E, void* stream);

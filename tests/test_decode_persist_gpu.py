@@ -41,6 +41,9 @@ def batch(B, T, V, L, seed):
 
 def run(model, V, E, feats, caps, fl, cl, eps_q, eps_p, persist):
     prev = _lib.lib().acvae_set_decode_persist(1 if persist else 0)
+    # the per-step reference with one workgroup per attention row: the persistent kernel restates THAT arithmetic bit for bit
+    # (the split-over-frames form of acvae_attn_fwd combines the softmax in another order)
+    prev_split = _lib.lib().acvae_set_attn_split(0)
     try:
         for p in model.parameters():
             p.grad = None
@@ -61,6 +64,7 @@ def run(model, V, E, feats, caps, fl, cl, eps_q, eps_p, persist):
         return keep, grads
     finally:
         _lib.lib().acvae_set_decode_persist(1 if prev != 0 else 0)
+        _lib.lib().acvae_set_attn_split(prev_split)
 
 
 @pytest.mark.parametrize("B,T,V,E,L", [(32, 1000, 5000, 512, 22), (16, 3000, 5000, 512, 22), (5, 200, 300, 512, 9),

@@ -234,3 +234,47 @@ def mse_check(out):
     da = torch.empty(33, 70, device="cuda"); db = torch.empty(33, 70, device="cuda")
     _lib.call("acvae_mse_bwd", dev(a), dev(b), torch.tensor([2.0], device="cuda"), da, db, a.numel(), S())
     close(da, 2.0 * 2 * (a - b) / a.numel(), 1e-5, 1e-8); close(db, -da.cpu(), 0, 0)
+
+
+@pytest.mark.parametrize("N,Tq,S_,A,E", [(16, 1, 187, 512, 512), (5, 3, 33, 64, 128), (3, 1, 17, 64, 64), (32, 2, 62, 512, 512),
+                                         (2, 1, 300, 96, 256)])
+def test_attention_split_over_frames_matches_one_workgroup_per_row(N, Tq, S_, A, E):
+    """acvae_attn_fwd with few query rows splits a row's frames over workgroups and combines the per-split softmax pieces
+    (models/attn_model.py:29-45 is one softmax over S): against the one-workgroup-per-row kernel (switched by
+    acvae_set_attn_split) on ragged lengths - weights and context to fp32 summation-order tolerance, masked frames exactly 0,
+    rows summing to 1; twice in a row and on two streams at once (the per-stream scratch and its self-resetting counters)."""
+    g = torch.Generator().manual_seed(N * 1000 + S_)
+    f = lambda *s: torch.randn(*s, generator=g).cuda()
+    q, p, e, v = f(N, Tq, A), f(N, S_, A), f(N, S_, E), f(A)
+    lens = torch.randint(1, S_ + 1, (N,), generator=g); lens[0] = S_
+    if N > 2:
+        lens[1] = 1
+    lens_d = lens.cuda()
+    def run(stream=None):
+        c, w = torch.empty(N, Tq, E, device="cuda"), torch.empty(N, Tq, S_, device="cuda")
+        st = S() if stream is None else stream.cuda_stream
+        _lib.call("acvae_attn_fwd", q, Tq * A, A, p, e, lens_d, v, c, Tq * E, E, w, Tq * S_, S_, N, Tq, S_, A, E, st)
+        return c, w
+    was = _lib.lib().acvae_set_attn_split(0)
+    try:
+        c0, w0 = run()
+    finally:
+        _lib.lib().acvae_set_attn_split(1)
+    try:
+        c1, w1 = run()
+        c2, w2 = run()
+        torch.cuda.synchronize()
+        s2 = torch.cuda.Stream()
+        s2.wait_stream(torch.cuda.current_stream())
+        c3, w3 = run(s2)
+        c4, w4 = run()
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().acvae_set_attn_split(was)
+    for c, w in ((c1, w1), (c2, w2), (c3, w3), (c4, w4)):
+        assert torch.equal(c, c1) and torch.equal(w, w1)              # the same arithmetic whichever workgroup combines
+        torch.testing.assert_close(w, w0, rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(c, c0, rtol=1e-4, atol=2e-6)
+        for n in range(N):
+            assert float(w[n, :, int(lens[n]):].abs().max()) == 0.0 if int(lens[n]) < S_ else True
+        torch.testing.assert_close(w.sum(-1), torch.ones(N, Tq, device="cuda"), rtol=0, atol=1e-5)

@@ -1,11 +1,11 @@
 """Driver-visible records of BASELINE configs[3] and configs[4], written as JSON under gpurun_out/
 (copy into profiles/):
 
-  r02_c4_t3000.json  configs[3]: long-audio stress B=16, T=3000 (S=187 encoder frames): full optimiser step ms (fp32 and
+  r03_c4_t3000.json  configs[3]: long-audio stress B=16, T=3000 (S=187 encoder frames): full optimiser step ms (fp32 and
                      bf16 conv stack) and the attention kernels' achieved bytes/s - per decode step the decoder attention
                      reads, for each of the 16 clips, encproj [S,A] + mem [S,E] fp32 once (2 * 187 * 512 * 4 B = 766 KB per
                      clip and step, served by L2 / Infinity Cache), measured with HIP events around acvae_attn_fwd / _bwd.
-  r02_infer.json     configs[4]: captions/s of the inference twin through evaluate(): greedy, N=5 z-samples per clip,
+  r03_infer_records.json     configs[4]: captions/s of the inference twin through evaluate(): greedy, N=5 z-samples per clip,
                      beam (3), diverse beam search (5 groups), and method="sample".
 """
 import json, os, sys, time
@@ -32,7 +32,7 @@ def c4():
     fl, cl = np.full(B, T), np.full(B, L)
     rec = {"config": "BASELINE configs[3]: B=16, T=3000, F=64 (S=187), vocab 5000, E=H=A=512, 22-token captions; full "
                      "optimiser step", "steps": 12, "warmup": 4}
-    for dt in ("f32", "bf16"):
+    for dt in (() if which == "attn" else ("f32", "bf16")):
         model = bench.build_model().cuda().train()
         ts = TrainStep(model, V, precision=dt)
         for _ in range(4):
@@ -62,7 +62,12 @@ def c4():
     def bwd():
         _lib.call("acvae_attn_bwd", dctx, E, E, qproj, A, A, encproj, enc, lens, v, w, S, S, dq, A, A, dencp, denc, dv, ws,
                   wsb, N, 1, S, A, E, st)
+    def fwd_one_wg():
+        was = _lib.lib().acvae_set_attn_split(0)
+        fwd()
+        _lib.lib().acvae_set_attn_split(was)
     for name, fn, nbytes in (("attn_fwd", fwd, N * S * (A + E) * 4),
+                             ("attn_fwd_one_workgroup_per_row", fwd_one_wg, N * S * (A + E) * 4),
                              ("attn_bwd", bwd, N * S * (2 * A + 3 * E) * 4)):     # bwd: reads encproj, enc; r/w dencproj, denc
         for _ in range(5):
             fn()
@@ -75,7 +80,22 @@ def c4():
         rec[name] = {"us_per_call": us, "algorithmic_bytes": nbytes, "GB_per_s": nbytes / us / 1e3,
                      "note": "one decode step, 16 clips x S=187, back-to-back calls (operands L2 / Infinity-Cache resident: "
                              "12.3 MB); roofline: L2 ~34 TB/s aggregate, HBM 8 TB/s - the call is latency-bound at this size"}
-    json.dump(rec, open(os.path.join(OUT, "r02_c4_t3000.json"), "w"), indent=1)
+    # us_per_call above is bounded by the host (a ctypes call with 19 arguments every ~15 us); the kernels' own durations come
+    # from a rocprofv3 --kernel-trace --stats run of `bench_records.py attn` (ATTN_KERNEL_STATS = its kernel_stats.csv)
+    stats = os.environ.get("ATTN_KERNEL_STATS")
+    if stats and os.path.exists(stats):
+        import csv
+        for r in csv.DictReader(open(stats)):
+            for key, pat in (("attn_fwd", "attn_fwd_split_kernel"), ("attn_fwd_one_workgroup_per_row", "attn_fwd_kernel<"),
+                             ("attn_bwd_score", "attn_bwd_score_kernel"), ("attn_bwd_accum", "attn_bwd_accum_kernel"),
+                             ("attn_bwd_reduce", "attn_bwd_reduce_kernel")):
+                if pat in r["Name"]:
+                    d = rec.setdefault(key, {})
+                    d["kernel_us"] = float(r["AverageNs"]) / 1e3
+                    d["kernel_calls"] = int(r["Calls"])
+                    if "algorithmic_bytes" in d:
+                        d["kernel_GB_per_s"] = d["algorithmic_bytes"] / d["kernel_us"] / 1e3
+    json.dump(rec, open(os.path.join(OUT, "r03_c4_attn_only.json" if which == "attn" else "r03_c4_t3000.json"), "w"), indent=1)
     print(json.dumps(rec))
 
 
@@ -100,11 +120,11 @@ def infer():
         ncap = sum(len(p.get("captions", [0])) for p in out["predictions"])
         rec["runs"].append({"method": method, "beam_size_or_samples": bs, **extra, "clips": len(n_items), "captions": ncap,
                             "seconds": dt, "clips_per_s": len(n_items) / dt, "captions_per_s": ncap / dt})
-    json.dump(rec, open(os.path.join(OUT, "r02_infer.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(OUT, "r03_infer_records.json"), "w"), indent=1)
     print(json.dumps(rec))
 
 
-if which in ("all", "c4"):
+if which in ("all", "c4", "attn"):
     c4()
 if which in ("all", "infer"):
     infer()

@@ -80,6 +80,27 @@ VARIANTS["full"] += [
     ("constexpr int WN_THREADS = 512;\n", "float* g_lab = nullptr;\nconstexpr int WN_THREADS = 512;\n"),
 ]
 VARIANTS["mfmaonly"] = VARIANTS["nob"] + VARIANTS["noraw"] + VARIANTS["nod"]
+# no transforms either: what the bare MFMA stream (plus barrier and loop control) takes
+NOTRANS = [("    wino_htrans_ip(t1, v1);\n", "#pragma unroll\n    for (int j = 0; j < 4; ++j) v1[j] = t1[j];\n"),
+           ("    vertical(d0, d1, d2);\n", ""),
+           ("    wino_htrans_ip(d0, v0);\n#pragma unroll\n    for (int j = 0; j < 4; ++j) t1[j] = d1[j];\n    WN_SB();\n    if (sub == 0)",
+            "#pragma unroll\n    for (int j = 0; j < 4; ++j) { v0[j] = d0[j]; t1[j] = d1[j]; }\n    WN_SB();\n    if (sub == 0)")]
+VARIANTS["puremfma"] = VARIANTS["mfmaonly"] + NOTRANS
+VARIANTS["notrans"] = NOTRANS
+# scalar v_add_f32 / v_sub_f32 instead of the packed forms (twice the instructions)
+VARIANTS["scalar"] = [
+    ('  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3") : "+v"(lo), "+v"(hi) : "v"(f32x2{b.x, b.y}), "v"(f32x2{b.z, b.w}));\n  a = make_float4(lo[0], lo[1], hi[0], hi[1]);',
+     '  (void)lo; (void)hi; a = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);'),
+    ('  asm(WN_PK_ADD("%0", "%0", "%2") WN_PK_ADD("%1", "%1", "%3") : "+v"(lo), "+v"(hi) : "v"(f32x2{b.x, b.y}), "v"(f32x2{b.z, b.w}));\n  a = make_float4(lo[0], lo[1], hi[0], hi[1]);',
+     '  (void)lo; (void)hi; a = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);'),
+    ('  f32x2 n0, n1;\n  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3")          // t0 - t2',
+     '  f32x2 n0, n1;\n  { const float4 T0 = t[0], T1 = t[1], T2 = t[2], T3 = t[3];\n'
+     '    v[0] = make_float4(T0.x - T2.x, T0.y - T2.y, T0.z - T2.z, T0.w - T2.w); v[1] = make_float4(T1.x + T2.x, T1.y + T2.y, T1.z + T2.z, T1.w + T2.w);\n'
+     '    v[2] = make_float4(T2.x - T1.x, T2.y - T1.y, T2.z - T1.z, T2.w - T1.w); v[3] = make_float4(T1.x - T3.x, T1.y - T3.y, T1.z - T3.z, T1.w - T3.w);\n'
+     '    (void)a0; (void)a1; (void)c0; (void)c1; (void)e0; (void)e1; (void)n0; (void)n1; return; }\n'
+     '  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3")          // t0 - t2'),
+]
+VARIANT_FLAGS = {"scalar": ["-fno-slp-vectorize"]}
 
 
 def build(name):
@@ -94,7 +115,7 @@ def build(name):
         src += '\nextern "C" void acvae_lab_set(float* p) { g_lab = p; }\n'
     open(cpp, "w").write(src.replace('#include "../../include/acvae_hip.h"', f'#include "{ROOT}/include/acvae_hip.h"'))
     obj = os.path.join(LAB, f"conv_wino_{name}.o")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-c", cpp, "-o", obj])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *globals().get("VARIANT_FLAGS", {}).get(name, []), "-c", cpp, "-o", obj])
     objs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".o") and f != "conv_wino.o"]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                            os.path.join(LAB, f"libacvae_{name}.so"), obj, *objs])
