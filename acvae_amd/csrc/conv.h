@@ -36,6 +36,13 @@ bool conv3x3_wino_ok(int H, int W, int Cin, int Cout);
 long conv3x3_wino_weight_floats(int Cin, int Cout);
 int conv_wino_partials_rows(int N, int H, int W);
 int conv3x3_wino_weights(const float* W_oihw, float* U, int Cout, int Cin, bool dgrad, hipStream_t st);
+// several images in one launch (fill W, U, Cout, Cin, dgrad and n; start is computed)
+struct WinoWeightsBatch {
+  static constexpr int MAXL = 32;
+  const float* W[MAXL]; float* U[MAXL]; int Cout[MAXL], Cin[MAXL], dgrad[MAXL]; long start[MAXL + 1]; int n = 0;
+  void add(const float* w, float* u, int cout, int cin, bool dg) { W[n] = w; U[n] = u; Cout[n] = cout; Cin[n] = cin; dgrad[n] = dg ? 1 : 0; ++n; }
+};
+int conv3x3_wino_weights_batch(WinoWeightsBatch& b, hipStream_t st);
 int conv3x3_wino(const float* X, const float* scale, const float* shift, const float* U, float* Y, float* partials, int N,
                  int H, int W, int Cin, int Cout, hipStream_t st);
 bool conv3x3_wino_wgrad_ok(int H, int W, int Cin, int Cout);

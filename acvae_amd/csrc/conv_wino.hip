@@ -480,10 +480,11 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_act_kernel(WinoParams p)
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
 //   [output block of 64][8-channel chunk][position 16][k half 2][column 64][4 channels]
 // dgrad: the data gradient's filter is the forward one flipped and transposed (its input channels are the layer's outputs)
-__global__ void wino_weights_kernel(const float* __restrict__ Wt, float4* __restrict__ U, int Cout, int Cin, int dgrad) {
+// one (output channel, input-channel quad) item of a layer's image
+__device__ __forceinline__ void wino_weights_item(const float* __restrict__ Wt, float4* __restrict__ U, int Cout, int Cin, int dgrad,
+                                                  long idx) {
   const int K = dgrad ? Cout : Cin, NO = dgrad ? Cin : Cout;
-  const long total = (long)NO * (K >> 2);
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  {
     const int out = (int)(idx % NO), kq = (int)(idx / NO);
     float u[16][4];
 #pragma unroll
@@ -518,6 +519,22 @@ __global__ void wino_weights_kernel(const float* __restrict__ Wt, float4* __rest
     for (int pos = 0; pos < 16; ++pos) dst[(long)pos * 128] = make_float4(u[pos][0], u[pos][1], u[pos][2], u[pos][3]);
   }
 }
+__global__ void wino_weights_kernel(const float* __restrict__ Wt, float4* __restrict__ U, int Cout, int Cin, int dgrad) {
+  const int K = dgrad ? Cout : Cin, NO = dgrad ? Cin : Cout;
+  const long total = (long)NO * (K >> 2);
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+    wino_weights_item(Wt, U, Cout, Cin, dgrad, idx);
+}
+// The images of several layers (forward and / or data gradient) in ONE launch: the encoder builds all of a step's images in
+// front of its first convolution instead of one 8-12 us launch in front of each of the 14 convolutions.
+__global__ void wino_weights_batch_kernel(acvae::WinoWeightsBatch b) {
+  const long total = b.start[b.n];
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < b.n && idx >= b.start[l + 1]) ++l;
+    wino_weights_item(b.W[l], reinterpret_cast<float4*>(b.U[l]), b.Cout[l], b.Cin[l], b.dgrad[l], idx - b.start[l]);
+  }
+}
 
 inline int tile_rows_per_block(int W) { return WN_TILES / (W / 2); }
 }  // namespace
@@ -538,6 +555,21 @@ int conv3x3_wino_weights(const float* W_oihw, float* U, int Cout, int Cin, bool 
   const long total = (long)NO * (K / 4);
   hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)), dim3(256), 0, st, W_oihw,
                      reinterpret_cast<float4*>(U), Cout, Cin, dgrad ? 1 : 0);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+int conv3x3_wino_weights_batch(WinoWeightsBatch& b, hipStream_t st) {
+  if (b.n <= 0) return ACVAE_OK;
+  b.start[0] = 0;
+  for (int l = 0; l < b.n; ++l) {
+    if (!b.W[l] || !b.U[l]) return ACVAE_EINVAL;
+    const int K = b.dgrad[l] ? b.Cout[l] : b.Cin[l], NO = b.dgrad[l] ? b.Cin[l] : b.Cout[l];
+    if (K % 16 != 0 || NO % WN_TN != 0) return ACVAE_EUNSUPPORTED;
+    b.start[l + 1] = b.start[l] + (long)NO * (K / 4);
+  }
+  const long total = b.start[b.n];
+  hipLaunchKernelGGL(wino_weights_batch_kernel, dim3(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256)), dim3(256), 0, st, b);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

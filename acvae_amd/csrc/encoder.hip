@@ -39,6 +39,7 @@ struct EncLayout {
   int H[kMaxBlocks + 1], W[kMaxBlocks + 1];    // conv spatial dims of block b (1..nb); [0] = dims after the last block
   long y1[kMaxBlocks + 1], y2[kMaxBlocks + 1], p[kMaxBlocks + 1];     // float offsets into `saved`
   long wf1[kMaxBlocks + 1], wf2[kMaxBlocks + 1];
+  long wd1[kMaxBlocks + 1], wd2[kMaxBlocks + 1];   // fp32: Winograd images of the data gradient's filters (built with the forward's)
   long bn[2 * kMaxBlocks + 1];  // each: 4*C floats (scale, shift, mean, invstd); 0 = bn0, 1+2*(b-1)+{0,1} = block b bn1/bn2
   long pooled_in;
   long total;
@@ -71,6 +72,11 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
     const long wtaps = esz == 4 ? 16 : 9;      // fp32: room for the 16 Winograd positions of conv_wino.hip
     L.wf1[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b - 1]));
     L.wf2[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b]));
+    L.wd1[b] = L.wd2[b] = -1;
+    if (esz == 4) {
+      L.wd1[b] = off; off = align4(off + (long)kChan[b] * 16 * kChan[b - 1]);
+      L.wd2[b] = off; off = align4(off + (long)kChan[b] * 16 * kChan[b]);
+    }
     if (act > max_act) max_act = act;
     if (pool > max_pool) max_pool = pool;
     const long part = (long)acvae::conv_partials_rows(N, h, w) * 2 * kChan[b];
@@ -137,10 +143,10 @@ inline int p_fc_b(int nb) { return 6 + nb * 12; }
 // Y = conv3x3(act(X), W): weights repacked / transformed into `wbuf`, BN partial rows returned in *nparts
 template <class TA>
 int conv_fwd(const TA* X, const float* scale, const float* shift, const float* W_oihw, float* wbuf, TA* Y, float* partials,
-             int N, int H, int W, int Cin, int Cout, int* nparts, hipStream_t st) {
+             int N, int H, int W, int Cin, int Cout, int* nparts, hipStream_t st, bool ready = false) {
   if constexpr (sizeof(TA) == 4) {
     if (use_wino<TA>(H, W, Cin, Cout)) {
-      ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, wbuf, Cout, Cin, false, st));
+      if (!ready) ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, wbuf, Cout, Cin, false, st));
       *nparts = acvae::conv_wino_partials_rows(N, H, W);
       return acvae::conv3x3_wino(X, scale, shift, wbuf, Y, partials, N, H, W, Cin, Cout, st);
     }
@@ -151,10 +157,11 @@ int conv_fwd(const TA* X, const float* scale, const float* shift, const float* W
 }
 // dX = conv3x3(dY, flipped / transposed W) for the layer Cin -> Cout
 template <class TA>
-int conv_dgrad(const TA* dY, const float* W_oihw, TA* wbuf, TA* dX, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+int conv_dgrad(const TA* dY, const float* W_oihw, TA* wbuf, TA* dX, int N, int H, int W, int Cin, int Cout, hipStream_t st,
+               bool ready = false) {
   if constexpr (sizeof(TA) == 4) {
     if (use_wino<TA>(H, W, Cout, Cin)) {
-      ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, (float*)wbuf, Cout, Cin, true, st));
+      if (!ready) ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, (float*)wbuf, Cout, Cin, true, st));
       return acvae::conv3x3_wino(dY, nullptr, nullptr, (const float*)wbuf, dX, nullptr, N, H, W, Cout, Cin, st);
     }
   }
@@ -239,6 +246,26 @@ int encoder_fwd_t(const void* const* params, const float* feats, float* audio_em
   if (training) ACVAE_TRY(acvae::bn0_stats(feats, partials, (long)N * T, F, &nparts, st));
   ACVAE_TRY(acvae::bn_finalize(partials, nparts, 64, (double)N * T, P(p_bn0(0)), P(p_bn0(1)), P(p_bn0(2)), P(p_bn0(3)),
                                (int64_t*)params[p_bn0(4)], training, b0.scale, b0.shift, b0.mean, b0.invstd, dpart, st));
+  // fp32: the Winograd images of every layer that takes that path - forward filters, and in training the data gradient's
+  // too (kept in `saved` for the backward) - in ONE launch here instead of a launch in front of each convolution
+  bool wready[kMaxBlocks + 1][2] = {};
+  if constexpr (sizeof(TA) == 4) {
+    acvae::WinoWeightsBatch wb;
+    for (int b = 1; b <= L.nb; ++b) {
+      const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
+      if (b > 1 && use_wino<TA>(H, W, Cin, C)) {
+        wb.add(P(p_conv(b, 1)), saved + L.wf1[b], C, Cin, false);
+        if (training && use_wino<TA>(H, W, C, Cin)) wb.add(P(p_conv(b, 1)), saved + L.wd1[b], C, Cin, true);
+        wready[b][0] = true;
+      }
+      if (use_wino<TA>(H, W, C, C)) {
+        wb.add(P(p_conv(b, 2)), saved + L.wf2[b], C, C, false);
+        if (training) wb.add(P(p_conv(b, 2)), saved + L.wd2[b], C, C, true);
+        wready[b][1] = true;
+      }
+    }
+    ACVAE_TRY(acvae::conv3x3_wino_weights_batch(wb, st));
+  }
   const TA* x_in = nullptr;
   for (int b = 1; b <= L.nb; ++b) {
     const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];
@@ -253,14 +280,14 @@ int encoder_fwd_t(const void* const* params, const float* feats, float* audio_em
       np1 = acvae::conv1_first_blocks(N, T);
     } else {
       ACVAE_TRY(conv_fwd<TA>(x_in, nullptr, nullptr, P(p_conv(b, 1)), saved + L.wf1[b], Y1, training ? partials : nullptr, N,
-                             H, W, Cin, C, &np1, st));
+                             H, W, Cin, C, &np1, st, wready[b][0]));
     }
     ACVAE_TRY(acvae::bn_finalize(partials, np1, C, cnt, P(p_bn(b, 1, 0)), P(p_bn(b, 1, 1)), P(p_bn(b, 1, 2)),
                                  P(p_bn(b, 1, 3)), (int64_t*)params[p_bn(b, 1, 4)], training, n1.scale, n1.shift,
                                  n1.mean, n1.invstd, dpart, st));
     int np2;
     ACVAE_TRY(conv_fwd<TA>((const TA*)Y1, n1.scale, n1.shift, P(p_conv(b, 2)), saved + L.wf2[b], Y2,
-                           training ? partials : nullptr, N, H, W, C, C, &np2, st));
+                           training ? partials : nullptr, N, H, W, C, C, &np2, st, wready[b][1]));
     ACVAE_TRY(acvae::bn_finalize(partials, np2, C, cnt, P(p_bn(b, 2, 0)),
                                  P(p_bn(b, 2, 1)), P(p_bn(b, 2, 2)), P(p_bn(b, 2, 3)), (int64_t*)params[p_bn(b, 2, 4)],
                                  training, n2.scale, n2.shift, n2.mean, n2.invstd, dpart, st));
@@ -347,7 +374,10 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
                             G(p_bn(b, 2, 0)), dya, dpart, N, H, W, C, dspec(p_block, masks, seed, b - 1, training), st,
                             training != 0));
     ACVAE_TRY(conv_wgrad<TA>((const TA*)dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
-    ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd, dyb, N, H, W, C, C, st));
+    // the data gradient's Winograd images were built by the training forward (same parameters: the optimiser runs after us)
+    const bool wd_ready = sizeof(TA) == 4 && training != 0;
+    ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd_ready && use_wino<TA>(H, W, C, C) ? (TA*)(saved + L.wd2[b]) : wd, dyb, N,
+                             H, W, C, C, st, wd_ready));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
     ACVAE_TRY(acvae::bn_bwd<TA>(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
@@ -355,7 +385,8 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
     if (b > 1) {
       ACVAE_TRY(conv_wgrad<TA>((const TA*)dya, (const TA*)(saved + L.p[b - 1]), nullptr, nullptr, G(p_conv(b, 1)), slab, N, H,
                                W, Cin, C, st));
-      ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 1)), wd, dp_nxt, N, H, W, Cin, C, st));
+      const bool r1 = wd_ready && use_wino<TA>(H, W, Cin, C) && use_wino<TA>(H, W, C, Cin);
+      ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 1)), r1 ? (TA*)(saved + L.wd1[b]) : wd, dp_nxt, N, H, W, Cin, C, st, r1));
       TA* t = dp_cur; dp_cur = dp_nxt; dp_nxt = t;
     } else {
       BnPtrs b0 = bn_at(saved, L, 0);
