@@ -17,6 +17,7 @@
 #include "conv.h"
 #include "rnn.h"
 #include "decode_persist.h"
+#include <atomic>
 #include "../../include/acvae_hip.h"
 
 namespace {
@@ -601,11 +602,18 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
   return ACVAE_OK;
 }
 
+// -1: not set (the environment decides: ACVAE_DECODE_DEFER=1 switches it on); 0 / 1: set by acvae_set_decode_defer
+static std::atomic<int> g_decode_defer{-1};
+extern "C" int acvae_set_decode_defer(int on) { return g_decode_defer.exchange(on != 0 ? 1 : 0); }
+
 extern "C" int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream) {
-  // Off unless ACVAE_DECODE_DEFER=1: measured on configs[1], the decode backward shrinks by 0.48 ms (2.41 -> 1.93) and the
-  // encoder backward beside the trailing work grows by 0.46 ms (17.17 -> 17.64) - the trailing products are not idle-CU
-  // work, so the step does not move (tools/gpu_phases.py).
-  static const bool on = getenv("ACVAE_DECODE_DEFER") && atoi(getenv("ACVAE_DECODE_DEFER")) == 1;
+  // Library default: off (everything ordered on `stream` on return - the contract a plain C caller expects) unless
+  // ACVAE_DECODE_DEFER=1 or acvae_set_decode_defer(1): Hybrid_VAEModel, which joins the second stream itself, switches it on.
+  // Round 2 (implicit-GEMM convolutions): decode backward -0.48 ms, encoder backward beside the trailing work +0.46 ms.
+  // Round 3 (A/B inside one session, three runs each): 17.106 -> 17.034 ms per step.
+  static const bool env_on = getenv("ACVAE_DECODE_DEFER") && atoi(getenv("ACVAE_DECODE_DEFER")) == 1;
+  const int set = g_decode_defer.load();
+  const bool on = set < 0 ? env_on : set != 0;
   if (!on || !aux_stream || aux_stream == stream || !dis_flags_host) return 0;
   for (int t = 0; t < Tc; ++t)
     if (dis_flags_host[t] != 0) return 0;      // the prior BPTT waits for the decoder's dz: nothing to overlap

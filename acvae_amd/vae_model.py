@@ -132,6 +132,10 @@ class Hybrid_VAEModel(CaptionModel):
         self.decoder._owner = weakref.ref(self)
         self._encproj_cache = {}
         self.use_side_stream = os.environ.get("ACVAE_SIDE_STREAM", "1") != "0"
+        # the decode backward leaves its parameter gradients trailing on the second stream beside the encoder backward
+        # (_DecodeFn.backward joins it); ACVAE_DECODE_DEFER=0 keeps everything on the main stream
+        if os.environ.get("ACVAE_DECODE_DEFER", "1") != "0":
+            _lib.lib().acvae_set_decode_defer(1)
         self.staged = None         # device copies of caps / cap_lens-1 made by the last training forward
         self.noise = None          # optional replay: dict(eps_q=[N,Tc,E], eps_p=[Tc,N,E]) consumed by the next forward
         self._grad_views = None    # {param: flat-gradient view}, set by the train-step harness

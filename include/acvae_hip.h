@@ -370,9 +370,11 @@ int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, con
  * does not depend on - the parameter gradients and d_q_z - is queued on `aux_stream` behind the call, so that it runs
  * beside whatever `stream` does next (the encoder backward): the caller joins aux_stream before those results are read
  * on another stream, and keeps saved / scratch / outputs / the upstream gradients untouched until aux_stream has
- * drained.  Otherwise (0) everything is ordered on `stream` on return.  Opt-in: 0 unless ACVAE_DECODE_DEFER=1 (measured
- * zero-sum against the encoder backward on the reference configuration). */
+ * drained.  Otherwise (0) everything is ordered on `stream` on return.  Opt-in: 0 unless ACVAE_DECODE_DEFER=1 or
+ * acvae_set_decode_defer(1) (returns the previous setting, -1 = never set; Hybrid_VAEModel, which joins the second stream
+ * at the end of the backward pass, sets it unless ACVAE_DECODE_DEFER=0: -0.07 ms per step on the reference configuration). */
 int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream);
+int acvae_set_decode_defer(int on);
 int acvae_decode_bwd(const void* const* params, void* const* grads, const float* mem_in, const int64_t* mem_lens,
                      const int64_t* lens1, const float* eps_p, const int* dis_flags_host, const float* outputs,
                      const float* attn_w, const float* p_logs, const float* d_logits, const float* d_outputs_ext,

@@ -689,14 +689,15 @@ def test_checkpoint_round_trip_and_torch_adam_compat():
             close(b, a, 1e-5, 1e-6, what="torch Adam vs fused " + k)
 
 
-def test_train_step_goldens_with_trailing_parameter_gradients():
-    """ACVAE_DECODE_DEFER=1 (acvae_decode_bwd leaves the parameter gradients and d_q_z on the second stream, joined at
-    the end of the backward pass): the training-step goldens and the ragged edge shapes must still hold.  The switch is
-    read once per process, hence the child process."""
+def test_train_step_goldens_without_trailing_parameter_gradients():
+    """Hybrid_VAEModel lets acvae_decode_bwd leave the parameter gradients and d_q_z on the second stream, joined at the end
+    of the backward pass (what every other test in this file runs with).  ACVAE_DECODE_DEFER=0 keeps everything on the main
+    stream - the library's own default for plain C callers: the training-step goldens and the ragged edge shapes must hold
+    that way too.  The model reads the switch when it is built, the library keeps it per process, hence the child process."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, ACVAE_DECODE_DEFER="1")
+    env = dict(os.environ, ACVAE_DECODE_DEFER="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "g6 or g13 or edge_shapes or checkpoint"], env=env, capture_output=True, text=True,
                        timeout=600)
