@@ -105,7 +105,7 @@ class _DecodeFn(torch.autograd.Function):
             side, cur = model._side_stream(torch.cuda.current_stream()), torch.cuda.current_stream()
             for t in [ctx.saved, outputs, d_qz] + [u for u in ups if u is not None]:
                 t.record_stream(side)                      # freed by autograd while the side stream still reads them
-            if any(p is not None and p.grad is not None for p in params):
+            if any(p is not None and p.is_leaf and p.grad is not None for p in params):   # (a projected embedding table is not a leaf)
                 cur.wait_stream(side)                      # autograd will accumulate into .grad on this stream right away
             else:
                 torch.autograd.Variable._execution_engine.queue_callback(lambda: cur.wait_stream(side))
