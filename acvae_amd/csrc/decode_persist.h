@@ -56,3 +56,42 @@ bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A);
 long decode_persist_counter_words(int Tc);
 int decode_persist_fwd(PdParams p, hipStream_t st);
 }  // namespace acvae
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The posterior's packed bidirectional GRU (PosteriorRNN_hybrid, models/text_encoder.py:189-191) as one persistent launch per
+// pass: both directions, all Tc steps.  A workgroup owns 32 hidden units of one direction: forward it forms the three gate
+// tiles gh = h . Whh^T + b of its units (weight fragments resident in registers), runs the GRU cell and hands its slice of h to
+// the direction's other workgroups; backward it forms dh = dh . z + dgh . Whh for its units, runs the cell backward and
+// hands over its slice of dgh.  One hand-off per step and direction (protocol of decode_persist.hip).
+struct PqParams {
+  const float* w_hh[2];        // [3Hq][Hq] per direction
+  const float* b_hh[2];        // [3Hq]
+  const float* gi[2];          // hoisted input projections [N][Tc][3Hq]
+  const int64_t* lens1;        // [N]
+  float* hid;                  // [N][Tc][2Hq]
+  float* save[2];              // [N][Tc][4Hq] = r | z | n | gh_n
+  float* hprev[2];             // [N][Tc][Hq]
+  float* hbuf;                 // [2 directions][2 step parities][N][Hq]: the state in flight, ZEROED by the caller (step 0 reads parity 1)
+  unsigned* cnt;               // posterior_persist_counter_words(Tc), zeroed by the launcher
+  unsigned* abort_word;        // set by the launcher
+  int N, Tc, Hq;
+};
+struct PqbParams {
+  const float* wt[2];          // transposed weight_hh: [Hq][3Hq]
+  const float* dhid;           // [N][Tc][2Hq]
+  const float* save[2];
+  const float* hprev[2];
+  const int64_t* lens1;
+  float* dgi[2];               // [N][Tc][3Hq]
+  float* dgh[2];               // [N][Tc][3Hq] (handed over inside the launch)
+  unsigned* cnt;
+  unsigned* abort_word;
+  int N, Tc, Hq;
+};
+namespace acvae {
+bool posterior_persist_ok(int N, int Tc, int Hq);
+long posterior_persist_counter_words(int Tc);
+int posterior_persist_fwd(PqParams p, hipStream_t st);
+int posterior_persist_bwd(PqbParams p, hipStream_t st);
+}  // namespace acvae

@@ -902,6 +902,155 @@ __global__ __launch_bounds__(PB_THREADS) void decode_persist_bwd_kernel(PbParams
 
 }  // namespace
 
+namespace {
+// =====================================================================================================================
+// Posterior BiGRU, persistent (PqParams / PqbParams in decode_persist.h).  Arithmetic of the per-step path (acvae_posterior_fwd
+// in decoder.hip): gemm_skinny's K order for every 32 x 32 tile, gru_fwd_kernel's / gru_bwd_kernel's cell formulas.
+// =====================================================================================================================
+struct PqSmem {
+  float red[SK_WAVES][32][33];
+  int flag;
+};
+
+__global__ __launch_bounds__(PD_THREADS) void posterior_persist_fwd_kernel(PqParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem_raw[];
+  PqSmem& sm = *reinterpret_cast<PqSmem*>(pq_smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int Hq = p.Hq, nwg = Hq / 32;
+  const int dir = blockIdx.x / nwg, u0 = (blockIdx.x - dir * nwg) * 32;
+  const float* W = p.w_hh[dir];
+  const int arow = li < p.N ? li : 0;
+  // weight fragments of the three gate tiles: resident for all steps (K = Hq <= 512: one batch per wavefront)
+  PdFrag fb[3];
+  const float* bp[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    bp[g] = W + (long)(g * Hq + u0 + li) * Hq + 4 * lh;
+    pd_fetch_b(fb[g], bp[g], Hq, wave);
+  }
+  // the two elements (row mm, unit u0 + nn) this thread owns in the cell
+  const int nn = threadIdx.x & 31, m0 = threadIdx.x >> 5;          // rows m0, m0 + 16
+  const float br = p.b_hh[dir][u0 + nn], bz = p.b_hh[dir][Hq + u0 + nn], bn_ = p.b_hh[dir][2 * Hq + u0 + nn];
+  float hreg[2] = {0.f, 0.f};
+  int len[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) len[i] = (m0 + 16 * i) < p.N ? (int)p.lens1[m0 + 16 * i] : 0;
+  unsigned* cnt = p.cnt + (long)dir * p.Tc;
+  float* hb = p.hbuf + (long)dir * 2 * p.N * Hq;
+  for (int k = 0; k < p.Tc; ++k) {
+    const int t = dir ? p.Tc - 1 - k : k;
+    if (k > 0 && !pd_wait(cnt + (k - 1), (unsigned)nwg, p.abort_word, &sm.flag)) return;
+    const float* hin = hb + (long)((k + 1) & 1) * p.N * Hq;      // step 0: parity 1 = the zeros the caller put there
+    float4 a[PD_U];
+    pd_load_a<true>(a, hin, (long)arow * Hq + 4 * lh, Hq, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    float ghv[3][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      pd_mfma(acc, a, fb[g], Hq, wave);
+      if (g) __syncthreads();                      // the previous tile's sums have been taken
+      pd_stash(sm.red, acc, wave, li, lh);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ghv[g][i] = pd_sum(sm.red, m0 + 16 * i, nn);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = m0 + 16 * i;
+      if (mm < p.N) {
+        const long row = (long)mm * p.Tc + t;
+        const float h = hreg[i];
+        p.hprev[dir][row * Hq + u0 + nn] = h;
+        float hn = h, os = 0.f;
+        if (t < len[i]) {
+          const float* gi = p.gi[dir] + row * 3 * Hq + u0 + nn;
+          const float r = sigmoidf_(gi[0] + (ghv[0][i] + br));
+          const float z = sigmoidf_(gi[Hq] + (ghv[1][i] + bz));
+          const float ghn = ghv[2][i] + bn_;
+          const float nv = tanhf(gi[2 * Hq] + r * ghn);
+          hn = (1.f - z) * nv + z * h;
+          os = hn;
+          float* sv = p.save[dir] + row * 4 * Hq + u0 + nn;
+          sv[0] = r; sv[Hq] = z; sv[2 * Hq] = nv; sv[3 * Hq] = ghn;
+        }
+        hreg[i] = hn;
+        st_sc1(hb + (long)(k & 1) * p.N * Hq + (long)mm * Hq + u0 + nn, hn);
+        p.hid[row * 2 * Hq + dir * Hq + u0 + nn] = os;
+      }
+    }
+    pd_arrive(cnt + k);
+  }
+}
+
+// backward: t runs against the forward's order.  dh(k) = dh(k-1) . z(k-1)  [own elements, registers]  +  dgh(k-1) . Whh  [all of the
+// direction's dgh of the previous step: the hand-off];  then gru_bwd_kernel's formulas.
+__global__ __launch_bounds__(PD_THREADS) void posterior_persist_bwd_kernel(PqbParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem_raw[];
+  PqSmem& sm = *reinterpret_cast<PqSmem*>(pq_smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int Hq = p.Hq, nwg = Hq / 32;
+  const int dir = blockIdx.x / nwg, u0 = (blockIdx.x - dir * nwg) * 32;
+  const int arow = li < p.N ? li : 0;
+  const float* bp = p.wt[dir] + (long)(u0 + li) * 3 * Hq + 4 * lh;         // row = output unit, K = 3Hq contiguous
+  const int nn = threadIdx.x & 31, m0 = threadIdx.x >> 5;
+  float dhd[2] = {0.f, 0.f};               // dh . z of the previous step (own elements)
+  int len[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) len[i] = (m0 + 16 * i) < p.N ? (int)p.lens1[m0 + 16 * i] : 0;
+  unsigned* cnt = p.cnt + (long)dir * p.Tc;
+  int tprev = 0;
+  for (int k = 0; k < p.Tc; ++k) {
+    const int t = dir ? k : p.Tc - 1 - k;
+    float prod[2] = {0.f, 0.f};
+    if (k > 0) {
+      if (!pd_wait(cnt + (k - 1), (unsigned)nwg, p.abort_word, &sm.flag)) return;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // A = dgh[:, tprev, :] of this direction ([N][Tc][3Hq]: row stride Tc * 3Hq), handed over
+      pd_accumulate<true>(acc, p.dgh[dir], ((long)arow * p.Tc + tprev) * 3 * Hq + 4 * lh, bp, 3 * Hq, wave);
+      pd_stash(sm.red, acc, wave, li, lh);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) prod[i] = pd_sum(sm.red, m0 + 16 * i, nn);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = m0 + 16 * i;
+      if (mm < p.N) {
+        const long row = (long)mm * p.Tc + t;
+        float dh = dhd[i] + prod[i];
+        float* a = p.dgi[dir] + row * 3 * Hq + u0 + nn;
+        float* b = p.dgh[dir] + row * 3 * Hq + u0 + nn;
+        if (!(t < len[i])) {
+          a[0] = a[Hq] = a[2 * Hq] = 0.f;
+          st_sc1(b, 0.f); st_sc1(b + Hq, 0.f); st_sc1(b + 2 * Hq, 0.f);
+          dhd[i] = dh;
+        } else {
+          dh += p.dhid[row * 2 * Hq + dir * Hq + u0 + nn];
+          const float* sv = p.save[dir] + row * 4 * Hq + u0 + nn;
+          const float r = sv[0], z = sv[Hq], nv = sv[2 * Hq], ghn = sv[3 * Hq];
+          const float h = p.hprev[dir][row * Hq + u0 + nn];
+          const float dn = dh * (1.f - z);
+          const float dz = dh * (h - nv);
+          const float dnp = dn * (1.f - nv * nv);
+          const float drp = dnp * ghn * r * (1.f - r);
+          const float dzp = dz * z * (1.f - z);
+          a[0] = drp; a[Hq] = dzp; a[2 * Hq] = dnp;
+          st_sc1(b, drp); st_sc1(b + Hq, dzp); st_sc1(b + 2 * Hq, dnp * r);
+          dhd[i] = dh * z;
+        }
+      }
+    }
+    tprev = t;
+    pd_arrive(cnt + k);
+  }
+}
+}  // namespace
+
 namespace acvae {
 
 static int g_persist = -1;      // -1: not decided yet (environment), 0 / 1: set
@@ -974,6 +1123,34 @@ int decode_persist_bwd(PbParams p, hipStream_t st) {
   }
   hipLaunchKernelGGL(decode_persist_bwd_kernel, dim3(grid), dim3(PB_THREADS), shm, st, p);
   hipLaunchKernelGGL(attn_dmem_kernel, dim3(p.N * p.S), dim3(256), 0, st, p.attn_w, p.dctx, p.dmem, p.Tc, p.S, p.E);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+}  // namespace acvae
+
+namespace acvae {
+bool posterior_persist_ok(int N, int Tc, int Hq) {
+  if (g_persist < 0) g_persist = (getenv("ACVAE_DECODE_PERSIST") && atoi(getenv("ACVAE_DECODE_PERSIST")) == 0) ? 0 : 1;
+  // one 32-row tile of clips; 32 hidden units per workgroup; a wavefront's share of K = Hq is one resident batch
+  return g_persist == 1 && N >= 1 && N <= 32 && Tc >= 1 && Hq >= 32 && Hq <= 64 * PD_U && Hq % 32 == 0;
+}
+long posterior_persist_counter_words(int Tc) { return (2L * Tc + 1 + 3) & ~3L; }
+
+int posterior_persist_fwd(PqParams p, hipStream_t st) {
+  if (!posterior_persist_ok(p.N, p.Tc, p.Hq)) return ACVAE_EUNSUPPORTED;
+  p.abort_word = p.cnt + 2L * p.Tc;
+  if (hipMemsetAsync(p.cnt, 0, (size_t)posterior_persist_counter_words(p.Tc) * sizeof(unsigned), st) != hipSuccess)
+    return (int)hipGetLastError();
+  hipLaunchKernelGGL(posterior_persist_fwd_kernel, dim3(2 * (p.Hq / 32)), dim3(PD_THREADS), sizeof(PqSmem), st, p);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int posterior_persist_bwd(PqbParams p, hipStream_t st) {
+  if (!posterior_persist_ok(p.N, p.Tc, p.Hq)) return ACVAE_EUNSUPPORTED;
+  p.abort_word = p.cnt + 2L * p.Tc;
+  if (hipMemsetAsync(p.cnt, 0, (size_t)posterior_persist_counter_words(p.Tc) * sizeof(unsigned), st) != hipSuccess)
+    return (int)hipGetLastError();
+  hipLaunchKernelGGL(posterior_persist_bwd_kernel, dim3(2 * (p.Hq / 32)), dim3(PD_THREADS), sizeof(PqSmem), st, p);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

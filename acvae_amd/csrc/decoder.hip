@@ -102,7 +102,8 @@ struct PostLayout {
   // saved
   long words, x, hidden, save_f, save_r, hprev_f, hprev_r, argmax, saved_total;
   // scratch
-  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, tn, dpart, skws, scratch_total;
+  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, wt2, pq_hbuf, pq_cnt, tn, dpart, skws,
+       scratch_total;
   long tn_floats;
 };
 int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
@@ -127,6 +128,9 @@ int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
   if ((long)3 * Hq * Hq > wt) wt = (long)3 * Hq * Hq;
   if ((long)3 * Hq * E > wt) wt = (long)3 * Hq * E;
   L.wt = c.take(wt);
+  L.wt2 = c.take((long)3 * Hq * Hq);                        // persistent BPTT: both directions' transposed weight_hh at once
+  L.pq_hbuf = c.take((long)4 * N * Hq);                     // persistent forward: h in flight, [direction][parity][N][Hq]
+  L.pq_cnt = c.take(acvae::posterior_persist_counter_words(Tc));
   long tn = tn_ws_floats(2 * E, 2 * Hq, (int)R);
   long t2 = tn_ws_floats(3 * Hq, E, (int)R); if (t2 > tn) tn = t2;
   t2 = tn_ws_floats(3 * Hq, Hq, (int)R); if (t2 > tn) tn = t2;
@@ -254,6 +258,22 @@ extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* cap
   float* hid = sv + L.hidden;
   ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));            // x[:, :-1] restricted to Tc steps
   ACVAE_TRY(acvae::embed_gather(words, 1, P(TP_Q_EMB), V, X, E, R, E, st));
+  if (acvae::posterior_persist_ok(N, Tc, Hq)) {
+    // both directions, all steps: one launch (decode_persist.hip); the hoisted input projections first
+    PqParams pq;
+    for (int dir = 0; dir < 2; ++dir) {
+      const int o = dir * 4;
+      float* gi = sc + (dir ? L.gi_r : L.gi_f);
+      ACVAE_TRY(gemm(X, E, P(TP_Q_WIH + o), E, P(TP_Q_BIH + o), gi, 3 * Hq, R, 3 * Hq, E, 0, st));
+      pq.w_hh[dir] = P(TP_Q_WHH + o); pq.b_hh[dir] = P(TP_Q_BHH + o); pq.gi[dir] = gi;
+      pq.save[dir] = sv + (dir ? L.save_r : L.save_f);
+      pq.hprev[dir] = sv + (dir ? L.hprev_r : L.hprev_f);
+    }
+    pq.lens1 = lens1; pq.hid = hid; pq.hbuf = sc + L.pq_hbuf; pq.cnt = (unsigned*)(sc + L.pq_cnt);
+    pq.N = N; pq.Tc = Tc; pq.Hq = Hq;
+    ACVAE_TRY(zero(pq.hbuf, (long)4 * N * Hq, st));
+    ACVAE_TRY(acvae::posterior_persist_fwd(pq, st.s));
+  } else
   for (int dir = 0; dir < 2; ++dir) {
     const int o = dir * 4;
     float* gi = sc + (dir ? L.gi_r : L.gi_f);
@@ -311,6 +331,22 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   ACVAE_TRY(gemm_tn(dml, 2 * E, hid, 2 * Hq, G(TP_Q_TML_W), 2 * Hq, 2 * E, 2 * Hq, R, tn, st));
   ACVAE_TRY(acvae::colsum2(dml, R, 2 * E, dpart, G(TP_Q_TML_B), nullptr, 0, st));
   float* dx = sc + L.dx;
+  const bool persist = acvae::posterior_persist_ok(N, Tc, Hq);
+  if (persist) {                 // BPTT of both directions in one launch; the parameter products below are unchanged
+    PqbParams pb;
+    for (int dir = 0; dir < 2; ++dir) {
+      float* wtd = dir ? sc + L.wt2 : wt;
+      ACVAE_TRY(transp(P(TP_Q_WHH + dir * 4), Hq, wtd, 3 * Hq, 3 * Hq, Hq, st));                   // [Hq][3Hq]
+      pb.wt[dir] = wtd;
+      pb.save[dir] = sv + (dir ? L.save_r : L.save_f);
+      pb.hprev[dir] = sv + (dir ? L.hprev_r : L.hprev_f);
+      pb.dgi[dir] = sc + (dir ? L.dgi_r : L.dgi_f);
+      pb.dgh[dir] = sc + (dir ? L.dgh_r : L.dgh_f);
+    }
+    pb.dhid = dhid; pb.lens1 = lens1; pb.cnt = (unsigned*)(sc + L.pq_cnt);
+    pb.N = N; pb.Tc = Tc; pb.Hq = Hq;
+    ACVAE_TRY(acvae::posterior_persist_bwd(pb, st.s));
+  }
   for (int dir = 0; dir < 2; ++dir) {
     const int o = dir * 4;
     float* save = sv + (dir ? L.save_r : L.save_f);
@@ -319,16 +355,18 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
     float* dgh = sc + (dir ? L.dgh_r : L.dgh_f);
     float* dh = sc + L.dh_a;
     float* dh2 = sc + L.dh_b;
-    ACVAE_TRY(transp(P(TP_Q_WHH + o), Hq, wt, 3 * Hq, 3 * Hq, Hq, st));                   // [Hq][3Hq]
-    ACVAE_TRY(acvae::copy_rows(dh, Hq, nullptr, 0, N, Hq, st));
-    for (int k = 0; k < Tc; ++k) {
-      const int t = dir ? k : Tc - 1 - k;  // reverse of the forward order
-      ACVAE_TRY(acvae::gru_bwd(dh, Hq, dhid + (long)t * 2 * Hq + dir * Hq, (long)Tc * 2 * Hq, save + (long)t * 4 * Hq,
-                               (long)Tc * 4 * Hq, hprev + (long)t * Hq, (long)Tc * Hq, dgi + (long)t * 3 * Hq,
-                               (long)Tc * 3 * Hq, dgh + (long)t * 3 * Hq, (long)Tc * 3 * Hq, dh2, Hq, lens1, t, N, Hq,
-                               st));
-      ACVAE_TRY(gemm(dgh + (long)t * 3 * Hq, (long)Tc * 3 * Hq, wt, 3 * Hq, nullptr, dh2, Hq, N, Hq, 3 * Hq, 1, st));
-      float* tmp = dh; dh = dh2; dh2 = tmp;
+    if (!persist) {
+      ACVAE_TRY(transp(P(TP_Q_WHH + o), Hq, wt, 3 * Hq, 3 * Hq, Hq, st));                   // [Hq][3Hq]
+      ACVAE_TRY(acvae::copy_rows(dh, Hq, nullptr, 0, N, Hq, st));
+      for (int k = 0; k < Tc; ++k) {
+        const int t = dir ? k : Tc - 1 - k;  // reverse of the forward order
+        ACVAE_TRY(acvae::gru_bwd(dh, Hq, dhid + (long)t * 2 * Hq + dir * Hq, (long)Tc * 2 * Hq, save + (long)t * 4 * Hq,
+                                 (long)Tc * 4 * Hq, hprev + (long)t * Hq, (long)Tc * Hq, dgi + (long)t * 3 * Hq,
+                                 (long)Tc * 3 * Hq, dgh + (long)t * 3 * Hq, (long)Tc * 3 * Hq, dh2, Hq, lens1, t, N, Hq,
+                                 st));
+        ACVAE_TRY(gemm(dgh + (long)t * 3 * Hq, (long)Tc * 3 * Hq, wt, 3 * Hq, nullptr, dh2, Hq, N, Hq, 3 * Hq, 1, st));
+        float* tmp = dh; dh = dh2; dh2 = tmp;
+      }
     }
     ACVAE_TRY(gemm_tn(dgi, 3 * Hq, X, E, G(TP_Q_WIH + o), E, 3 * Hq, E, R, tn, st));
     ACVAE_TRY(acvae::colsum2(dgi, R, 3 * Hq, dpart, G(TP_Q_BIH + o), nullptr, 0, st));
