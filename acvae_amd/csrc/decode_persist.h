@@ -42,16 +42,21 @@ struct PbParams {
   const float *d_out, *d_p_z, *d_p_means, *d_p_logs;
   // written by the launch (dctx: [N, Tc, E], one slot per step)
   float *dgi, *dgh, *dqd, *dctx, *dencproj, *dmem, *dvpart, *dgates, *dml_all, *dhp;
+  // K-split partials handed over inside the launch (scratch, decode_persist_bwd_part_floats): dctx [ks_rb][N][E],
+  // dhp [ks_pa][N][Hp], dml [ks_pa][N][2E]
+  float *dctx_part, *dhp_part, *dml_part;
   unsigned* cnt;
   unsigned* abort_word;
   int N, Tc, S, E, H, A;
   int n_ra, n_rb, n_pa, n_pb;
+  int ks_rb, ks_pa;                // K-splits of the RB / PA products (set by the launcher)
 };
 
 namespace acvae {
 bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A);
 long decode_persist_bwd_counter_words(int Tc);
 int decode_persist_bwd(PbParams p, hipStream_t st);
+long decode_persist_bwd_part_floats(int N, int E, int H);
 bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A);
 long decode_persist_counter_words(int Tc);
 int decode_persist_fwd(PdParams p, hipStream_t st);

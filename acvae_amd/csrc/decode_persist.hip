@@ -614,6 +614,82 @@ __device__ __forceinline__ void pb_gemm(f32x16& acc, const float* abase, long ai
   }
 }
 
+// The same product with ALL of the wave's handed-off operand fragments fetched in one round trip (NB batches of eight K-groups:
+// 32 registers each) and the weight fragments streamed batch by batch from L2 behind them, one batch ahead: a role whose K
+// spans several batches pays the 3-4 us to handed-off data once instead of once per batch (K = 2048: 21 -> 11 us).
+// NP > 1: the operand arrives as NP shares `pstride` floats apart (a K-split producer); they are summed in share order.
+// `keep` (optional): the lane's row of the summed operand is stored there for the fragments f (0 .. 8 NB - 1) with
+// f % keep_mod == keep_rem - the readers of one operand share the work of keeping it.
+template <int NB, int NP = 1>
+__device__ __forceinline__ void pb_gemm_apre(f32x16& acc, const float* abase, long aidx, const float* bp, int wave, long pstride = 0,
+                                             float* keep = nullptr, int keep_mod = 1, int keep_rem = 0) {
+  // K = 512 NB exactly: every K-group exists, all offsets are a per-wave base plus constants
+  constexpr int STEP = 8 * PB_WAVES;
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, 0x7fffffff, 0x00020000);
+  const int vbase = (int)((aidx + (long)wave * 8) * 4);
+  const float* bw = bp + wave * 8;
+  float4 a[NB][8];
+  {
+    pd_v4u r[NP][NB][8];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          r[q][nb][u] = __builtin_amdgcn_raw_buffer_load_b128(ars, vbase + (int)(q * pstride * 4), (nb * STEP + u * PB_WAVES) * 32, 16 /* sc1 */);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float4 v = make_float4(__uint_as_float(r[0][nb][u].x), __uint_as_float(r[0][nb][u].y), __uint_as_float(r[0][nb][u].z),
+                               __uint_as_float(r[0][nb][u].w));
+#pragma unroll
+        for (int q = 1; q < NP; ++q) {
+          v.x += __uint_as_float(r[q][nb][u].x); v.y += __uint_as_float(r[q][nb][u].y);
+          v.z += __uint_as_float(r[q][nb][u].z); v.w += __uint_as_float(r[q][nb][u].w);
+        }
+        a[nb][u] = v;
+        if (keep && (nb * 8 + u) % keep_mod == keep_rem) *reinterpret_cast<float4*>(keep + (wave + nb * STEP + u * PB_WAVES) * 8) = v;
+      }
+  }
+  float4 b0[8], b1[8];
+  auto load_b = [&](float4 (&b)[8], int nb) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const float4*>(bw + (nb * STEP + u * PB_WAVES) * 8);
+  };
+  auto mfma = [&](const float4 (&av)[8], const float4 (&b)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  };
+  if (NB <= 2) {                 // two weight sets: the next batch's fragments fly during this batch's MFMAs
+    load_b(b0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb += 2) {
+      if (nb + 1 < NB) load_b(b1, nb + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(a[nb], b0);
+      if (nb + 1 < NB) {
+        if (nb + 2 < NB) load_b(b0, nb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(a[nb + 1], b1);
+      }
+    }
+  } else {                       // 4 x 32 operand registers leave room for one weight set
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      load_b(b0, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(a[nb], b0);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- RA: dh_{t} for 32 units, GRU cell backward (rnn.hip gru_bwd_kernel)
 // (32-wide slices: every reader of a handed-off tensor pulls all of it across the chip - 196 KB of dgh per workgroup and
 // step - so fewer, full-width tiles halve that traffic at the same MFMA time per workgroup)
@@ -682,22 +758,29 @@ __device__ void role_ra(const PbParams& p, int slice, PbSmem& sm) {
 // ---------------------------------------------------------------- RB: dctx = dgi[t] . Wih[:, E:2E] for 32 context columns
 __device__ void role_rb(const PbParams& p, int slice, PbSmem& sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  const int H = p.H, E = p.E, e0 = slice * 32;
-  const float* bp = p.wt_dih + (long)(E + e0 + li) * 3 * H + 4 * lh;       // [3E][3H]
+  // K = 3H split over ks_rb workgroups per tile: a round trip to handed-off data costs 3-4 us per batch of eight K-groups per
+  // wavefront whatever its size, so three workgroups with one batch each (one round trip + 64 MFMAs) replace one workgroup with
+  // three (15 -> 6 us per step); the partial tiles are summed in split order by their reader (RC).
+  const int H = p.H, E = p.E, tile = slice / p.ks_rb, ks = slice - tile * p.ks_rb, e0 = tile * 32;
+  const int Kc = 3 * H / p.ks_rb, k0 = ks * Kc;
+  const float* bp = p.wt_dih + (long)(E + e0 + li) * 3 * H + k0 + 4 * lh;       // [3E][3H]
   const int arow = li < p.N ? li : 0;
   const int mm0 = threadIdx.x >> 5, j = threadIdx.x & 31;
+  float* part = p.dctx_part + (long)ks * p.N * E;
   for (int t = p.Tc - 1; t >= 0; --t) {
     if (!pd_wait(p.cnt + PB_C_RA * p.Tc + t, (unsigned)p.n_ra, p.abort_word, &sm.flag)) return;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    pb_gemm(acc, p.dgi, (long)arow * p.Tc * 3 * H + (long)t * 3 * H + 4 * lh, bp, 3 * H, wave);
+    const long aidx = (long)arow * p.Tc * 3 * H + (long)t * 3 * H + k0 + 4 * lh;
+    if (Kc <= 512) pb_gemm1(acc, p.dgi, aidx, bp, Kc, wave);
+    else pb_gemm(acc, p.dgi, aidx, bp, Kc, wave);
     pb_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int mm = mm0 + 16 * i;
-      if (mm < p.N) st_sc1(p.dctx + (long)mm * p.Tc * E + (long)t * E + e0 + j, pb_sum(sm.red, mm, j));
+      if (mm < p.N) st_sc1(part + (long)mm * E + e0 + j, pb_sum(sm.red, mm, j));
     }
     pd_arrive(p.cnt + PB_C_RB * p.Tc + t);
   }
@@ -736,7 +819,18 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
     const float qa = a < A ? p.qd[(long)n * p.Tc * A + (long)t * A + a] : 0.f;
     if (threadIdx.x < S) w_s[threadIdx.x] = p.attn_w[(long)n * p.Tc * S + (long)t * S + threadIdx.x];
     if (!pd_wait(p.cnt + PB_C_RB * p.Tc + t, (unsigned)p.n_rb, p.abort_word, s_flag)) return;
-    dc_s[a] = a < E ? ld_sc1(p.dctx + (long)n * p.Tc * E + (long)t * E + a) : 0.f;
+    {   // the step's context gradient: the K-split partials of RB in split order; kept per step for attn_dmem_kernel
+      float dc = 0.f;
+      if (a < E) {
+        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < p.ks_rb) pv[q] = ld_sc1(p.dctx_part + ((long)q * p.N + n) * E + a);
+        dc = ((pv[0] + pv[1]) + pv[2]) + pv[3];
+        p.dctx[(long)n * p.Tc * E + (long)t * E + a] = dc;
+      }
+      dc_s[a] = dc;
+    }
     __syncthreads();
     {
       float part = 0.f;
@@ -789,19 +883,27 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
 // ---------------------------------------------------------------- PA: [dhp | dlz] for 16 units, re-parameterisation backward
 __device__ void role_pa(const PbParams& p, int slice, PbSmem& sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  const int E = p.E, Hp = p.E, u0 = slice * 16;
+  // K = 4Hp split over ks_pa workgroups per tile: the product is bound by ONE CU's matrix pipe (32 x 32 x 2048: 7 us), so
+  // two CUs take half each.  Everything downstream of the product is linear in it: each split hands over ITS share of dhp and
+  // of the two halves of dml (split 0 adds the terms that do not come from the product), the reader (PB) sums the shares.
+  const int E = p.E, Hp = p.E, tile = slice / p.ks_pa, ks = slice - tile * p.ks_pa, u0 = tile * 16;
+  const int Kc = 4 * Hp / p.ks_pa, k0 = ks * Kc;
   // tile columns 0..15: dhp of units u0.. (rows of Whh^T), 16..31: d last_z of the same indices (rows 2E.. of Wih^T)
-  const float* bp = (li < 16 ? p.wt_phh + (long)(u0 + li) * 4 * Hp : p.wt_pih + (long)(2 * E + u0 + li - 16) * 4 * Hp) + 4 * lh;
+  const float* bp = (li < 16 ? p.wt_phh + (long)(u0 + li) * 4 * Hp : p.wt_pih + (long)(2 * E + u0 + li - 16) * 4 * Hp) + k0 + 4 * lh;
   const int arow = li < p.N ? li : 0;
   const int mm = threadIdx.x >> 4, j = threadIdx.x & 15, e = u0 + j;
   const bool mine = mm < p.N;
+  float* dhp_o = p.dhp_part + ((long)ks * p.N + mm) * Hp + e;
+  float* dml_o = p.dml_part + ((long)ks * p.N + mm) * 2 * E;
   for (int t = p.Tc - 1; t >= 0; --t) {
     const long o = (long)mm * p.Tc * E + (long)t * E + e;
     float dpz = 0.f, dme = 0.f, dle = 0.f, lv = 0.f, eps = 0.f;
     if (mine) {
-      if (p.d_p_z) dpz = p.d_p_z[o];
-      if (p.d_p_means) dme = p.d_p_means[o];
-      if (p.d_p_logs) dle = p.d_p_logs[o];
+      if (ks == 0) {
+        if (p.d_p_z) dpz = p.d_p_z[o];
+        if (p.d_p_means) dme = p.d_p_means[o];
+        if (p.d_p_logs) dle = p.d_p_logs[o];
+      }
       lv = p.p_logs[o];
       eps = p.eps_p[(long)t * p.N * E + (long)mm * E + e];
     }
@@ -811,17 +913,19 @@ __device__ void role_pa(const PbParams& p, int slice, PbSmem& sm) {
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-      pb_gemm(acc, p.dgates, (long)arow * p.Tc * 4 * Hp + (long)(t + 1) * 4 * Hp + 4 * lh, bp, 4 * Hp, wave);
+      const long aidx = (long)arow * p.Tc * 4 * Hp + (long)(t + 1) * 4 * Hp + k0 + 4 * lh;
+      if (Kc == 1024) pb_gemm_apre<2>(acc, p.dgates, aidx, bp, wave);
+      else if (Kc <= 512) pb_gemm1(acc, p.dgates, aidx, bp, Kc, wave);
+      else pb_gemm(acc, p.dgates, aidx, bp, Kc, wave);
       pb_stash(sm.red, acc, wave, li, lh);
       __syncthreads();
       if (mine) { vhp = pb_sum(sm.red, mm, j); vlz = pb_sum(sm.red, mm, 16 + j); }
     }
     if (mine) {
-      const float g = vlz + dpz;                                        // d z_t
-      float* dml = p.dml_all + (long)mm * p.Tc * 2 * E + (long)t * 2 * E;
-      st_sc1(dml + e, g + dme);
-      st_sc1(dml + E + e, g * eps * .5f * expf(.5f * lv) + dle);
-      st_sc1(p.dhp + (long)mm * Hp + e, vhp);
+      const float g = vlz + dpz;                                        // this split's share of d z_t
+      st_sc1(dml_o + e, g + dme);
+      st_sc1(dml_o + E + e, g * eps * .5f * expf(.5f * lv) + dle);
+      st_sc1(dhp_o, vhp);
     }
     pd_arrive(p.cnt + PB_C_PA * p.Tc + t);
   }
@@ -851,7 +955,32 @@ __device__ void role_pb(const PbParams& p, int slice, PbSmem& sm) {
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    pb_gemm(acc, p.dml_all, (long)arow * p.Tc * 2 * E + (long)t * 2 * E + 4 * lh, bp, 2 * E, wave);
+    // dhp and dml arrive as the ks_pa shares of PA's K-split: summed here in share order; dhp is fetched with the product's
+    // operands, not behind them (one round trip less per step).  The summed d [mean | logvar] of the step is kept for the
+    // parameter products behind the launch (every workgroup stores its share of the fragments).
+    float dhp_in[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (mm0 + 16 * i < p.N) {
+        float v0 = ld_sc1(p.dhp_part + (long)(mm0 + 16 * i) * Hp + u), v1 = 0.f;
+        if (p.ks_pa == 2) v1 = ld_sc1(p.dhp_part + ((long)p.N + mm0 + 16 * i) * Hp + u);
+        dhp_in[i] = v0 + v1;
+      }
+    {
+      const bool keeper = 16 % p.n_pb == 0 ? slice < 16 : slice == 0;          // every workgroup keeps 16 / n_pb of the 16 fragment columns
+      float* keep = (keeper && li < p.N) ? p.dml_all + (long)li * p.Tc * 2 * E + (long)t * 2 * E + 4 * lh : nullptr;
+      const long aidx = (long)arow * 2 * E + 4 * lh;
+      if (p.ks_pa == 2 && 2 * E == 1024)
+        pb_gemm_apre<2, 2>(acc, p.dml_part, aidx, bp, wave, (long)p.N * 2 * E, keep, 16 % p.n_pb == 0 ? p.n_pb : 1, 16 % p.n_pb == 0 ? slice : 0);
+      else {                     // other widths: one share (ks_pa = 1), the streaming product, the step's row copied by slice 0
+        pb_gemm(acc, p.dml_part, aidx, bp, 2 * E, wave);
+        if (slice == 0)
+          for (int i = threadIdx.x; i < p.N * 2 * E; i += PB_THREADS) {
+            const int n_ = i / (2 * E), c_ = i - n_ * 2 * E;
+            p.dml_all[(long)n_ * p.Tc * 2 * E + (long)t * 2 * E + c_] = ld_sc1(p.dml_part + i);
+          }
+      }
+    }
     pb_stash(sm.red, acc, wave, li, lh);
     __syncthreads();
 #pragma unroll
@@ -859,7 +988,7 @@ __device__ void role_pb(const PbParams& p, int slice, PbSmem& sm) {
       const int mm = mm0 + 16 * i;
       if (mm < p.N) {
         float d = pb_sum(sm.red, mm, j);
-        d += ld_sc1(p.dhp + (long)mm * Hp + u);
+        d += dhp_in[i];
         float dc = d * og[i] * (1.f - tc[i] * tc[i]);
         dc += dc_next[i];
         float* g = p.dgates + (long)mm * p.Tc * 4 * Hp + (long)t * 4 * Hp;
@@ -1103,10 +1232,14 @@ bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A) {
          (size_t)(4 + 128 + 512 + 512 + (long)S * A) * sizeof(float) <= 150 * 1024;
 }
 long decode_persist_bwd_counter_words(int Tc) { return ((long)PB_C_COUNT * Tc + 1 + 3) & ~3L; }
+long decode_persist_bwd_part_floats(int N, int E, int H) { return 4L * N * E + 4L * N * E + 4L * N * 2 * E; }
 
 int decode_persist_bwd(PbParams p, hipStream_t st) {
   if (!decode_persist_bwd_ok(p.N, p.Tc, p.S, p.E, p.H, p.A)) return ACVAE_EUNSUPPORTED;
-  p.n_ra = p.H / 32; p.n_rb = p.E / 32; p.n_pa = p.E / 16; p.n_pb = p.E / 32;
+  // K-splits: one resident batch (K <= 512) per workgroup where the K of the product divides that way, at most 4
+  p.ks_rb = (3 * p.H) % 512 == 0 && 3 * p.H / 512 <= 4 ? 3 * p.H / 512 : 1;
+  p.ks_pa = p.E == 512 ? 2 : 1;           // K = 4Hp = 2048 = 2 x 1024 and 2E = 1024: the shapes the split products are written for
+  p.n_ra = p.H / 32; p.n_rb = (p.E / 32) * p.ks_rb; p.n_pa = (p.E / 16) * p.ks_pa; p.n_pb = p.E / 32;
   const long words = decode_persist_bwd_counter_words(p.Tc);
   p.abort_word = p.cnt + (long)PB_C_COUNT * p.Tc;
   if (hipMemsetAsync(p.cnt, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();

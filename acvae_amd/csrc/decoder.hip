@@ -151,7 +151,7 @@ struct DecLayout {
   long skws, skws_p, gi_d, gh_d, gates_p, ml, h0, pd_cnt, scratch_fwd;
   // bwd scratch
   long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
-  long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a,
+  long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a, pd_part,
       dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, pd_cnt_b, scratch_bwd;
   // bwd scratch private to the prior chain (it may run on the second stream)
   long dencproj_p, dvpart_p, dmem_p, drnn_p, tn_p, dpart_p, attws_p;
@@ -220,6 +220,7 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
     L.dpart_p = b.take(2 * acvae::colsum_scratch_doubles(w));
   }
   L.pd_cnt_b = b.take(acvae::decode_persist_bwd_counter_words(Tc));   // arrival counters of the persistent BPTT launch
+  L.pd_part = b.take(acvae::decode_persist_bwd_part_floats(N, E, H));  // its K-split partial tiles
   L.scratch_bwd = b.off;
   return ACVAE_OK;
 }
@@ -934,6 +935,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     pb.d_out = d_out; pb.d_p_z = d_p_z; pb.d_p_means = d_p_means; pb.d_p_logs = d_p_logs;
     pb.dgi = dgi; pb.dgh = dgh; pb.dqd = dqd; pb.dctx = drnn;      // [N, Tc, E] slots in the (later) d rnn_input buffer
     pb.dencproj = dencproj; pb.dmem = dmem; pb.dvpart = dvpart; pb.dgates = dgates; pb.dml_all = dml_all; pb.dhp = dhp;
+    pb.dctx_part = sc + L.pd_part; pb.dhp_part = pb.dctx_part + 4L * N * E; pb.dml_part = pb.dhp_part + 4L * N * E;
     pb.cnt = (unsigned*)(sc + L.pd_cnt_b);
     pb.N = N; pb.Tc = Tc; pb.S = S; pb.E = E; pb.H = H; pb.A = A;
     ACVAE_TRY(acvae::decode_persist_bwd(pb, st.s));

@@ -11,10 +11,15 @@ def build():
     s = open(os.path.join(CSRC, "decode_persist.hip")).read()
     s = s.replace("struct PdSmem {", "__device__ unsigned long long* g_pd_trace = nullptr;\n#define PD_TR(slot) do { if (g_pd_trace && threadIdx.x == 0) { "
                   "g_pd_trace[((long)blockIdx.x * 32 + t) * 8 + (slot)] = wall_clock64(); } } while (0)\nstruct PdSmem {")
-    out, role, waits = [], None, 0
+    out, role, waits, skip = [], None, 0, False
     for l in s.split("\n"):
         if l.startswith("__device__ void role_") or (l.startswith("template <bool RES>")):
-            waits = 0
+            waits = 0; skip = False
+        if l.startswith("__global__"):
+            skip = "posterior_persist" in l          # the posterior's launches run beside the traced ones: no stamps from them
+        if skip:
+            out.append(l)
+            continue
         if "pd_arrive(" in l and "__device__" not in l:
             out += ["    PD_TR(6);", l, "    PD_TR(7);"]
             continue
@@ -75,8 +80,10 @@ def run_bwd():
     ts = TrainStep(model, bench.V)
     feats, caps, fl, cl = bench.synthetic(1)
     f = feats.cuda(); Tc = 21
-    roles = {"RA": (0, 16), "RB": (16, 32), "RC": (32, 64), "PA": (64, 96), "PB": (96, 112)}
-    nblk = 112
+    ks_rb, ks_pa = int(os.environ.get("KS_RB", "3")), int(os.environ.get("KS_PA", "4"))
+    b0 = 16; b1 = b0 + 16 * ks_rb; b2 = b1 + 32; b3 = b2 + 32 * ks_pa; b4 = b3 + 16
+    roles = {"RA": (0, b0), "RB": (b0, b1), "RC": (b1, b2), "PA": (b2, b3), "PB": (b3, b4)}
+    nblk = b4
     buf = torch.zeros(nblk * 32 * 8, dtype=torch.int64, device="cuda")
     lib = _lib.lib(); lib.acvae_pd_trace.argtypes = [ctypes.c_void_p]
     for rep in range(4):
@@ -93,8 +100,8 @@ def run_bwd():
         lastw = np.nanmax(x[:, :, :6], axis=2)
         firstw = np.nanmin(x[:, :, :6], axis=2)
         print(f"{name}: first wait end -> last wait end {np.nanmean(lastw - firstw):.2f}; last wait end -> before arrive {np.nanmean(x[:, :, 6] - lastw):.2f} us (slowest wg {np.nanmean(np.nanmax(x[:, :, 6] - lastw, axis=0)):.2f}); arrive {np.nanmean(x[:, :, 7] - x[:, :, 6]):.2f} us")
-    ra = np.nanmax(t[0:16, :, 7], axis=0); rb = np.nanmax(t[16:32, :, 7], axis=0); rc = np.nanmax(t[32:64, :, 7], axis=0)
-    pa = np.nanmax(t[64:96, :, 7], axis=0); pb = np.nanmax(t[96:112, :, 7], axis=0)
+    ra = np.nanmax(t[0:b0, :, 7], axis=0); rb = np.nanmax(t[b0:b1, :, 7], axis=0); rc = np.nanmax(t[b1:b2, :, 7], axis=0)
+    pa = np.nanmax(t[b2:b3, :, 7], axis=0); pb = np.nanmax(t[b3:b4, :, 7], axis=0)
     # time runs with DEcreasing t
     print("decoder chain step period %.2f us: RC(t+1)->RA(t) %.2f | RA->RB %.2f | RB->RC %.2f" % (
         (ra[1:-2] - ra[2:-1]).mean(), (ra[1:-2] - rc[2:-1]).mean(), (rb[1:-2] - ra[1:-2]).mean(), (rc[1:-2] - rb[1:-2]).mean()))
