@@ -1004,11 +1004,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
     for (long p = p0 + pl; p < p0 + pix_per_block && p < M; p += npl) {
-      const int w = (int)(p % W);
-      const long t = p / W;
-      const int h = (int)(t % H), n = (int)(t / H);
+      int w = 0, h = 0, n = 0;
+      if (UP != UP_PLAIN) {                       // (the plain upstream is the same element of dO: no coordinates)
+        w = (int)(p % W);
+        const long t = p / W;
+        h = (int)(t % H); n = (int)(t / H);
+      }
       const float4 y = load4(Y + p * C + c);
-      float4 g = upstream4<UP>(dO, drop, n, h, w, c, H, W, C);
+      float4 g = UP == UP_PLAIN ? load4(dO + p * C + c) : upstream4<UP>(dO, drop, n, h, w, c, H, W, C);
       if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
       if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
       if (y.z * sc.z + sh.z <= 0.f) g.z = 0.f;
@@ -1065,6 +1068,170 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ Y, const T* __restrict
     o.z = sc.z * (g.z - sg.z * invn - ((y.z - mu.z) * is.z) * (sgy.z * invn));
     o.w = sc.w * (g.w - sg.w * invn - ((y.w - mu.w) * is.w) * (sgy.w * invn));
     store4(dYout + 4 * i, o);
+  }
+}
+
+// ---- round 3: the same two passes with the index arithmetic and the dropout hash off the per-element path.
+// The generic kernels above spend ~150 VALU instructions per float4 on 64-bit divisions / remainders (and, through a pool, a
+// Philox hash per PIXEL: four per pooled element, in both passes); they ran at 4.5-5.2 TB/s where bn_relu_pool_kernel, which
+// hashes once per pooled element, streams at 7.4.
+//   UP_PLAIN: a thread keeps ONE channel quad (the grid stride is a multiple of C/4), its six per-channel constants live in
+//             registers, the element index is the only loop variable; two elements in flight.
+//   UP_POOL : a thread owns one POOLED element (n, ho, wo, c4): one hash, one upstream load, four pixels of Y.  Rows / columns
+//             behind the last full 2x2 window (odd H or W) have no upstream gradient but still get their dY.
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_plain_kernel(const T* __restrict__ Y, const T* __restrict__ dO,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ sum_g, const float* __restrict__ sum_gy,
+                                                                 T* __restrict__ dYout, long total, int C4, float invn) {
+  const long tid = blockIdx.x * 256L + threadIdx.x, stride = gridDim.x * 256L;       // stride % C4 == 0 (launcher)
+  const int c = (int)(tid % C4) * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+  float4 a = *reinterpret_cast<const float4*>(sum_g + c), b = *reinterpret_cast<const float4*>(sum_gy + c);
+  a.x *= invn; a.y *= invn; a.z *= invn; a.w *= invn;
+  b.x *= invn; b.y *= invn; b.z *= invn; b.w *= invn;
+  auto one = [&](float4 y, float4 g) {
+    if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
+    if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
+    if (y.z * sc.z + sh.z <= 0.f) g.z = 0.f;
+    if (y.w * sc.w + sh.w <= 0.f) g.w = 0.f;
+    float4 o;
+    o.x = sc.x * (g.x - a.x - ((y.x - mu.x) * is.x) * b.x);
+    o.y = sc.y * (g.y - a.y - ((y.y - mu.y) * is.y) * b.y);
+    o.z = sc.z * (g.z - a.z - ((y.z - mu.z) * is.z) * b.z);
+    o.w = sc.w * (g.w - a.w - ((y.w - mu.w) * is.w) * b.w);
+    return o;
+  };
+  long i = tid;
+  for (; i + stride < total; i += 2 * stride) {
+    const float4 y0 = load4(Y + 4 * i), g0 = load4(dO + 4 * i);
+    const float4 y1 = load4(Y + 4 * (i + stride)), g1 = load4(dO + 4 * (i + stride));
+    store4(dYout + 4 * i, one(y0, g0));
+    store4(dYout + 4 * (i + stride), one(y1, g1));
+  }
+  if (i < total) store4(dYout + 4 * i, one(load4(Y + 4 * i), load4(dO + 4 * i)));
+}
+
+// pooled element i -> (n, ho, wo, c4) over the grid of 2x2 windows INCLUDING the partial ones (Hc = ceil(H/2), Wc = ceil(W/2))
+struct PoolIdx { int n, ho, wo, c4; };
+__device__ __forceinline__ PoolIdx pool_idx(unsigned i, unsigned C4, unsigned Wc, unsigned Hc) {
+  PoolIdx r;
+  r.c4 = (int)(i % C4);
+  unsigned t = i / C4;
+  r.wo = (int)(t % Wc); t /= Wc;
+  r.ho = (int)(t % Hc);
+  r.n = (int)(t / Hc);
+  return r;
+}
+// upstream gradient of the four pixels of window (n, ho, wo): dP * dropout mask * 1/4 (0 for a partial window)
+template <class T>
+__device__ __forceinline__ float4 pool_upstream(const T* __restrict__ dO, const DropoutSpec& drop, const PoolIdx& q, int Ho, int Wo,
+                                                int C) {
+  if (q.ho >= Ho || q.wo >= Wo) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const long i4 = ((((long)q.n * Ho + q.ho) * Wo + q.wo) * C + q.c4 * 4) >> 2;
+  float4 v = load4(dO + 4 * i4);
+  const float4 m = drop4(drop, i4, q.n, q.ho, q.wo, q.c4 * 4, Ho, Wo, C);
+  v.x *= m.x * 0.25f; v.y *= m.y * 0.25f; v.z *= m.z * 0.25f; v.w *= m.w * 0.25f;
+  return v;
+}
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ Y, const T* __restrict__ dO,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ sum_g, const float* __restrict__ sum_gy,
+                                                                T* __restrict__ dYout, int N, int H, int W, int C, DropoutSpec drop,
+                                                                float invn) {
+  const int C4 = C / 4, Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+  const unsigned total = (unsigned)N * Hc * Wc * C4;          // < 2^31 (launcher)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const PoolIdx q = pool_idx(i, C4, Wc, Hc);
+    const int c = q.c4 * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    float4 a = *reinterpret_cast<const float4*>(sum_g + c), b = *reinterpret_cast<const float4*>(sum_gy + c);
+    a.x *= invn; a.y *= invn; a.z *= invn; a.w *= invn;
+    b.x *= invn; b.y *= invn; b.z *= invn; b.w *= invn;
+    const long base = (((long)q.n * H + 2 * q.ho) * W + 2 * q.wo) * C + c;
+    const bool hx = 2 * q.ho + 1 < H, wx = 2 * q.wo + 1 < W;
+    const long off[4] = {0, (long)C, (long)W * C, (long)W * C + C};
+    const bool ok[4] = {true, wx, hx, hx && wx};
+    float4 y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = ok[k] ? load4(Y + base + off[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 gp = pool_upstream(dO, drop, q, Ho, Wo, C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!ok[k]) continue;
+      float4 g = gp;
+      if (y[k].x * sc.x + sh.x <= 0.f) g.x = 0.f;
+      if (y[k].y * sc.y + sh.y <= 0.f) g.y = 0.f;
+      if (y[k].z * sc.z + sh.z <= 0.f) g.z = 0.f;
+      if (y[k].w * sc.w + sh.w <= 0.f) g.w = 0.f;
+      float4 o;
+      o.x = sc.x * (g.x - a.x - ((y[k].x - mu.x) * is.x) * b.x);
+      o.y = sc.y * (g.y - a.y - ((y[k].y - mu.y) * is.y) * b.y);
+      o.z = sc.z * (g.z - a.z - ((y[k].z - mu.z) * is.z) * b.z);
+      o.w = sc.w * (g.w - a.w - ((y[k].w - mu.w) * is.w) * b.w);
+      store4(dYout + base + off[k], o);
+    }
+  }
+}
+// partials [blocks][2][C] as bn_bwd_reduce_kernel; a block owns `win_per_block` FULL windows (partial ones carry no gradient)
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ Y, const T* __restrict__ dO,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* __restrict__ partials, int N, int H, int W, int C,
+                                                                 int win_per_block, DropoutSpec drop) {
+  extern __shared__ float red[];  // [256][8]
+  const int Cc = C < 1024 ? C : 1024;
+  const int C4 = Cc / 4, Ho = H / 2, Wo = W / 2;
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
+  const unsigned M = (unsigned)N * Ho * Wo;
+  const unsigned p0 = blockIdx.x * (unsigned)win_per_block;
+  const int c = blockIdx.y * Cc + cq * 4;
+  float s[4] = {0, 0, 0, 0}, qv[4] = {0, 0, 0, 0};
+  if (pl < npl) {
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    for (unsigned p = p0 + pl; p < p0 + win_per_block && p < M; p += npl) {
+      PoolIdx q;
+      q.c4 = c >> 2;
+      q.wo = (int)(p % (unsigned)Wo);
+      const unsigned t = p / (unsigned)Wo;
+      q.ho = (int)(t % (unsigned)Ho); q.n = (int)(t / (unsigned)Ho);
+      const long base = (((long)q.n * H + 2 * q.ho) * W + 2 * q.wo) * C + c;
+      const float4 y0 = load4(Y + base), y1 = load4(Y + base + C), y2 = load4(Y + base + (long)W * C),
+                   y3 = load4(Y + base + (long)W * C + C);
+      const float4 gp = pool_upstream(dO, drop, q, Ho, Wo, C);
+      const float4 ys[4] = {y0, y1, y2, y3};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float4 g = gp;
+        const float4 y = ys[k];
+        if (y.x * sc.x + sh.x <= 0.f) g.x = 0.f;
+        if (y.y * sc.y + sh.y <= 0.f) g.y = 0.f;
+        if (y.z * sc.z + sh.z <= 0.f) g.z = 0.f;
+        if (y.w * sc.w + sh.w <= 0.f) g.w = 0.f;
+        s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+        qv[0] += g.x * ((y.x - mu.x) * is.x); qv[1] += g.y * ((y.y - mu.y) * is.y);
+        qv[2] += g.z * ((y.z - mu.z) * is.z); qv[3] += g.w * ((y.w - mu.w) * is.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[k * 256 + threadIdx.x] = s[k]; red[(4 + k) * 256 + threadIdx.x] = qv[k]; }
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < npl; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += red[k * 256 + j * C4 + threadIdx.x];
+    float* out = partials + (long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { out[c + k] = a[k]; out[C + c + k] = a[4 + k]; }
   }
 }
 
@@ -1357,9 +1524,35 @@ int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const floa
   ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st)); /* sum_g (= dbeta) | sum_gy (= dgamma) */        \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<UP_, T>), dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,  \
                      invstd, sum_g, sum_gy, dY, N, H, W, C, drop, batch_stats ? 1 : 0)
-  if (upstream == UP_POOL) { BN_BWD_LAUNCH(UP_POOL); }
+  const float invn = batch_stats ? 1.0f / (float)((long)N * H * W) : 0.f;
+  const bool small = (long)N * H * W * C < (1L << 31);
+  if (upstream == UP_POOL && small && H >= 2 && W >= 2) {
+    // a thread per pooled element: one dropout hash and one upstream load for four pixels
+    const long wins = (long)N * (H / 2) * (W / 2);
+    const int wpb = bnb_pix(C) / 4 > 0 ? bnb_pix(C) / 4 : 1;
+    const dim3 pgrid((unsigned)cdiv(wins, wpb), C / Cc);            // <= nb of the layout: a window is four pixels
+    hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T>), pgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials, N, H, W,
+                       C, wpb, drop);
+    ACVAE_TRY(colsum2(partials, (int)pgrid.x, 2 * C, dpart, sum_g, sum_gy, C, st));
+    const long totalp = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(ew_grid(totalp)), dim3(256), 0, st, Y, dO, scale, shift, mean, invstd,
+                       sum_g, sum_gy, dY, N, H, W, C, drop, invn);
+  } else if (upstream == UP_POOL) { BN_BWD_LAUNCH(UP_POOL); }
   else if (upstream == UP_DROP) { BN_BWD_LAUNCH(UP_DROP); }
-  else { BN_BWD_LAUNCH(UP_PLAIN); }
+  else {
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<UP_PLAIN, T>), rgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials,
+                       N, H, W, C, bnb_pix(C), drop);
+    ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st));
+    // grid stride a multiple of C/4 (256 is one for C <= 1024; an even grid makes it one for C = 2048)
+    int g = ew_grid((total + 1) / 2);
+    if ((C / 4) > 256 && (g & 1)) ++g;
+    if ((256L * g) % (C / 4) == 0)
+      hipLaunchKernelGGL((bn_bwd_apply_plain_kernel<T>), dim3(g), dim3(256), 0, st, Y, dO, scale, shift, mean, invstd, sum_g, sum_gy,
+                         dY, total, C / 4, invn);
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<UP_PLAIN, T>), dim3(ew_grid(total)), dim3(256), 0, st, Y, dO, scale, shift, mean,
+                         invstd, sum_g, sum_gy, dY, N, H, W, C, drop, batch_stats ? 1 : 0);
+  }
 #undef BN_BWD_LAUNCH
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
