@@ -23,6 +23,10 @@
 // then the workgroup's barrier.  No fence anywhere.  Counters are per (role, step), zeroed by the launcher's memset:
 // nothing is ever reset or reused inside the launch.  All workgroups (160 + N + ...) fit the chip at once (512 threads,
 // 34 KB of LDS: two per CU would fit); every spin is bounded and raises an abort word that ends all roles.
+//
+// Also in this file: the backward through time of the same loop (decode_persist_bwd_kernel: roles RA / RB / RC / PA / PB, K-splits
+// with the combine on the reader's side) and the posterior's bidirectional GRU, forward and backward, as one launch per pass
+// (posterior_persist_fwd / _bwd_kernel: one role, one hand-off per step and direction).
 #include "mfma_tile.h"
 #include "common.h"
 #include "../../include/acvae_hip.h"

@@ -318,7 +318,9 @@ int acvae_posterior_bwd(const void* const* params, void* const* grads, const int
 /* The teacher-forced decode loop (all words known, no step feeds the prior's z to the decoder: acvae_decode_fwd with every
  * ss flag set and every dis flag clear) runs as ONE persistent launch (csrc/decode_persist.hip) when N <= 32, S <= 512,
  * E is a power of two in 32..2048 and H, A are multiples of 32; its results are bit-identical to the per-step path.
- * on = 0 forces the per-step path (A/B, parity tests), 1 re-enables it; returns the previous setting (-1: the
+ * The posterior's packed BiGRU (acvae_posterior_fwd / _bwd) runs the same way - one launch per pass for both directions - when
+ * N <= 32 and Hq is a multiple of 32 up to 512.
+ * on = 0 forces the per-step paths (A/B, parity tests), 1 re-enables them; returns the previous setting (-1: the
  * environment's ACVAE_DECODE_PERSIST had not been consulted yet).  Replaces nothing in the reference (scheduling only). */
 int acvae_set_decode_persist(int on);
 
