@@ -112,3 +112,4 @@ int acvae_gemm_nt_pair(const float* A0, int64_t lda0, const float* B0, int64_t l
                        const float* bias1, float* C1, int64_t ldc1, int N1, int acc1, int M, hipStream_t st);
 long acvae_skinny_ws_floats();
 int acvae_skinny_ws_reset(float* ws, hipStream_t st);
+#include "transpose_batch.h"

@@ -712,15 +712,19 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   float *wt_pih = sc + L.wt_pih, *wt_phh = sc + L.wt_phh, *wt_pml = sc + L.wt_pml, *wt_patt = sc + L.wt_patt;
   float *wt_mlo = sc + L.wt_mlo, *wt_ln = sc + L.wt_ln;
   (void)Vp;
-  ACVAE_TRY(transp(P(TP_DEC_CLS_W), H, wt_cls, V, V, H, st));            // [H][V]
-  ACVAE_TRY(transp(P(TP_DEC_WIH), 3 * E, wt_dih, 3 * H, 3 * H, 3 * E, st));  // [3E][3H]
-  ACVAE_TRY(transp(P(TP_DEC_WHH), H, wt_dhh, 3 * H, 3 * H, H, st));      // [H][3H]
-  ACVAE_TRY(transp(P(TP_DEC_ATT_W), E + H, wt_datt, A, A, E + H, st));   // [H+E][A]: rows 0:H query half, H: memory half
-  ACVAE_TRY(transp(P(TP_P_WIH), 3 * E, wt_pih, 4 * Hp, 4 * Hp, 3 * E, st));  // [3E][4Hp]
-  ACVAE_TRY(transp(P(TP_P_WHH), Hp, wt_phh, 4 * Hp, 4 * Hp, Hp, st));    // [Hp][4Hp]
-  ACVAE_TRY(transp(P(TP_P_ML_W), Hp, wt_pml, 2 * E, 2 * E, Hp, st));     // [Hp][2E]
-  ACVAE_TRY(transp(P(TP_P_ATT_W), 2 * E, wt_patt, E, E, 2 * E, st));     // [2E][E]
-  ACVAE_TRY(transp(P(TP_MLO_W), H, wt_mlo, 2 * E, 2 * E, H, st));        // [H][2E]
+  {   // one launch for the nine (they sit in front of the BPTT on the critical path: 9 x 7 us as separate launches)
+    TransposeBatch tb;
+    tb.add(P(TP_DEC_CLS_W), H, wt_cls, V, V, H);                     // [H][V]
+    tb.add(P(TP_DEC_WIH), 3 * E, wt_dih, 3 * H, 3 * H, 3 * E);       // [3E][3H]
+    tb.add(P(TP_DEC_WHH), H, wt_dhh, 3 * H, 3 * H, H);               // [H][3H]
+    tb.add(P(TP_DEC_ATT_W), E + H, wt_datt, A, A, E + H);            // [H+E][A]: rows 0:H query half, H: memory half
+    tb.add(P(TP_P_WIH), 3 * E, wt_pih, 4 * Hp, 4 * Hp, 3 * E);       // [3E][4Hp]
+    tb.add(P(TP_P_WHH), Hp, wt_phh, 4 * Hp, 4 * Hp, Hp);             // [Hp][4Hp]
+    tb.add(P(TP_P_ML_W), Hp, wt_pml, 2 * E, 2 * E, Hp);              // [Hp][2E]
+    tb.add(P(TP_P_ATT_W), 2 * E, wt_patt, E, E, 2 * E);              // [2E][E]
+    tb.add(P(TP_MLO_W), H, wt_mlo, 2 * E, 2 * E, H);                 // [H][2E]
+    ACVAE_TRY(acvae_transpose_batch(tb, st.s));
+  }
   int64_t* words_c = (int64_t*)(sc + L.words_c);
   ACVAE_TRY(acvae::gather_words(words, Tc, 1, words_c, N, Tc, st));
   ACVAE_TRY(fork.begin());

@@ -4,6 +4,7 @@
 // models/text_encoder.py:192,255, models/vae_model.py:726 and the GEMMs inside nn.GRU / nn.LSTM.
 #include <cstdlib>
 #include "mfma_tile.h"
+#include "transpose_batch.h"
 #include "../../include/acvae_hip.h"
 
 namespace {
@@ -139,9 +140,42 @@ __global__ void transpose_kernel(const float* __restrict__ in, long ld_in, float
   }
 }
 
+__global__ void transpose_batch_kernel(TransposeBatch b) {
+  __shared__ float tile[32][33];
+  int m = 0;
+  while (m + 1 < b.n && (int)blockIdx.x >= b.tile0[m + 1]) ++m;
+  const int t = blockIdx.x - b.tile0[m];
+  const int tcols = (b.cols[m] + 31) / 32;
+  const int c0 = (t % tcols) * 32, r0 = (t / tcols) * 32;
+  const float* in = b.in[m];
+  float* out = b.out[m];
+  const int rows = b.rows[m], cols = b.cols[m];
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * b.ld_in[m] + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(long)c * b.ld_out[m] + r] = tile[threadIdx.x][j];
+  }
+}
+
 inline bool vec_ok(const float* p, int64_t ld, int k) { return aligned16(p) && (ld & 3) == 0 && (k & 3) == 0; }
 
 }  // namespace
+
+int acvae_transpose_batch(TransposeBatch& b, hipStream_t st) {
+  if (b.n <= 0) return ACVAE_OK;
+  b.tile0[0] = 0;
+  for (int m = 0; m < b.n; ++m) {
+    if (!b.in[m] || !b.out[m] || b.rows[m] <= 0 || b.cols[m] <= 0) return ACVAE_EINVAL;
+    b.tile0[m + 1] = b.tile0[m] + cdiv(b.cols[m], 32) * cdiv(b.rows[m], 32);
+  }
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(b.tile0[b.n]), dim3(32, 8), 0, st, b);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
 
 // Internal C++ entry (also used by the composite encoder/decoder drivers).
 long acvae_skinny_ws_floats() { return SK_MAX_TILES + (long)SK_MAX_TILES * 1024; }
