@@ -468,6 +468,38 @@ extern "C" int acvae_mse_bwd(const float* a, const float* b, const float* grad_o
   return ACVAE_OK;
 }
 
+// loss = ce + w_kl * kl (+ w_mse * mse): the runner's loss assembly (runners/pytorch_runner_vae.py:315-320) as one launch each way
+// instead of ~a dozen scalar torch kernels in front of the decode backward.  Same arithmetic and order as the torch expression.
+__global__ void loss_combine_fwd_kernel(const float* ce, const float* kl, const float* mse, float w_kl, float w_mse, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float v = ce[0] + w_kl * kl[0];
+    if (mse) v = v + w_mse * mse[0];
+    out[0] = v;
+  }
+}
+__global__ void loss_combine_bwd_kernel(const float* g, float w_kl, float w_mse, float* g_ce, float* g_kl, float* g_mse) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float v = g[0];
+    g_ce[0] = v;
+    g_kl[0] = v * w_kl;
+    if (g_mse) g_mse[0] = v * w_mse;
+  }
+}
+extern "C" int acvae_loss_combine_fwd(const float* ce, const float* kl, const float* mse, float w_kl, float w_mse, float* out,
+                                      void* stream) {
+  if (!ce || !kl || !out) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ce, kl, mse, w_kl, w_mse, out);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+extern "C" int acvae_loss_combine_bwd(const float* grad_out, float w_kl, float w_mse, float* g_ce, float* g_kl, float* g_mse,
+                                      void* stream) {
+  if (!grad_out || !g_ce || !g_kl) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grad_out, w_kl, w_mse, g_ce, g_kl, g_mse);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
 extern "C" int acvae_row_logsoftmax_argmax(const float* logits, int64_t ld_n, int64_t ld_t, int64_t* argmax,
                                            float* max_logprob, float* lse, int64_t o_sn, int64_t o_st, int N, int T,
                                            int V, void* stream) {

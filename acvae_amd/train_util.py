@@ -156,6 +156,33 @@ class _MSEFn(torch.autograd.Function):
         return da, db
 
 
+class _CombineLossFn(torch.autograd.Function):
+    """loss = ce + w_kl * kl (+ w_mse * mse) on device scalars (runners/pytorch_runner_vae.py:315-320): one launch forward, one
+    backward - the same arithmetic as the tensor expression, without its dozen scalar kernels on the step's critical path."""
+
+    @staticmethod
+    def forward(ctx, ce, kl, mse, w_kl, w_mse):
+        _lib.require_cuda(ce, kl)
+        out = _dev_scalar(ce.device)
+        _lib.call("acvae_loss_combine_fwd", ce.reshape(1), kl.reshape(1), None if mse is None else mse.reshape(1), float(w_kl),
+                  float(w_mse), out, _lib.current_stream())
+        ctx.w = (float(w_kl), float(w_mse), mse is not None)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        w_kl, w_mse, has_mse = ctx.w
+        gs = torch.empty(3, device=g.device)
+        _lib.call("acvae_loss_combine_bwd", g.contiguous().float().reshape(1), w_kl, w_mse, gs[0:1], gs[1:2],
+                  gs[2:3] if has_mse else None, _lib.current_stream())
+        return gs[0], gs[1], (gs[2] if has_mse else None), None, None
+
+
+def combine_losses(ce, kl, mse=None, kl_weight=1.0, alpha=0.0):
+    """ce + kl_weight * kl + alpha * mse as the runner forms it, fused (device scalars in, device scalar out)."""
+    return _CombineLossFn.apply(ce, kl, mse, kl_weight, alpha if mse is not None else 0.0)
+
+
 class MSELoss(nn.Module):
     """nn.MSELoss() as used for the global constraint (runners/pytorch_runner_vae.py:220,317)."""
 

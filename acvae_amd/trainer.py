@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .train_util import LabelSmoothingLoss, MSELoss, Normal_kl_loss
+from .train_util import LabelSmoothingLoss, MSELoss, Normal_kl_loss, combine_losses
 
 
 class FlatGradExchange:
@@ -271,11 +271,10 @@ class TrainStep:
         targets = (caps if caps_src is None else caps_src)[:, 1:1 + out["logits"].shape[1]].to(torch.long)
         ce = self.criterion.masked(out["logits"], targets, lens1)     # == criterion(packed_logits, packed targets)
         kl = self.kl_loss(out["q_means"], out["q_logs"], out["p_means"], out["p_logs"])
-        loss = ce + kl_weight * kl
         mse = None
         if self.alpha is not None:
             mse = self.mse_loss(out["q_means_utt"], out["p_means_utt"])
-            loss = loss + self.alpha * mse
+        loss = combine_losses(ce, kl, mse, kl_weight, self.alpha if self.alpha is not None else 0.0)    # ce + w kl + alpha mse
         return loss, {"ce": ce.detach(), "kl": kl.detach(), "mse": None if mse is None else mse.detach()}, out
 
     def step(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):

@@ -135,6 +135,10 @@ int acvae_ls_ce_bwd(const float* logits, int64_t ld_n, int64_t ld_t, const int64
 /* mean((a-b)^2) over n elements and its backward (runner :317, nn.MSELoss). */
 int acvae_mse_fwd(const float* a, const float* b, float* partials, float* out_scalar, int64_t n, void* stream);
 int acvae_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, float* db, int64_t n, void* stream);
+/* A10 loss assembly, runners/pytorch_runner_vae.py:315-320: loss = ce + w_kl * kl (+ w_mse * mse; mse may be NULL) on device
+ * scalars, and its gradient (g, g * w_kl, g * w_mse) - one launch each instead of a chain of scalar tensor kernels. */
+int acvae_loss_combine_fwd(const float* ce, const float* kl, const float* mse, float w_kl, float w_mse, float* out, void* stream);
+int acvae_loss_combine_bwd(const float* grad_out, float w_kl, float w_mse, float* g_ce, float* g_kl, float* g_mse, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1  Cnn10.forward  models/encoder.py:672-707 (ConvBlock :606-649) and its backward.
