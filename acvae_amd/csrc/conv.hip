@@ -602,7 +602,10 @@ __global__ __launch_bounds__(256) void bn0_stats_kernel(const float* __restrict_
 
 // Column sums of a [P][width] fp32 partial matrix in two fixed-order stages (deterministic):
 // stage 1: grid (width/64, R) blocks, block r sums rows p = r, r+R, ... in fp64 -> dpart[r][width].
-constexpr int CS_R = 16;
+constexpr int CS_R = 64;          // most row groups of stage 1 (scratch: CS_R x width doubles)
+// Row groups for P partial rows: 16 up to 1024 rows, 32 up to 4096, 64 beyond - with 16 groups the 8000-row partials of the
+// 64-channel layers were read by 32 workgroups (42 us for 4 MB); the second stage reads the groups' sums.
+inline int cs_groups(int P) { return P < 1 ? 1 : P < 16 ? P : P <= 1024 ? 16 : P <= 4096 ? 32 : CS_R; }
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ partials, int P, int width,
                                                             double* __restrict__ dpart) {
   __shared__ double red[4][64];
@@ -1434,7 +1437,7 @@ int bn0_partials_rows(long rows) { return cdiv(rows, 256); }
 
 int colsum2(const float* partials, int P, int width, double* dpart, float* out, float* out2, int split,
             hipStream_t st) {
-  const int R = P < CS_R ? (P < 1 ? 1 : P) : CS_R;
+  const int R = cs_groups(P);
   hipLaunchKernelGGL(colsum_stage1_kernel, dim3(cdiv(width, 64), R), dim3(256), 0, st, partials, P, width, dpart);
   hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(width, 64)), dim3(64), 0, st, dpart, R, width, out, out2, split);
   ACVAE_LAUNCH_CHECK();
@@ -1447,7 +1450,7 @@ int bn_finalize(const float* partials, int P, int C, double count, const float* 
                 float* mean, float* invstd, double* dpart, hipStream_t st) {
   int R = 0;
   if (training) {
-    R = P < CS_R ? (P < 1 ? 1 : P) : CS_R;
+    R = cs_groups(P);
     hipLaunchKernelGGL(colsum_stage1_kernel, dim3(cdiv(2 * C, 64), R), dim3(256), 0, st, partials, P, 2 * C, dpart);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, dpart, R, C, count, gamma, beta,
