@@ -278,3 +278,25 @@ def test_attention_split_over_frames_matches_one_workgroup_per_row(N, Tq, S_, A,
         for n in range(N):
             assert float(w[n, :, int(lens[n]):].abs().max()) == 0.0 if int(lens[n]) < S_ else True
         torch.testing.assert_close(w.sum(-1), torch.ones(N, Tq, device="cuda"), rtol=0, atol=1e-5)
+
+
+def test_loss_assembly_equals_the_tensor_expression():
+    """combine_losses(ce, kl, mse, kl_weight, alpha) = ce + kl_weight * kl + alpha * mse as the runner writes it
+    (runners/pytorch_runner_vae.py:315-320): the same fp32 value bit for bit, and the gradients (g, g kl_weight, g alpha);
+    mse=None leaves the last term out."""
+    from acvae_amd.train_util import combine_losses
+    g = torch.Generator().manual_seed(11)
+    for kl_w, alpha, with_mse in ((0.5, 1.0, True), (0.37, 2.5, True), (1.0, 0.0, False)):
+        vals = [torch.randn((), generator=g).mul(10).cuda().requires_grad_(True) for _ in range(3)]
+        ce, kl, mse = vals
+        out = combine_losses(ce, kl, mse if with_mse else None, kl_w, alpha)
+        ref = ce.detach() + kl_w * kl.detach()
+        if with_mse:
+            ref = ref + alpha * mse.detach()
+        assert torch.equal(out.detach(), ref)
+        (out * 3.0).backward()
+        assert float(ce.grad) == 3.0 and float(kl.grad) == np.float32(3.0) * np.float32(kl_w)
+        if with_mse:
+            assert float(mse.grad) == np.float32(3.0) * np.float32(alpha)
+        else:
+            assert mse.grad is None
