@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "acvae_hip.h")
-LIB_PATH = os.environ.get("ACVAE_DEV_LIB") or os.path.join(_HERE, "libacvae_hip.so")   # dev hook: A/B builds (tools/)
+LIB_PATH = os.path.join(_HERE, "libacvae_hip.so")      # the product library; tools load an A/B build with use_library()
 
 _CT = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
        "uint64_t": ctypes.c_uint64}
@@ -57,7 +57,59 @@ _defs = dict(re.findall(r"#define\s+(ACVAE_\w+)\s+(\d+)", open(HEADER).read()))
 ENUMS_TEXT_N = int(_defs["ACVAE_TEXT_NPARAMS"])
 ENC_NPARAMS = int(_defs["ACVAE_ENC_NPARAMS"])
 ENC_BF16 = int(_defs["ACVAE_ENC_BF16"])
+FLAG_NO_PERSIST = int(_defs["ACVAE_FLAG_NO_PERSIST"])
+FLAG_DEFER_PARAM_GRADS = int(_defs["ACVAE_FLAG_DEFER_PARAM_GRADS"])
+FLAG_NO_ATTN_SPLIT = int(_defs["ACVAE_FLAG_NO_ATTN_SPLIT"])
+FLAG_TEST_STALL = int(_defs["ACVAE_FLAG_TEST_STALL"])
 _lib = None
+
+
+class options:
+    """Host-side defaults for the per-call `flags` of the C ABI (the library itself keeps no switches).  Tests and the
+    A/B tools change them through `with _lib.override(persist=False): ...`; the environment variables of the earlier
+    rounds still set the initial values."""
+    persist = os.environ.get("ACVAE_DECODE_PERSIST", "1") != "0"      # persistent decode / posterior launches
+    defer = os.environ.get("ACVAE_DECODE_DEFER", "1") != "0"          # decode backward: parameter gradients trail on the side stream
+    attn_split = True                                                 # split-over-frames attention for few query rows
+    test_stall = False                                                # ACVAE_FLAG_TEST_STALL (tests only)
+
+
+class override:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: getattr(options, k) for k in self.kw}
+        for k, v in self.kw.items():
+            setattr(options, k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            setattr(options, k, v)
+        return False
+
+
+def call_flags(defer=False):
+    f = 0
+    if not options.persist:
+        f |= FLAG_NO_PERSIST
+    if not options.attn_split:
+        f |= FLAG_NO_ATTN_SPLIT
+    if options.test_stall:
+        f |= FLAG_TEST_STALL
+    if defer and options.defer:
+        f |= FLAG_DEFER_PARAM_GRADS
+    return f
+
+
+def use_library(path):
+    """Load another build of the library (tools/ab_build.py) instead of the product one.  Explicit and process-wide: must
+    be called before the first library call."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("acvae_amd._lib.use_library() must come before the first library call")
+    LIB_PATH = os.path.abspath(path)
 
 
 def lib():
@@ -92,6 +144,54 @@ def call(name, *args):
         what = ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
         raise RuntimeError(f"{name} failed: {what}")
     return rc
+
+
+# ---- persistent launches: status words (include/acvae_hip.h, acvae_persist_status_register)
+_STATUS = {}
+_STATUS_NAMES = ("decode forward", "decode backward", "posterior forward", "posterior backward")
+
+
+def persist_status(dev):
+    """The device's status words (page-locked int32[8], registered with the library on first use)."""
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _STATUS.get(key)
+    if t is None:
+        t = torch.zeros(8, dtype=torch.int32).pin_memory()
+        call("acvae_persist_status_register", key, t.data_ptr())
+        _STATUS[key] = t
+    return t
+
+
+def check_persist_status(dev):
+    """Raise if a persistent launch on `dev` gave up since the last check.  Meaningful once the streams that carried the
+    launches have drained (TrainStep calls it behind its in-flight event); the launch's outputs are NaN either way."""
+    t = persist_status(dev)
+    if int(t[4]) != 0:
+        which = [n for k, n in enumerate(_STATUS_NAMES) if int(t[k]) != 0]
+        t.zero_()
+        raise RuntimeError("acvae_amd: a persistent launch could not complete (" + ", ".join(which) + "): part of its grid was "
+                           "never resident - is another process running persistent kernels on this GPU?  Its outputs were "
+                           "overwritten with NaN.  ACVAE_DECODE_PERSIST=0 selects the per-step launches.")
+
+
+# ---- workspaces of acvae_attn_fwd's split-over-frames form: zeroed once, one per (device, stream)
+_ATTN_WS = {}
+
+
+def attn_fwd_workspace(N, Tq, S, A, E, dev):
+    """(tensor or None, bytes) for acvae_attn_fwd on the current stream.  The counters at its head must start zeroed and are
+    left zeroed by every call, so the buffer is cached per stream and only re-made (zeroed) when it has to grow."""
+    nbytes = call("acvae_attn_fwd_workspace_bytes", N, Tq, S, A, E)
+    if nbytes <= 0 or not options.attn_split:
+        return None, 0
+    dev = torch.device(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), current_stream())
+    t = _ATTN_WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)
+        _ATTN_WS[key] = t
+    return t, t.numel()
 
 
 def require_cuda(*tensors):

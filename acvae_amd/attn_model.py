@@ -33,6 +33,7 @@ class Seq2SeqAttention(nn.Module):
         _lib.call("acvae_gemm_nt", h_dec, Hd, W, Hd + E, None, qproj, A, N, A, Hd, 0, st)
         ctx = torch.empty(N, E, device=dev)
         weights = torch.empty(N, S, device=dev)
+        ws, ws_b = _lib.attn_fwd_workspace(N, 1, S, A, E, dev)
         _lib.call("acvae_attn_fwd", qproj, A, 0, encproj, h_enc, lens, self.v, ctx, E, 0, weights, S, 0, N, 1, S, A, E,
-                  st)
+                  ws, ws_b, st, _lib.call_flags())
         return ctx, weights

@@ -11,6 +11,8 @@ LIB = os.path.join(HERE, "libacvae_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]   # no implicit FMA contraction: keeps fp32 results reproducible vs the oracle
+if os.environ.get("ACVAE_EXACT_TANH") == "1":      # parity-debug build: the attention's tanh from the math library (common.h)
+    FLAGS.append("-DACVAE_EXACT_TANH")
 
 
 def sources():

@@ -8,9 +8,7 @@
 // tanh-dot (wave64 shuffle reduction), scores/weights staged in LDS, context by E-strided lanes so
 // every enc row is read as full 128-B lines.
 #include "common.h"
-#include <mutex>
 #include <type_traits>
-#include <unordered_map>
 #include "../../include/acvae_hip.h"
 
 namespace {
@@ -490,42 +488,33 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ dq_part, const 
   }
 }
 
-// Scratch of the split kernel, one per HIP stream (calls on different streams run side by side: the prior chain and the
-// decoder chain of a decode step): [rows][nsplit][E + 4] partials (context, max, sum, pad) and a counter per row, zero between launches (the
-// combining workgroup resets it).  Grown on demand; hipFree synchronises the device, so nothing still reads the old one.
-struct AttnSplitScratch { float* part = nullptr; unsigned* cnt = nullptr; size_t part_floats = 0; long rows = 0; };
-bool g_attn_split = true;
-AttnSplitScratch* attn_split_scratch(hipStream_t st, long rows, int nsplit, int E) {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, AttnSplitScratch> reg;
-  std::lock_guard<std::mutex> lock(mu);
-  AttnSplitScratch& sc = reg[st];
-  const size_t need = (size_t)rows * nsplit * (E + 4);
-  if (need > sc.part_floats) {
-    if (sc.part) (void)hipFree(sc.part);
-    sc.part = nullptr; sc.part_floats = 0;
-    if (hipMalloc(&sc.part, need * sizeof(float)) != hipSuccess) return nullptr;
-    sc.part_floats = need;
-  }
-  if (rows > sc.rows) {
-    if (sc.cnt) (void)hipFree(sc.cnt);
-    sc.cnt = nullptr; sc.rows = 0;
-    const long nr = rows < 256 ? 256 : rows;
-    if (hipMalloc(&sc.cnt, nr * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(sc.cnt, 0, nr * sizeof(unsigned)) != hipSuccess) return nullptr;
-    sc.rows = nr;
-  }
-  return &sc;
+// Workspace of the split kernel (caller-owned, acvae_attn_fwd_workspace_bytes): ATS_CNT_WORDS arrival counters, one per
+// query row, then [rows][nsplit][E + 4] partials (context, max, sum, pad).  The counters must be zero when a call starts
+// and are zero again when it has run (the combining workgroup resets its row's word), so a caller zeroes the first
+// ATS_CNT_WORDS * 4 bytes ONCE and may then reuse the workspace for any number of stream-ordered calls; two calls that may
+// run side by side (two streams) need a workspace each.
+constexpr int ATS_CNT_WORDS = 256;
+inline bool attn_split_shape(long rows, int S, int A, int E) {
+  const int nsplit = (S + ATS_CHUNK - 1) / ATS_CHUNK;
+  const int G = (E & 3) == 0 && E >= 4 && E / 4 <= ATS_THREADS ? ATS_THREADS / (E / 4) : 0;
+  return (A & 3) == 0 && (E & 3) == 0 && G > 0 && rows * 2 <= ATS_CNT_WORDS && nsplit >= 2 && nsplit <= 512 &&
+         (size_t)(ATS_CHUNK + 16 + ((nsplit + 3) & ~3) + (long)G * E) * sizeof(float) <= 64 * 1024;
 }
 
 }  // namespace
 
-extern "C" int acvae_set_attn_split(int on) { const int was = g_attn_split ? 1 : 0; g_attn_split = on != 0; return was; }
+extern "C" int64_t acvae_attn_fwd_workspace_bytes(int N, int Tq, int S, int A, int E) {
+  if (N <= 0 || Tq <= 0 || S <= 0 || A <= 0 || E <= 0) return -1;
+  const long rows = (long)N * Tq;
+  if (!attn_split_shape(rows, S, A, E)) return 0;          // the one-workgroup form needs none
+  const long nsplit = (S + ATS_CHUNK - 1) / ATS_CHUNK;
+  return (int64_t)ATS_CNT_WORDS * 4 + rows * nsplit * (E + 4) * (int64_t)sizeof(float);
+}
 
 extern "C" int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, const float* encproj, const float* enc,
                               const int64_t* lens, const float* v, float* ctx, int64_t c_sn, int64_t c_sj,
-                              float* weights, int64_t w_sn, int64_t w_sj, int N, int Tq, int S, int A, int E,
-                              void* stream) {
+                              float* weights, int64_t w_sn, int64_t w_sj, int N, int Tq, int S, int A, int E, void* ws,
+                              int64_t ws_bytes, void* stream, int flags) {
   if (!qproj || !encproj || !enc || !lens || !v || !ctx || !weights) return ACVAE_EINVAL;
   if (N <= 0 || Tq <= 0 || S <= 0 || A <= 0 || E <= 0) return ACVAE_EINVAL;
   if (S > 8192) return ACVAE_EUNSUPPORTED;
@@ -533,20 +522,20 @@ extern "C" int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, co
     return ACVAE_EALIGN;
   const int threads = (long)N * Tq < 256 ? ATT_THREADS_BIG : ATT_THREADS;
   const bool vec = (A & 3) == 0 && (E & 3) == 0 && E / 4 <= threads && aligned16(enc);
-  // few rows and more than one chunk of frames: split S over workgroups (see attn_fwd_split_kernel)
+  // few rows and more than one chunk of frames: split S over workgroups (see attn_fwd_split_kernel) - when the caller
+  // handed over the workspace for it; without one (or with ACVAE_FLAG_NO_ATTN_SPLIT) the one-workgroup form runs
   const int nsplit = (S + ATS_CHUNK - 1) / ATS_CHUNK;
-  if (g_attn_split && vec && (long)N * Tq * 2 <= 256 && nsplit >= 2 && nsplit <= 512 && E / 4 <= ATS_THREADS && aligned16(ctx) &&
-      (c_sn & 3) == 0 && (c_sj & 3) == 0) {
-    AttnSplitScratch* sc = attn_split_scratch((hipStream_t)stream, (long)N * Tq, nsplit, E);
-    if (!sc) return ACVAE_EWORKSPACE;
+  if (ws && !(flags & ACVAE_FLAG_NO_ATTN_SPLIT) && vec && attn_split_shape((long)N * Tq, S, A, E) && aligned16(ctx) &&
+      aligned16(ws) && (c_sn & 3) == 0 && (c_sj & 3) == 0) {
+    if (ws_bytes < acvae_attn_fwd_workspace_bytes(N, Tq, S, A, E)) return ACVAE_EWORKSPACE;
+    unsigned* cnt = reinterpret_cast<unsigned*>(ws);
+    float* part = reinterpret_cast<float*>(ws) + ATS_CNT_WORDS;
     const int G = ATS_THREADS / (E / 4);
     const size_t shm = (size_t)(ATS_CHUNK + 16 + ((nsplit + 3) & ~3) + (long)G * E) * sizeof(float);
-    if (shm <= 64 * 1024) {
-      hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(N * Tq * nsplit), dim3(ATS_THREADS), shm, (hipStream_t)stream, qproj, q_sn,
-                         q_sj, encproj, enc, lens, v, ctx, c_sn, c_sj, weights, w_sn, w_sj, Tq, S, A, E, nsplit, sc->part, sc->cnt);
-      ACVAE_LAUNCH_CHECK();
-      return ACVAE_OK;
-    }
+    hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(N * Tq * nsplit), dim3(ATS_THREADS), shm, (hipStream_t)stream, qproj, q_sn,
+                       q_sj, encproj, enc, lens, v, ctx, c_sn, c_sj, weights, w_sn, w_sj, Tq, S, A, E, nsplit, part, cnt);
+    ACVAE_LAUNCH_CHECK();
+    return ACVAE_OK;
   }
   const int groups = vec ? threads / (E / 4) : 0;
   const size_t shm = (size_t)(((S + 16 + 3) & ~3) + (long)groups * E) * sizeof(float);
@@ -557,6 +546,19 @@ extern "C" int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, co
   else
     hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(N * Tq), dim3(threads), shm, (hipStream_t)stream, qproj, q_sn,
                        q_sj, encproj, enc, lens, v, ctx, c_sn, c_sj, weights, w_sn, w_sj, Tq, S, A, E);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+namespace {
+__global__ void tanh_att_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = tanh_att(x[i]);
+}
+}  // namespace
+extern "C" int acvae_tanh_att(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return ACVAE_EINVAL;
+  hipLaunchKernelGGL(tanh_att_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

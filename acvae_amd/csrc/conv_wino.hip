@@ -13,8 +13,10 @@
 //     that the 16 tiles a 16-lane LDS read group serves are 16 consecutive 16-byte slots;
 //   * every wavefront builds the Bt d B fragments of its 8 positions in registers from 12 ds_read_b128 (64 adds, issued as
 //     32 v_pk_add_f32, per 32 MFMAs) - the vertical half of the transform splits cleanly over the two position halves: rows 0-2 / 1-3;
-//   * G g G^T is precomputed per step into the exact LDS image of a weight panel (wino_weights_kernel) and streams
-//     global -> LDS by LDS-DMA, 32 KB per 8-channel chunk;
+//   * G g G^T is precomputed per step (wino_weights_kernel, all layers in one launch) into a 32 KB-per-8-channel-chunk image
+//     whose fragments go from L2 STRAIGHT into the MFMA operand registers (raw_buffer_load_b128 into a ring of four
+//     float4 per lane, reloaded four position groups ahead): they never pass through LDS (round 3; the LDS-DMA path
+//     cost ~470 cycles per chunk);
 //   * the epilogue applies At . A in registers, the two position halves of a tile meet through LDS once per tile, and
 //     the BatchNorm batch statistics of the raw output are reduced exactly like conv.hip's epilogue does.
 // The same kernel is the data gradient (X = dY, filter flipped and transposed by wino_weights_kernel, no activation).

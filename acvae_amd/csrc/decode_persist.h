@@ -1,5 +1,6 @@
 // decode_persist.hip: the teacher-forced decode loop as one persistent launch (internal C++ interface; the C ABI entry is
-// acvae_decode_fwd, which takes this path when acvae::decode_persist_ok says so).
+// acvae_decode_fwd, which takes this path when acvae::decode_persist_ok says so: the shape is one the kernel takes AND its
+// whole grid is resident on the current device at once; `flags`: ACVAE_FLAG_* of include/acvae_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -23,6 +24,7 @@ struct PdParams {
   float *rnn_p, *hp_all, *c_all, *lstm_save, *p_means, *p_logs, *p_z;
   unsigned* cnt;                   // decode_persist_counter_words(Tc) words, zeroed by the launcher
   unsigned* abort_word;            // set by the launcher (last counter word)
+  unsigned spin_limit;             // set by the launcher: polls after which a wait gives up and raises abort_word
   int N, Tc, S, E, H, A;
   int n_d1, n_d3, n_p1, n_p2;      // set by the launcher
   int att_resident;                // set by the launcher: the attention keeps its clip's memory on the CU
@@ -47,6 +49,7 @@ struct PbParams {
   float *dctx_part, *dhp_part, *dml_part;
   unsigned* cnt;
   unsigned* abort_word;
+  unsigned spin_limit;
   int N, Tc, S, E, H, A;
   int n_ra, n_rb, n_pa, n_pb;
   int ks_rb, ks_pa;                // K-splits of the RB / PA products (set by the launcher)
@@ -55,11 +58,11 @@ struct PbParams {
 namespace acvae {
 bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A);
 long decode_persist_bwd_counter_words(int Tc);
-int decode_persist_bwd(PbParams p, hipStream_t st);
+int decode_persist_bwd(PbParams p, hipStream_t st, int flags);
 long decode_persist_bwd_part_floats(int N, int E, int H);
 bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A);
 long decode_persist_counter_words(int Tc);
-int decode_persist_fwd(PdParams p, hipStream_t st);
+int decode_persist_fwd(PdParams p, hipStream_t st, int flags);
 }  // namespace acvae
 
 
@@ -80,6 +83,7 @@ struct PqParams {
   float* hbuf;                 // [2 directions][2 step parities][N][Hq]: the state in flight, ZEROED by the caller (step 0 reads parity 1)
   unsigned* cnt;               // posterior_persist_counter_words(Tc), zeroed by the launcher
   unsigned* abort_word;        // set by the launcher
+  unsigned spin_limit;         // set by the launcher
   int N, Tc, Hq;
 };
 struct PqbParams {
@@ -92,11 +96,12 @@ struct PqbParams {
   float* dgh[2];               // [N][Tc][3Hq] (handed over inside the launch)
   unsigned* cnt;
   unsigned* abort_word;
+  unsigned spin_limit;
   int N, Tc, Hq;
 };
 namespace acvae {
 bool posterior_persist_ok(int N, int Tc, int Hq);
 long posterior_persist_counter_words(int Tc);
-int posterior_persist_fwd(PqParams p, hipStream_t st);
-int posterior_persist_bwd(PqbParams p, hipStream_t st);
+int posterior_persist_fwd(PqParams p, hipStream_t st, int flags);
+int posterior_persist_bwd(PqbParams p, hipStream_t st, int flags);
 }  // namespace acvae

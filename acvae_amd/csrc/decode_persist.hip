@@ -31,12 +31,14 @@
 #include "common.h"
 #include "../../include/acvae_hip.h"
 #include "decode_persist.h"
+#include <atomic>
+#include <mutex>
 
 namespace {
 using namespace mfma;
 
 constexpr int PD_THREADS = 512;          // 8 wavefronts, as gemm_skinny_kernel
-constexpr unsigned PD_SPIN_LIMIT = 1u << 24;   // x ~150 ns: seconds; never reached unless a role died
+constexpr unsigned PD_SPIN_LIMIT = 1u << 24;   // polls x ~150 ns: seconds; never reached unless part of the grid is not resident
 
 #define PD_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -57,12 +59,12 @@ __device__ __forceinline__ float4 ld_sc1_4(const float* base, long idx) {
 
 // Lane 0 waits until *cnt >= target (relaxed polls, s_sleep between them), then the workgroup's barrier.  Returns false
 // when the launch is aborting (a bounded spin ran out somewhere): every role then leaves its loop.
-__device__ __forceinline__ bool pd_wait(const unsigned* cnt, unsigned target, unsigned* abort_word, int* s_flag) {
+__device__ __forceinline__ bool pd_wait(const unsigned* cnt, unsigned target, unsigned* abort_word, unsigned spin_limit, int* s_flag) {
   if (threadIdx.x == 0) {
     int ok = 1;
     for (unsigned spins = 0; __hip_atomic_load(cnt, PD_RLX_AGENT) < target;) {
       __builtin_amdgcn_s_sleep(2);
-      if ((++spins & 255u) == 0u && (spins > PD_SPIN_LIMIT || __hip_atomic_load(abort_word, PD_RLX_AGENT) != 0u)) {
+      if ((++spins & 255u) == 0u && (spins > spin_limit || __hip_atomic_load(abort_word, PD_RLX_AGENT) != 0u)) {
         __hip_atomic_store(abort_word, 1u, PD_RLX_AGENT);
         ok = 0;
         break;
@@ -194,7 +196,7 @@ __device__ void role_d1(const PdParams& p, int tile, PdSmem& sm) {
   pd_fetch_b(fb, bp, p.H, wave);
   const float bias = is_q ? 0.f : p.b_hh[n0 + (threadIdx.x & 31)];      // both outputs of a thread share the column
   for (int t = 0; t < p.Tc; ++t) {
-    if (t > 0 && !pd_wait(p.cnt + PD_C_D3 * p.Tc + (t - 1), (unsigned)p.n_d3, p.abort_word, &sm.flag)) return;
+    if (t > 0 && !pd_wait(p.cnt + PD_C_D3 * p.Tc + (t - 1), (unsigned)p.n_d3, p.abort_word, p.spin_limit, &sm.flag)) return;
     const float* hprev = t ? p.outputs + (long)(t - 1) * p.H : p.zeros;
     const long ldh = t ? (long)p.Tc * p.H : (long)p.H;
     f32x16 acc;
@@ -257,7 +259,7 @@ __device__ void role_d2(const PdParams& p, int n, float* smem, int* s_flag) {
     vv[i] = a < A ? *reinterpret_cast<const float4*>(v + a) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int t = 0; t < p.Tc; ++t) {
-    if (!pd_wait(p.cnt + PD_C_D1Q * p.Tc + t, (unsigned)(A / 32), p.abort_word, s_flag)) return;
+    if (!pd_wait(p.cnt + PD_C_D1Q * p.Tc + t, (unsigned)(A / 32), p.abort_word, p.spin_limit, s_flag)) return;
     const long qi = (long)n * p.Tc * A + (long)t * A;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -361,12 +363,12 @@ __device__ void role_d3(const PdParams& p, int slice, PdSmem& sm) {
       const float* gi = p.gi + (long)mm * p.Tc * 3 * H + (long)t * 3 * H;
       g_r = gi[u]; g_z = gi[H + u]; g_n = gi[2 * H + u];
     }
-    if (!pd_wait(p.cnt + PD_C_D1H * p.Tc + t, (unsigned)(3 * H / 32), p.abort_word, &sm.flag)) return;
+    if (!pd_wait(p.cnt + PD_C_D1H * p.Tc + t, (unsigned)(3 * H / 32), p.abort_word, p.spin_limit, &sm.flag)) return;
     if (mine) {
       const float* gh = p.gh + (long)mm * 3 * H;
       b_r = ld_sc1(gh + u); b_z = ld_sc1(gh + H + u); ghn = ld_sc1(gh + 2 * H + u);
     }
-    if (!pd_wait(p.cnt + PD_C_D2 * p.Tc + t, (unsigned)p.N, p.abort_word, &sm.flag)) return;
+    if (!pd_wait(p.cnt + PD_C_D2 * p.Tc + t, (unsigned)p.N, p.abort_word, p.spin_limit, &sm.flag)) return;
     const long ai = (long)arow * p.Tc * 3 * E + (long)t * 3 * E + E + 4 * lh;
     f32x16 acc, acc2;
 #pragma unroll
@@ -439,17 +441,17 @@ __device__ void role_p1(const PdParams& p, int slice, PdSmem& sm) {
     if (E <= 64 * PD_U) {
       // hp_{t-1} is complete long before z_{t-1} (P2 works from it): fetch it behind this role's own counter, then wait for z
       float4 ah[PD_U], azv[PD_U];
-      if (t > 0 && !pd_wait(p.cnt + PD_C_P1 * p.Tc + (t - 1), (unsigned)p.n_p1, p.abort_word, &sm.flag)) return;
+      if (t > 0 && !pd_wait(p.cnt + PD_C_P1 * p.Tc + (t - 1), (unsigned)p.n_p1, p.abort_word, p.spin_limit, &sm.flag)) return;
       if (t) pd_load_a<true>(ah, hprev, arow * ldh + 4 * lh, Hp, wave);
       else pd_load_a<false>(ah, hprev, arow * ldh + 4 * lh, Hp, wave);
-      if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, &sm.flag)) return;
+      if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, p.spin_limit, &sm.flag)) return;
       if (t) pd_load_a<true>(azv, p.rnn_p, zi, E, wave);
       else pd_load_a<false>(azv, p.rnn_p, zi, E, wave);
       __builtin_amdgcn_sched_barrier(0);
       pd_mfma(acc, azv, fbz, E, wave);             // the per-step path's order: the z product, then the hp product
       pd_mfma(acc, ah, fbh, Hp, wave);
     } else {
-      if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, &sm.flag)) return;
+      if (t > 0 && !pd_wait(p.cnt + PD_C_P2 * p.Tc + (t - 1), (unsigned)p.n_p2, p.abort_word, p.spin_limit, &sm.flag)) return;
       if (t) {
         pd_product<true>(acc, p.rnn_p, zi, bz, E, wave, fbz);
         pd_product<true>(acc, hprev, arow * ldh + 4 * lh, bh, Hp, wave, fbh);
@@ -496,7 +498,7 @@ __device__ void role_p2(const PdParams& p, int slice, PdSmem& sm) {
   const float b_mu = p.b_ml[e], b_lv = p.b_ml[E + e];
   for (int t = 0; t < p.Tc; ++t) {
     const float eps = mine ? p.eps_p[(long)t * p.N * E + (long)mm * E + e] : 0.f;
-    if (!pd_wait(p.cnt + PD_C_P1 * p.Tc + t, (unsigned)p.n_p1, p.abort_word, &sm.flag)) return;
+    if (!pd_wait(p.cnt + PD_C_P1 * p.Tc + t, (unsigned)p.n_p1, p.abort_word, p.spin_limit, &sm.flag)) return;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -712,7 +714,7 @@ __device__ void role_ra(const PbParams& p, int slice, PbSmem& sm) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     if (t < p.Tc - 1) {
-      if (!pd_wait(p.cnt + PB_C_RA * p.Tc + (t + 1), (unsigned)p.n_ra, p.abort_word, &sm.flag)) return;
+      if (!pd_wait(p.cnt + PB_C_RA * p.Tc + (t + 1), (unsigned)p.n_ra, p.abort_word, p.spin_limit, &sm.flag)) return;
       pb_gemm(acc, p.dgh, (long)arow * p.Tc * 3 * H + (long)(t + 1) * 3 * H + 4 * lh, b_hh, 3 * H, wave);
     }
     // this step's cell inputs do not depend on the launch (fetched here, behind the long product: its two batches of
@@ -730,7 +732,7 @@ __device__ void role_ra(const PbParams& p, int slice, PbSmem& sm) {
       }
     }
     if (t < p.Tc - 1) {
-      if (!pd_wait(p.cnt + PB_C_RC * p.Tc + (t + 1), (unsigned)p.N, p.abort_word, &sm.flag)) return;
+      if (!pd_wait(p.cnt + PB_C_RC * p.Tc + (t + 1), (unsigned)p.N, p.abort_word, p.spin_limit, &sm.flag)) return;
       pb_gemm1(acc, p.dqd, (long)arow * p.Tc * A + (long)(t + 1) * A + 4 * lh, b_att, A, wave);   // A <= 512 (decode_persist_bwd_ok)
       pb_stash(sm.red, acc, wave, li, lh);
       __syncthreads();
@@ -772,7 +774,7 @@ __device__ void role_rb(const PbParams& p, int slice, PbSmem& sm) {
   const int mm0 = threadIdx.x >> 5, j = threadIdx.x & 31;
   float* part = p.dctx_part + (long)ks * p.N * E;
   for (int t = p.Tc - 1; t >= 0; --t) {
-    if (!pd_wait(p.cnt + PB_C_RA * p.Tc + t, (unsigned)p.n_ra, p.abort_word, &sm.flag)) return;
+    if (!pd_wait(p.cnt + PB_C_RA * p.Tc + t, (unsigned)p.n_ra, p.abort_word, p.spin_limit, &sm.flag)) return;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -822,7 +824,7 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
   for (int t = p.Tc - 1; t >= 0; --t) {
     const float qa = a < A ? p.qd[(long)n * p.Tc * A + (long)t * A + a] : 0.f;
     if (threadIdx.x < S) w_s[threadIdx.x] = p.attn_w[(long)n * p.Tc * S + (long)t * S + threadIdx.x];
-    if (!pd_wait(p.cnt + PB_C_RB * p.Tc + t, (unsigned)p.n_rb, p.abort_word, s_flag)) return;
+    if (!pd_wait(p.cnt + PB_C_RB * p.Tc + t, (unsigned)p.n_rb, p.abort_word, p.spin_limit, s_flag)) return;
     {   // the step's context gradient: the K-split partials of RB in split order; kept per step for attn_dmem_kernel
       float dc = 0.f;
       if (a < E) {
@@ -913,7 +915,7 @@ __device__ void role_pa(const PbParams& p, int slice, PbSmem& sm) {
     }
     float vhp = 0.f, vlz = 0.f;
     if (t < p.Tc - 1) {
-      if (!pd_wait(p.cnt + PB_C_PB * p.Tc + (t + 1), (unsigned)p.n_pb, p.abort_word, &sm.flag)) return;
+      if (!pd_wait(p.cnt + PB_C_PB * p.Tc + (t + 1), (unsigned)p.n_pb, p.abort_word, p.spin_limit, &sm.flag)) return;
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -955,7 +957,7 @@ __device__ void role_pb(const PbParams& p, int slice, PbSmem& sm) {
         c[i] = t ? p.c_all[(long)mm * p.Tc * Hp + (long)(t - 1) * Hp + u] : 0.f;
       }
     }
-    if (!pd_wait(p.cnt + PB_C_PA * p.Tc + t, (unsigned)p.n_pa, p.abort_word, &sm.flag)) return;
+    if (!pd_wait(p.cnt + PB_C_PA * p.Tc + t, (unsigned)p.n_pa, p.abort_word, p.spin_limit, &sm.flag)) return;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(PD_THREADS) void posterior_persist_fwd_kernel(PqPar
   float* hb = p.hbuf + (long)dir * 2 * p.N * Hq;
   for (int k = 0; k < p.Tc; ++k) {
     const int t = dir ? p.Tc - 1 - k : k;
-    if (k > 0 && !pd_wait(cnt + (k - 1), (unsigned)nwg, p.abort_word, &sm.flag)) return;
+    if (k > 0 && !pd_wait(cnt + (k - 1), (unsigned)nwg, p.abort_word, p.spin_limit, &sm.flag)) return;
     const float* hin = hb + (long)((k + 1) & 1) * p.N * Hq;      // step 0: parity 1 = the zeros the caller put there
     float4 a[PD_U];
     pd_load_a<true>(a, hin, (long)arow * Hq + 4 * lh, Hq, wave);
@@ -1139,7 +1141,7 @@ __global__ __launch_bounds__(PD_THREADS) void posterior_persist_bwd_kernel(PqbPa
     const int t = dir ? k : p.Tc - 1 - k;
     float prod[2] = {0.f, 0.f};
     if (k > 0) {
-      if (!pd_wait(cnt + (k - 1), (unsigned)nwg, p.abort_word, &sm.flag)) return;
+      if (!pd_wait(cnt + (k - 1), (unsigned)nwg, p.abort_word, p.spin_limit, &sm.flag)) return;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1184,117 +1186,245 @@ __global__ __launch_bounds__(PD_THREADS) void posterior_persist_bwd_kernel(PqbPa
 }
 }  // namespace
 
+// =====================================================================================================================
+// Launchers.  A persistent launch only makes progress while ALL of its workgroups are resident (every role spins on what
+// another role produces), so a launcher
+//   (1) asks the occupancy calculator whether the whole grid fits the device with the launch's LDS and registers, and
+//       reports "does not fit" to its caller BEFORE anything is queued (the per-step path of decoder.hip runs instead);
+//   (2) chains the device's persistent launches behind each other (one event per device, recorded after every such launch
+//       and waited for by the next one, whatever stream or host thread it comes from): two spin-wait grids of one process
+//       never share the chip;
+//   (3) queues a one-workgroup tail kernel behind the launch that reads the launch's abort word - set when a bounded wait ran
+//       out all the same (another PROCESS holds the CUs, a CU mask the occupancy query does not see) - and, if it is set,
+//       overwrites the launch's outputs with NaN and raises the device's status word (acvae_persist_status_register):
+//       an aborted launch can neither be trained on nor go unnoticed.
+// The slot below (event, status pointer, CU count) is the library's per-device mutable state, listed in acvae_hip.h.
+// =====================================================================================================================
+namespace {
+constexpr int PERSIST_MAX_DEV = 64;
+enum { PK_DECODE_FWD, PK_DECODE_BWD, PK_POST_FWD, PK_POST_BWD, PK_COUNT };
+struct PersistSlot {
+  std::mutex mu;
+  hipEvent_t done = nullptr;                      // completion of the device's latest persistent launch
+  std::atomic<unsigned*> status{nullptr};         // registered status words (device-visible), or null
+  std::atomic<int> cus{0};
+  std::atomic<bool> raised[PK_COUNT];             // dynamic-LDS attribute of kernel k raised on this device
+};
+PersistSlot g_slot[PERSIST_MAX_DEV];
+
+struct PoisonList { float* p[8]; long n[8]; int count; };
+inline void poison_add(PoisonList& l, float* p, long n) {
+  if (p && n > 0 && l.count < 8) { l.p[l.count] = p; l.n[l.count] = n; ++l.count; }
+}
+__global__ void persist_tail_kernel(const unsigned* abort_word, unsigned* status, int kind, PoisonList list) {
+  if (__hip_atomic_load(abort_word, PD_RLX_AGENT) == 0u) return;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  for (int k = 0; k < list.count; ++k)
+    for (long i = threadIdx.x; i < list.n[k]; i += blockDim.x) list.p[k][i] = qnan;
+  if (status && threadIdx.x == 0) {
+    __hip_atomic_store(status + kind, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(status + PK_COUNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+int persist_device(int& dev) {
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  return (dev < 0 || dev >= PERSIST_MAX_DEV) ? ACVAE_EUNSUPPORTED : ACVAE_OK;
+}
+// does a grid of `grid` workgroups of 512 threads with `shm` bytes of dynamic LDS fit the current device all at once?
+template <class K>
+bool persist_fits(K kernel, int kid, int grid, size_t shm) {
+  int dev = 0;
+  if (persist_device(dev) != ACVAE_OK) return false;
+  PersistSlot& sl = g_slot[dev];
+  if (shm > 64 * 1024 && !sl.raised[kid].load()) {       // more than 64 KB of dynamic LDS needs the attribute, once per device
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    sl.raised[kid].store(true);
+  }
+  int cus = sl.cus.load();
+  if (cus == 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      (void)hipGetLastError();
+      return false;
+    }
+    sl.cus.store(cus);
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PD_THREADS, shm) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return (long)per_cu * cus >= grid;
+}
+// memset of the counters, the launch and its tail, chained behind the device's previous persistent launch
+template <class K, class P>
+int persist_launch(K kernel, int kid, const P& p, int grid, size_t shm, long counter_words, const PoisonList& poison, hipStream_t st) {
+  int dev = 0;
+  ACVAE_TRY(persist_device(dev));
+  PersistSlot& sl = g_slot[dev];
+  std::lock_guard<std::mutex> lock(sl.mu);
+  if (!sl.done) {
+    if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  } else if (hipStreamWaitEvent(st, sl.done, 0) != hipSuccess) {
+    return (int)hipGetLastError();
+  }
+  if (hipMemsetAsync(p.cnt, 0, (size_t)counter_words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(PD_THREADS), shm, st, p);
+  hipLaunchKernelGGL(persist_tail_kernel, dim3(1), dim3(1024), 0, st, p.abort_word, sl.status.load(), kid, poison);
+  ACVAE_LAUNCH_CHECK();
+  if (hipEventRecord(sl.done, st) != hipSuccess) return (int)hipGetLastError();
+  return ACVAE_OK;
+}
+// ACVAE_FLAG_TEST_STALL: one workgroup short and a short spin limit - the roles that wait for the missing workgroup run into
+// their bound, exactly as when part of a grid is not resident (tests/test_decode_persist_gpu.py)
+inline void persist_test_stall(int flags, int& grid, unsigned& spin_limit) {
+  spin_limit = PD_SPIN_LIMIT;
+  if (flags & ACVAE_FLAG_TEST_STALL) { grid -= 1; spin_limit = 1u << 12; }
+}
+}  // namespace
+
+extern "C" int acvae_persist_status_register(int device, void* status_words_host) {
+  if (device < 0 || device >= PERSIST_MAX_DEV) return ACVAE_EINVAL;
+  unsigned* dptr = nullptr;
+  if (status_words_host) {
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, status_words_host, 0) != hipSuccess) { (void)hipGetLastError(); return ACVAE_EINVAL; }
+    dptr = static_cast<unsigned*>(d);
+  }
+  g_slot[device].status.store(dptr);
+  return ACVAE_OK;
+}
+
 namespace acvae {
 
-static int g_persist = -1;      // -1: not decided yet (environment), 0 / 1: set
-bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A) {
-  if (g_persist < 0) g_persist = (getenv("ACVAE_DECODE_PERSIST") && atoi(getenv("ACVAE_DECODE_PERSIST")) == 0) ? 0 : 1;
+// ---- decode forward
+static void decode_fwd_geometry(int N, int S, int E, int H, int A, bool resident, int& grid, size_t& shm, int& att_resident) {
+  grid = (A / 32 + 3 * H / 32) + N + H / 16 + E / 8 + E / 16;
+  shm = sizeof(PdSmem);
+  size_t att = (size_t)(4 + ((S + 16 + 3) & ~3) + 4096) * sizeof(float);      // context partials: (1024 / (E/4)) x E
+  // the clip's projected memory in LDS and its memory rows in registers (8 frames for each of a thread's 2 context groups)
+  const int GV = 1024 / (E / 4);
+  att_resident = (resident && S <= 8 * GV && att + (size_t)S * A * sizeof(float) <= 150 * 1024) ? 1 : 0;
+  if (att_resident) att += (size_t)S * A * sizeof(float);
+  if (att > shm) shm = att;
+}
+static bool decode_fwd_shape_ok(int N, int Tc, int S, int E, int H, int A) {
   // one 32-row tile of clips; whole 32 / 16 / 8-wide slices and K-groups of 8; one score per thread in the softmax; E a
   // power of two so that the context groups of the per-step attention kernel (1024 / (E / 4)) can be replayed exactly
-  return g_persist == 1 && N >= 1 && N <= 32 && Tc >= 1 && S >= 1 && S <= PD_THREADS && E >= 32 && E <= 2048 &&
-         (E & (E - 1)) == 0 && H % 32 == 0 && A % 32 == 0;
+  return N >= 1 && N <= 32 && Tc >= 1 && S >= 1 && S <= PD_THREADS && E >= 32 && E <= 2048 && (E & (E - 1)) == 0 &&
+         H % 32 == 0 && A % 32 == 0;
+}
+// picks the attention form (memory resident on the CU or streamed) whose grid fits the device; false: neither does
+static bool decode_fwd_plan(int N, int Tc, int S, int E, int H, int A, int& grid, size_t& shm, int& att_resident) {
+  if (!decode_fwd_shape_ok(N, Tc, S, E, H, A)) return false;
+  for (int resident = 1; resident >= 0; --resident) {
+    decode_fwd_geometry(N, S, E, H, A, resident != 0, grid, shm, att_resident);
+    if (resident && !att_resident) continue;
+    if (persist_fits(decode_persist_kernel, PK_DECODE_FWD, grid, shm)) return true;
+  }
+  return false;
+}
+bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A) {
+  int grid, res; size_t shm;
+  return decode_fwd_plan(N, Tc, S, E, H, A, grid, shm, res);
 }
 long decode_persist_counter_words(int Tc) { return ((long)PD_C_COUNT * Tc + 1 + 3) & ~3L; }
 
-int decode_persist_fwd(PdParams p, hipStream_t st) {
-  if (!decode_persist_ok(p.N, p.Tc, p.S, p.E, p.H, p.A)) return ACVAE_EUNSUPPORTED;
+int decode_persist_fwd(PdParams p, hipStream_t st, int flags) {
+  int grid; size_t shm;
+  if (!decode_fwd_plan(p.N, p.Tc, p.S, p.E, p.H, p.A, grid, shm, p.att_resident)) return ACVAE_EUNSUPPORTED;
   p.n_d1 = p.A / 32 + 3 * p.H / 32;
   p.n_d3 = p.H / 16;
   p.n_p1 = p.E / 8;
   p.n_p2 = p.E / 16;
   const long words = decode_persist_counter_words(p.Tc);
   p.abort_word = p.cnt + (long)PD_C_COUNT * p.Tc;
-  if (hipMemsetAsync(p.cnt, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
-  const int grid = p.n_d1 + p.N + p.n_d3 + p.n_p1 + p.n_p2;
-  size_t shm = sizeof(PdSmem);
-  size_t att = (size_t)(4 + ((p.S + 16 + 3) & ~3) + 4096) * sizeof(float);      // context partials: (1024 / (E/4)) x E
-  // the clip's projected memory in LDS and its memory rows in registers (8 frames for each of a thread's 2 context groups)
-  const int GV = 1024 / (p.E / 4);
-  p.att_resident = (p.S <= 8 * GV && att + (size_t)p.S * p.A * sizeof(float) <= 150 * 1024) ? 1 : 0;
-  if (p.att_resident) att += (size_t)p.S * p.A * sizeof(float);
-  if (att > shm) shm = att;
-  if (shm > 64 * 1024) {
-    static bool raised = false;               // more than 64 KB of dynamic LDS needs the attribute, once per process
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024) != hipSuccess)
-        return (int)hipGetLastError();
-      raised = true;
-    }
-  }
-  hipLaunchKernelGGL(decode_persist_kernel, dim3(grid), dim3(PD_THREADS), shm, st, p);
-  ACVAE_LAUNCH_CHECK();
-  return ACVAE_OK;
+  persist_test_stall(flags, grid, p.spin_limit);
+  const long R = (long)p.N * p.Tc;
+  PoisonList poison{};
+  poison_add(poison, p.outputs, R * p.H); poison_add(poison, p.p_means, R * p.E); poison_add(poison, p.p_logs, R * p.E);
+  poison_add(poison, p.p_z, R * p.E); poison_add(poison, p.attn_w, R * p.S);
+  return persist_launch(decode_persist_kernel, PK_DECODE_FWD, p, grid, shm, words, poison, st);
 }
 
-}  // namespace acvae
-
-namespace acvae {
+// ---- decode backward
+static size_t decode_bwd_shm(int S, int A) {
+  size_t shm = sizeof(PbSmem);
+  const size_t att = (size_t)(4 + 128 + 512 + 512 + (long)S * A) * sizeof(float);
+  return att > shm ? att : shm;
+}
+static void decode_bwd_splits(int E, int H, int& ks_rb, int& ks_pa) {
+  // K-splits: one resident batch (K <= 512) per workgroup where the K of the product divides that way, at most 4
+  ks_rb = (3 * H) % 512 == 0 && 3 * H / 512 <= 4 ? 3 * H / 512 : 1;
+  ks_pa = E == 512 ? 2 : 1;               // K = 4Hp = 2048 = 2 x 1024 and 2E = 1024: the shapes the split products are written for
+}
 bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A) {
   // the attention role keeps a clip's frames in 2 x 32 register slots and its channels in 512 thread columns
-  return decode_persist_ok(N, Tc, S, E, H, A) && S <= 64 && E <= 512 && A <= 512 && H % 32 == 0 && H == E &&
-         (size_t)(4 + 128 + 512 + 512 + (long)S * A) * sizeof(float) <= 150 * 1024;
+  if (!(decode_fwd_shape_ok(N, Tc, S, E, H, A) && S <= 64 && E <= 512 && A <= 512 && H % 32 == 0 && H == E &&
+        (size_t)(4 + 128 + 512 + 512 + (long)S * A) * sizeof(float) <= 150 * 1024))
+    return false;
+  int ks_rb, ks_pa;
+  decode_bwd_splits(E, H, ks_rb, ks_pa);
+  const int grid = H / 32 + (E / 32) * ks_rb + N + (E / 16) * ks_pa + E / 32;
+  return persist_fits(decode_persist_bwd_kernel, PK_DECODE_BWD, grid, decode_bwd_shm(S, A));
 }
 long decode_persist_bwd_counter_words(int Tc) { return ((long)PB_C_COUNT * Tc + 1 + 3) & ~3L; }
 long decode_persist_bwd_part_floats(int N, int E, int H) { return 4L * N * E + 4L * N * E + 4L * N * 2 * E; }
 
-int decode_persist_bwd(PbParams p, hipStream_t st) {
+int decode_persist_bwd(PbParams p, hipStream_t st, int flags) {
   if (!decode_persist_bwd_ok(p.N, p.Tc, p.S, p.E, p.H, p.A)) return ACVAE_EUNSUPPORTED;
-  // K-splits: one resident batch (K <= 512) per workgroup where the K of the product divides that way, at most 4
-  p.ks_rb = (3 * p.H) % 512 == 0 && 3 * p.H / 512 <= 4 ? 3 * p.H / 512 : 1;
-  p.ks_pa = p.E == 512 ? 2 : 1;           // K = 4Hp = 2048 = 2 x 1024 and 2E = 1024: the shapes the split products are written for
+  decode_bwd_splits(p.E, p.H, p.ks_rb, p.ks_pa);
   p.n_ra = p.H / 32; p.n_rb = (p.E / 32) * p.ks_rb; p.n_pa = (p.E / 16) * p.ks_pa; p.n_pb = p.E / 32;
   const long words = decode_persist_bwd_counter_words(p.Tc);
   p.abort_word = p.cnt + (long)PB_C_COUNT * p.Tc;
-  if (hipMemsetAsync(p.cnt, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
-  const int grid = p.n_ra + p.n_rb + p.N + p.n_pa + p.n_pb;
-  size_t shm = sizeof(PbSmem);
-  const size_t att = (size_t)(4 + 128 + 512 + 512 + (long)p.S * p.A) * sizeof(float);
-  if (att > shm) shm = att;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_persist_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return (int)hipGetLastError();
-    raised = true;
-  }
-  hipLaunchKernelGGL(decode_persist_bwd_kernel, dim3(grid), dim3(PB_THREADS), shm, st, p);
+  int grid = p.n_ra + p.n_rb + p.N + p.n_pa + p.n_pb;
+  persist_test_stall(flags, grid, p.spin_limit);
+  const long R = (long)p.N * p.Tc;
+  PoisonList poison{};
+  poison_add(poison, p.dgi, R * 3 * p.H); poison_add(poison, p.dgh, R * 3 * p.H); poison_add(poison, p.dgates, R * 4 * p.E);
+  poison_add(poison, p.dml_all, R * 2 * p.E); poison_add(poison, p.dctx, R * p.E); poison_add(poison, p.dqd, R * p.A);
+  poison_add(poison, p.dencproj, (long)p.N * p.S * p.A);
+  ACVAE_TRY(persist_launch(decode_persist_bwd_kernel, PK_DECODE_BWD, p, grid, decode_bwd_shm(p.S, p.A), words, poison, st));
+  // (dctx poisoned = NaN in dmem: attn_dmem_kernel forms it from dctx behind the tail)
   hipLaunchKernelGGL(attn_dmem_kernel, dim3(p.N * p.S), dim3(256), 0, st, p.attn_w, p.dctx, p.dmem, p.Tc, p.S, p.E);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
-}  // namespace acvae
 
-namespace acvae {
+// ---- posterior
 bool posterior_persist_ok(int N, int Tc, int Hq) {
-  if (g_persist < 0) g_persist = (getenv("ACVAE_DECODE_PERSIST") && atoi(getenv("ACVAE_DECODE_PERSIST")) == 0) ? 0 : 1;
   // one 32-row tile of clips; 32 hidden units per workgroup; a wavefront's share of K = Hq is one resident batch
-  return g_persist == 1 && N >= 1 && N <= 32 && Tc >= 1 && Hq >= 32 && Hq <= 64 * PD_U && Hq % 32 == 0;
+  if (!(N >= 1 && N <= 32 && Tc >= 1 && Hq >= 32 && Hq <= 64 * PD_U && Hq % 32 == 0)) return false;
+  return persist_fits(posterior_persist_fwd_kernel, PK_POST_FWD, 2 * (Hq / 32), sizeof(PqSmem)) &&
+         persist_fits(posterior_persist_bwd_kernel, PK_POST_BWD, 2 * (Hq / 32), sizeof(PqSmem));
 }
 long posterior_persist_counter_words(int Tc) { return (2L * Tc + 1 + 3) & ~3L; }
 
-int posterior_persist_fwd(PqParams p, hipStream_t st) {
+int posterior_persist_fwd(PqParams p, hipStream_t st, int flags) {
   if (!posterior_persist_ok(p.N, p.Tc, p.Hq)) return ACVAE_EUNSUPPORTED;
   p.abort_word = p.cnt + 2L * p.Tc;
-  if (hipMemsetAsync(p.cnt, 0, (size_t)posterior_persist_counter_words(p.Tc) * sizeof(unsigned), st) != hipSuccess)
-    return (int)hipGetLastError();
-  hipLaunchKernelGGL(posterior_persist_fwd_kernel, dim3(2 * (p.Hq / 32)), dim3(PD_THREADS), sizeof(PqSmem), st, p);
-  ACVAE_LAUNCH_CHECK();
-  return ACVAE_OK;
+  int grid = 2 * (p.Hq / 32);
+  persist_test_stall(flags, grid, p.spin_limit);
+  PoisonList poison{};
+  poison_add(poison, p.hid, (long)p.N * p.Tc * 2 * p.Hq);
+  return persist_launch(posterior_persist_fwd_kernel, PK_POST_FWD, p, grid, sizeof(PqSmem), posterior_persist_counter_words(p.Tc),
+                        poison, st);
 }
-int posterior_persist_bwd(PqbParams p, hipStream_t st) {
+int posterior_persist_bwd(PqbParams p, hipStream_t st, int flags) {
   if (!posterior_persist_ok(p.N, p.Tc, p.Hq)) return ACVAE_EUNSUPPORTED;
   p.abort_word = p.cnt + 2L * p.Tc;
-  if (hipMemsetAsync(p.cnt, 0, (size_t)posterior_persist_counter_words(p.Tc) * sizeof(unsigned), st) != hipSuccess)
-    return (int)hipGetLastError();
-  hipLaunchKernelGGL(posterior_persist_bwd_kernel, dim3(2 * (p.Hq / 32)), dim3(PD_THREADS), sizeof(PqSmem), st, p);
-  ACVAE_LAUNCH_CHECK();
-  return ACVAE_OK;
+  int grid = 2 * (p.Hq / 32);
+  persist_test_stall(flags, grid, p.spin_limit);
+  PoisonList poison{};
+  for (int dir = 0; dir < 2; ++dir) {
+    poison_add(poison, p.dgi[dir], (long)p.N * p.Tc * 3 * p.Hq);
+    poison_add(poison, p.dgh[dir], (long)p.N * p.Tc * 3 * p.Hq);
+  }
+  return persist_launch(posterior_persist_bwd_kernel, PK_POST_BWD, p, grid, sizeof(PqSmem), posterior_persist_counter_words(p.Tc),
+                        poison, st);
 }
 }  // namespace acvae
-
-extern "C" int acvae_set_decode_persist(int on) {
-  const int before = acvae::g_persist;
-  acvae::g_persist = on ? 1 : 0;
-  return before;
-}

@@ -17,7 +17,6 @@
 #include "conv.h"
 #include "rnn.h"
 #include "decode_persist.h"
-#include <atomic>
 #include "../../include/acvae_hip.h"
 
 namespace {
@@ -148,7 +147,7 @@ struct DecLayout {
   long words, mem, encproj_d, encproj_p, qd, qp, attw_p, rnn_d, rnn_p, gru_save, hprev_d, lstm_save, c_all, hp_all,
       hpprev, lse, pool_arg, pool_hid, unfinished, saved_total;
   // fwd scratch
-  long skws, skws_p, gi_d, gh_d, gates_p, ml, h0, pd_cnt, scratch_fwd;
+  long skws, skws_p, gi_d, gh_d, gates_p, ml, h0, pd_cnt, attfws_d, attfws_p, attfws_bytes, scratch_fwd;
   // bwd scratch
   long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a, pd_part,
@@ -179,6 +178,10 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   L.gi_d = f.take(R * 3 * H); L.gh_d = f.take((long)N * 3 * H); L.gates_p = f.take(R * 4 * Hp);
   L.ml = f.take((long)N * 2 * E); L.h0 = f.take((long)N * (H > Hp ? H : Hp));
   L.pd_cnt = f.take(acvae::decode_persist_counter_words(Tc));      // arrival counters of the persistent decode loop
+  // per-step path: workspaces of the split-over-frames attention, one per chain (the chains may run on two streams)
+  L.attfws_bytes = acvae_attn_fwd_workspace_bytes(N, 1, S, A, E);
+  { const long w2 = acvae_attn_fwd_workspace_bytes(N, 1, S, E, E); if (w2 > L.attfws_bytes) L.attfws_bytes = w2; }
+  L.attfws_d = f.take(L.attfws_bytes / 4 + 64); L.attfws_p = f.take(L.attfws_bytes / 4 + 64);
   L.scratch_fwd = f.off;
   Bump b;
   b.take(acvae_skinny_ws_floats());            // skinny split-K workspaces first (L.skws, L.skws_p)
@@ -242,7 +245,7 @@ extern "C" int64_t acvae_posterior_scratch_bytes(int N, int Tc, int E, int Hq, i
 extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* caps, int64_t ld_caps, const int64_t* lens1,
                                    const float* eps_q, float* q_means, float* q_logs, float* q_z, float* q_means_utt,
                                    void* saved_v, int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N,
-                                   int Tc, int E, int Hq, int V, void* stream) {
+                                   int Tc, int E, int Hq, int V, void* stream, int flags) {
   PostLayout L;
   ACVAE_TRY(post_layout(N, Tc, E, Hq, V, L));
   if (!params || !caps || !lens1 || !eps_q || !q_means || !q_logs || !q_z || !q_means_utt || !saved_v || !scratch_v)
@@ -259,7 +262,7 @@ extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* cap
   float* hid = sv + L.hidden;
   ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));            // x[:, :-1] restricted to Tc steps
   ACVAE_TRY(acvae::embed_gather(words, 1, P(TP_Q_EMB), V, X, E, R, E, st));
-  if (acvae::posterior_persist_ok(N, Tc, Hq)) {
+  if (!(flags & ACVAE_FLAG_NO_PERSIST) && acvae::posterior_persist_ok(N, Tc, Hq)) {
     // both directions, all steps: one launch (decode_persist.hip); the hoisted input projections first
     PqParams pq;
     for (int dir = 0; dir < 2; ++dir) {
@@ -273,7 +276,7 @@ extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* cap
     pq.lens1 = lens1; pq.hid = hid; pq.hbuf = sc + L.pq_hbuf; pq.cnt = (unsigned*)(sc + L.pq_cnt);
     pq.N = N; pq.Tc = Tc; pq.Hq = Hq;
     ACVAE_TRY(zero(pq.hbuf, (long)4 * N * Hq, st));
-    ACVAE_TRY(acvae::posterior_persist_fwd(pq, st.s));
+    ACVAE_TRY(acvae::posterior_persist_fwd(pq, st.s, flags));
   } else
   for (int dir = 0; dir < 2; ++dir) {
     const int o = dir * 4;
@@ -303,7 +306,7 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
                                    const float* eps_q, const float* q_logs, const float* d_q_means,
                                    const float* d_q_logs, const float* d_q_z, const float* d_q_means_utt, void* saved_v,
                                    int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int E,
-                                   int Hq, int V, void* stream) {
+                                   int Hq, int V, void* stream, int flags) {
   PostLayout L;
   ACVAE_TRY(post_layout(N, Tc, E, Hq, V, L));
   if (!params || !grads || !lens1 || !eps_q || !q_logs || !saved_v || !scratch_v) return ACVAE_EINVAL;
@@ -332,7 +335,7 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   ACVAE_TRY(gemm_tn(dml, 2 * E, hid, 2 * Hq, G(TP_Q_TML_W), 2 * Hq, 2 * E, 2 * Hq, R, tn, st));
   ACVAE_TRY(acvae::colsum2(dml, R, 2 * E, dpart, G(TP_Q_TML_B), nullptr, 0, st));
   float* dx = sc + L.dx;
-  const bool persist = acvae::posterior_persist_ok(N, Tc, Hq);
+  const bool persist = !(flags & ACVAE_FLAG_NO_PERSIST) && acvae::posterior_persist_ok(N, Tc, Hq);
   if (persist) {                 // BPTT of both directions in one launch; the parameter products below are unchanged
     PqbParams pb;
     for (int dir = 0; dir < 2; ++dir) {
@@ -346,7 +349,7 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
     }
     pb.dhid = dhid; pb.lens1 = lens1; pb.cnt = (unsigned*)(sc + L.pq_cnt);
     pb.N = N; pb.Tc = Tc; pb.Hq = Hq;
-    ACVAE_TRY(acvae::posterior_persist_bwd(pb, st.s));
+    ACVAE_TRY(acvae::posterior_persist_bwd(pb, st.s, flags));
   }
   for (int dir = 0; dir < 2; ++dir) {
     const int o = dir * 4;
@@ -401,12 +404,12 @@ extern "C" int acvae_decode_fwd(const void* const* params, const float* mem_in, 
                                 float* p_logs, float* p_z, float* p_means_utt, float* h_final, float* hp_final,
                                 float* cp_final, void* saved_v, int64_t saved_bytes, void* scratch_v,
                                 int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc,
-                                int start_idx, int end_idx, void* stream, void* aux_stream) {
+                                int start_idx, int end_idx, void* stream, void* aux_stream, int flags) {
   return acvae_decode_fwd_sampled(params, mem_in, mem_lens, caps, ld_caps, lens1, q_z, eps_p, ss_flags_host,
                                   dis_flags_host, logits, outputs, seqs, sampled_logprobs, attn_w, p_means, p_logs, p_z,
                                   p_means_utt, h_final, hp_final, cp_final, saved_v, saved_bytes, scratch_v,
                                   scratch_bytes, N, Tc, S, E, H, A, V, Eenc, start_idx, end_idx, stream, aux_stream,
-                                  ACVAE_SAMPLE_GREEDY, 1.f, nullptr, nullptr, 0.f);
+                                  ACVAE_SAMPLE_GREEDY, 1.f, nullptr, nullptr, 0.f, flags);
 }
 
 extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, const int64_t* mem_lens,
@@ -418,7 +421,7 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
                                         int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S,
                                         int E, int H, int A, int V, int Eenc, int start_idx, int end_idx, void* stream,
                                         void* aux_stream, int sample_method, float temp, const float* sample_noise,
-                                        const uint8_t* emb_keep, float emb_drop_p) {
+                                        const uint8_t* emb_keep, float emb_drop_p, int flags) {
   if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p <= 1.f)) return ACVAE_EINVAL;   // p = 1: nn.Dropout zeroes everything
   if (sample_method != ACVAE_SAMPLE_GREEDY &&
       ((sample_method != ACVAE_SAMPLE_GUMBEL && sample_method != ACVAE_SAMPLE_MULTINOMIAL) || !sample_noise ||
@@ -450,6 +453,15 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
   Ctx sp{fork.aux, sc + L.skws_p};
   ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
   ACVAE_TRY(acvae_skinny_ws_reset(sp.skws, st.s));
+  // the step-by-step paths may use the split-over-frames attention: its arrival counters start at zero (ordered in front of
+  // the fork); the persistent launch has its own attention
+  const bool persist_fwd = teacher && !prior_feeds_decoder && !(flags & ACVAE_FLAG_NO_PERSIST) && H == E &&
+                           acvae::decode_persist_ok(N, Tc, S, E, H, A);
+  const bool attws_ready = !persist_fwd && L.attfws_bytes > 0;
+  if (attws_ready) {
+    ACVAE_TRY(zero(sc + L.attfws_d, 256, st.s));
+    ACVAE_TRY(zero(sc + L.attfws_p, 256, st.s));
+  }
 
   int64_t* words = (int64_t*)(sv + L.words);
   float* mem = sv + L.mem;
@@ -491,7 +503,7 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
                    ldof(cnt, E), M, E, E, 0, sp));
     ACVAE_TRY(acvae_attn_fwd(qp + (long)t0 * E, (long)Tc * E, E, encproj_p, mem, mem_lens, P(TP_P_ATT_V),
                              rnn_p + (long)t0 * 3 * E + E, ld3E, 3 * E, attw_p + (long)t0 * S, (long)Tc * S, S, N, cnt, S,
-                             E, E, sp));
+                             E, E, (cnt == 1 && attws_ready) ? sc + L.attfws_p : nullptr, L.attfws_bytes, sp, flags));
     // LSTM input projection of [emb; ctx] (+ both biases); the last_z / h parts are added per step
     ACVAE_TRY(gemm(rnn_p + (long)t0 * 3 * E, ldof(cnt, 3 * E), P(TP_P_WIH), 3 * E, P(TP_P_BIH),
                    gates_p + (long)t0 * 4 * Hp, ldof(cnt, 4 * Hp), M, 4 * Hp, 2 * E, 0, sp));
@@ -558,7 +570,7 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
     }
     ACVAE_TRY(acvae_attn_fwd(qd + (long)t * A, (long)Tc * A, A, encproj_d, mem, mem_lens, P(TP_DEC_ATT_V),
                              rnn_d + (long)t * 3 * E + E, ld3E, 3 * E, attn_w + (long)t * S, (long)Tc * S, S, N, 1, S, A,
-                             E, st));
+                             E, attws_ready ? sc + L.attfws_d : nullptr, L.attfws_bytes, st, flags));
     ACVAE_TRY(gemm(rnn_d + (long)t * 3 * E + E, ld3E, P(TP_DEC_WIH) + E, 3 * E, nullptr, gi_d + (long)t * 3 * H,
                    (long)Tc * 3 * H, N, 3 * H, E, 1, st));
     ACVAE_TRY(acvae::gru_fwd(gi_d + (long)t * 3 * H, (long)Tc * 3 * H, gh_d, 3 * H, hprev, ldh, outputs + (long)t * H,
@@ -589,7 +601,7 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
       ACVAE_TRY(fork.join());
       ACVAE_TRY(dec_pre(0, Tc));
       for (int t = 0; t < Tc; ++t) ACVAE_TRY(dec_step(t));
-    } else if (acvae::decode_persist_ok(N, Tc, S, E, H, A) && H == E) {
+    } else if (persist_fwd) {
       // independent chains, all words known: the Tc steps of both chains as ONE persistent launch (decode_persist.hip);
       // the hoisted halves are computed as before (the prior's on the second stream), then the streams join
       ACVAE_TRY(dec_pre(0, Tc));
@@ -606,7 +618,7 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
       pd.lstm_save = sv + L.lstm_save; pd.p_means = p_means; pd.p_logs = p_logs; pd.p_z = p_z;
       pd.cnt = (unsigned*)(sc + L.pd_cnt);
       pd.N = N; pd.Tc = Tc; pd.S = S; pd.E = E; pd.H = H; pd.A = A;
-      ACVAE_TRY(acvae::decode_persist_fwd(pd, st.s));
+      ACVAE_TRY(acvae::decode_persist_fwd(pd, st.s, flags));
     } else {                              // independent chains: feed both queues step by step
       ACVAE_TRY(dec_pre(0, Tc));
       for (int t = 0; t < Tc; ++t) {
@@ -641,19 +653,12 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
   return ACVAE_OK;
 }
 
-// -1: not set (the environment decides: ACVAE_DECODE_DEFER=1 switches it on); 0 / 1: set by acvae_set_decode_defer
-static std::atomic<int> g_decode_defer{-1};
-extern "C" int acvae_set_decode_defer(int on) { return g_decode_defer.exchange(on != 0 ? 1 : 0); }
-
-extern "C" int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream) {
-  // Library default: off (everything ordered on `stream` on return - the contract a plain C caller expects) unless
-  // ACVAE_DECODE_DEFER=1 or acvae_set_decode_defer(1): Hybrid_VAEModel, which joins the second stream itself, switches it on.
+extern "C" int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream, int flags) {
+  // Default: everything ordered on `stream` on return - the contract a plain C caller expects.  ACVAE_FLAG_DEFER_PARAM_GRADS
+  // (Hybrid_VAEModel, which joins the second stream itself, passes it) leaves the parameter gradients trailing.
   // Round 2 (implicit-GEMM convolutions): decode backward -0.48 ms, encoder backward beside the trailing work +0.46 ms.
   // Round 3 (A/B inside one session, three runs each): 17.106 -> 17.034 ms per step.
-  static const bool env_on = getenv("ACVAE_DECODE_DEFER") && atoi(getenv("ACVAE_DECODE_DEFER")) == 1;
-  const int set = g_decode_defer.load();
-  const bool on = set < 0 ? env_on : set != 0;
-  if (!on || !aux_stream || aux_stream == stream || !dis_flags_host) return 0;
+  if (!(flags & ACVAE_FLAG_DEFER_PARAM_GRADS) || !aux_stream || aux_stream == stream || !dis_flags_host) return 0;
   for (int t = 0; t < Tc; ++t)
     if (dis_flags_host[t] != 0) return 0;      // the prior BPTT waits for the decoder's dz: nothing to overlap
   return 1;
@@ -667,7 +672,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
                                 const float* d_p_means_utt, float* d_mem_in, float* d_q_z, void* saved_v,
                                 int64_t saved_bytes, void* scratch_v, int64_t scratch_bytes, int N, int Tc, int S, int E,
                                 int H, int A, int V, int Eenc, void* stream, void* aux_stream, const uint8_t* emb_keep,
-                                float emb_drop_p) {
+                                float emb_drop_p, int flags) {
   if (emb_keep && !(emb_drop_p > 0.f && emb_drop_p <= 1.f)) return ACVAE_EINVAL;   // p = 1: nn.Dropout zeroes everything
   DecLayout L;
   ACVAE_TRY(dec_layout(N, Tc, S, E, H, A, V, Eenc, L));
@@ -695,7 +700,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   // the encoder backward.  The caller then owns two obligations (include/acvae_hip.h): the second stream must be joined
   // before the gradients / d_q_z are read on another stream, and saved / scratch / the incoming gradients must stay
   // untouched until it has drained.
-  const bool defer = acvae_decode_bwd_defers(dis_flags_host, Tc, stream, aux_stream) != 0;
+  const bool defer = acvae_decode_bwd_defers(dis_flags_host, Tc, stream, aux_stream, flags) != 0;
   const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
   TnWs tn_p{sc + L.tn_p, L.tn_p_floats * 4};
@@ -925,7 +930,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(prior_bptt(t));
     ACVAE_TRY(prior_memgrad());
     ACVAE_TRY(prior_params());
-  } else if (acvae::decode_persist_bwd_ok(N, Tc, S, E, H, A)) {
+  } else if (!(flags & ACVAE_FLAG_NO_PERSIST) && acvae::decode_persist_bwd_ok(N, Tc, S, E, H, A)) {
     // independent chains: the Tc steps of both BPTT chains as ONE persistent launch on the first stream
     // (decode_persist.hip); everything batched behind it runs as before, the prior's share on the second stream.  Of
     // prior_begin() only the zeroing of the prior attention's memory gradient is needed (and its memsets of dhp / dc / dlz
@@ -942,7 +947,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     pb.dctx_part = sc + L.pd_part; pb.dhp_part = pb.dctx_part + 4L * N * E; pb.dml_part = pb.dhp_part + 4L * N * E;
     pb.cnt = (unsigned*)(sc + L.pd_cnt_b);
     pb.N = N; pb.Tc = Tc; pb.S = S; pb.E = E; pb.H = H; pb.A = A;
-    ACVAE_TRY(acvae::decode_persist_bwd(pb, st.s));
+    ACVAE_TRY(acvae::decode_persist_bwd(pb, st.s, flags));
     ACVAE_TRY(dec_memgrad());
     if (fork.on()) ACVAE_TRY(Fork::edge(st.s, sp.s));     // the prior's batched work reads what the launch wrote
     ACVAE_TRY(prior_memgrad());
@@ -993,7 +998,7 @@ extern "C" int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, vo
 // beam search (models/vae_model.py:896-995) and by anyone calling the sub-modules directly
 // ==========================================================================================
 namespace {
-struct StepLayout { long skws, encproj, rnn, q, gates, gh, ml, words, total; };
+struct StepLayout { long skws, encproj, rnn, q, gates, gh, ml, words, attws, attws_bytes, total; };
 int step_layout(int N, int S, int E, int H, int A, int V, StepLayout& L) {
   if (N <= 0 || S <= 0 || E <= 0 || H <= 0 || A <= 0 || V <= 1) return ACVAE_EINVAL;
   Bump b;
@@ -1005,8 +1010,16 @@ int step_layout(int N, int S, int E, int H, int A, int V, StepLayout& L) {
   L.gh = b.take((long)N * 3 * H);
   L.ml = b.take((long)N * 2 * E);
   L.words = b.take((long)N * 2);
+  // workspace of the split-over-frames attention (acvae_attn_fwd: few query rows); its counters are zeroed by every entry point
+  L.attws_bytes = acvae_attn_fwd_workspace_bytes(N, 1, S, A, E);
+  const long w2 = acvae_attn_fwd_workspace_bytes(N, 1, S, E, E);
+  if (w2 > L.attws_bytes) L.attws_bytes = w2;
+  L.attws = b.take(L.attws_bytes / 4 + 64);
   L.total = b.off;
   return ACVAE_OK;
+}
+inline int step_attws_reset(float* sc, const StepLayout& L, hipStream_t st) {
+  return L.attws_bytes > 0 ? zero(sc + L.attws, 256, st) : ACVAE_OK;
 }
 }  // namespace
 
@@ -1041,7 +1054,7 @@ int prior_step(const void* const* params, const int64_t* word, const float* mem,
   ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_P_EMB), V, rnn, 3 * E, N, E, st));
   ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_ATT_W), 2 * E, nullptr, q, E, N, E, E, 0, st));
   ACVAE_TRY(acvae_attn_fwd(q, (long)Tq * E, E, ep, mem, mem_lens, P(TP_P_ATT_V), rnn + E, (long)Tq * 3 * E, 3 * E, attw,
-                           (long)Tq * S, S, Nm, Tq, S, E, E, st));
+                           (long)Tq * S, S, Nm, Tq, S, E, E, L.attws_bytes > 0 ? sc + L.attws : nullptr, L.attws_bytes, st, 0));
   ACVAE_TRY(acvae::copy_rows(rnn + 2 * E, 3 * E, last_z, E, N, E, st));
   ACVAE_TRY(gemm(rnn, 3 * E, P(TP_P_WIH), 3 * E, P(TP_P_BIH), gates, 4 * Hp, N, 4 * Hp, 3 * E, 0, st));
   ACVAE_TRY(gemm(h_prev, Hp, P(TP_P_WHH), Hp, P(TP_P_BHH), gates, 4 * Hp, N, 4 * Hp, Hp, 1, st));
@@ -1062,7 +1075,7 @@ int decoder_step(const void* const* params, const int64_t* word, const float* h_
   ACVAE_TRY(acvae::embed_gather(word, 1, P(TP_DEC_EMB), V, rnn_input, 3 * E, N, E, st));
   ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_ATT_W), E + H, nullptr, q, A, N, A, H, 0, st));
   ACVAE_TRY(acvae_attn_fwd(q, (long)Tq * A, A, ed, mem, mem_lens, P(TP_DEC_ATT_V), rnn_input + E, (long)Tq * 3 * E, 3 * E,
-                           attw, (long)Tq * S, S, Nm, Tq, S, A, E, st));
+                           attw, (long)Tq * S, S, Nm, Tq, S, A, E, L.attws_bytes > 0 ? sc + L.attws : nullptr, L.attws_bytes, st, 0));
   ACVAE_TRY(acvae::copy_rows(rnn_input + 2 * E, 3 * E, z, E, N, E, st));
   ACVAE_TRY(gemm(rnn_input, 3 * E, P(TP_DEC_WIH), 3 * E, P(TP_DEC_BIH), gi, 3 * H, N, 3 * H, 3 * E, 0, st));
   ACVAE_TRY(gemm(h_prev, H, P(TP_DEC_WHH), H, P(TP_DEC_BHH), gh, 3 * H, N, 3 * H, H, 0, st));
@@ -1086,6 +1099,7 @@ extern "C" int acvae_prior_step_fwd(const void* const* params, const int64_t* wo
   float* sc = (float*)scratch_v;
   Ctx st{(hipStream_t)stream, sc + L.skws};
   ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  ACVAE_TRY(step_attws_reset(sc, L, st.s));
   const float* ep = encproj_p;
   if (!ep) {
     ACVAE_TRY(acvae_attn_precompute(params, 1, mem, sc + L.encproj, N, S, E, E, E, stream));
@@ -1107,6 +1121,7 @@ extern "C" int acvae_decoder_step_fwd(const void* const* params, const int64_t* 
   float* sc = (float*)scratch_v;
   Ctx st{(hipStream_t)stream, sc + L.skws};
   ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  ACVAE_TRY(step_attws_reset(sc, L, st.s));
   const float* ed = encproj_d;
   if (!ed) {
     ACVAE_TRY(acvae_attn_precompute(params, 0, mem, sc + L.encproj, N, S, E, H, A, stream));
@@ -1199,6 +1214,7 @@ extern "C" int acvae_beam_search(const void* const* params, const float* mem, co
   float* ssc = sc + L.step;
   Ctx st{(hipStream_t)stream, ssc + SL.skws};
   ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  ACVAE_TRY(step_attws_reset(ssc, SL, st.s));
   ACVAE_TRY(acvae_attn_precompute(params, 0, mem, sc + L.encd, N, S, E, H, A, stream));
   ACVAE_TRY(acvae_attn_precompute(params, 1, mem, sc + L.encp, N, S, E, E, E, stream));
   float *h = sc + L.h, *hp = sc + L.hp, *cp = sc + L.cp, *lz = sc + L.lz;

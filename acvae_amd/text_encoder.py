@@ -62,8 +62,9 @@ class _PosteriorFn(torch.autograd.Function):
         scratch = scratch_buffer(scratch_b, dev)
         qm, ql, qz = (torch.empty(N, Tc, E, device=dev) for _ in range(3))
         utt = torch.empty(N, 2 * Hq, device=dev)
+        _lib.persist_status(dev)                 # the device's status words are registered before the first persistent launch
         _lib.call("acvae_posterior_fwd", ptr_table(params), caps_d, caps_d.stride(0), lens1_d, eps_q, qm, ql, qz, utt,
-                  saved, saved_b, scratch, scratch_b, N, Tc, E, Hq, V, _lib.current_stream())
+                  saved, saved_b, scratch, scratch_b, N, Tc, E, Hq, V, _lib.current_stream(), _lib.call_flags())
         ctx.mod, ctx.saved, ctx.dims = mod, saved, (N, Tc, E, Hq, V)
         # an OUTPUT kept as a plain ctx attribute forms a tensor -> grad_fn -> ctx -> tensor cycle that is never collected
         ctx.save_for_backward(lens1_d, eps_q, ql)
@@ -84,7 +85,7 @@ class _PosteriorFn(torch.autograd.Function):
         scratch = scratch_buffer(scratch_b, eps_q.device)
         _lib.call("acvae_posterior_bwd", ptr_table(params), ptr_table(grads), lens1_d, eps_q, ql, c(d_qm),
                   c(d_ql), c(d_qz), c(d_utt), ctx.saved, ctx.saved.numel(), scratch, scratch_b, N, Tc, E, Hq, V,
-                  _lib.current_stream())
+                  _lib.current_stream(), _lib.call_flags())
         ctx.saved = None
         owner = mod._owner() if mod._owner is not None else None
         if owner is not None and owner._grad_ready_cb is not None:

@@ -318,7 +318,16 @@ class TrainStep:
             self._in_flight.append(ev)
             if len(self._in_flight) > self.max_steps_in_flight:
                 self._in_flight.pop(0).synchronize()
+                # a persistent launch of that step that could not complete has poisoned the step with NaN and raised the
+                # device's status word: turn it into an error at the first synchronisation point the loop has anyway
+                _lib.check_persist_status(self.flat_p.device)
         return parts
+
+    def synchronize(self):
+        """Wait for every queued step and raise if one of their persistent launches gave up (acvae_persist_status_register)."""
+        torch.cuda.synchronize(self.flat_p.device)
+        self._in_flight.clear()
+        _lib.check_persist_status(self.flat_p.device)
 
     def sync_buffers(self):
         """Join the asynchronous BatchNorm-buffer broadcast of the previous step (a stream dependency under RCCL)."""

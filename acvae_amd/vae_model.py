@@ -53,11 +53,12 @@ class _DecodeFn(torch.autograd.Function):
         mem = mem.contiguous()
         method, temp, noise = sampling["sample"] if sampling and sampling.get("sample") else (0, 1.0, None)
         keep, drop_p = sampling["emb_keep"] if sampling and sampling.get("emb_keep") else (None, 0.0)
+        _lib.persist_status(dev)                 # the device's status words are registered before the first persistent launch
         _lib.call("acvae_decode_fwd_sampled", ptr_table(params), mem, mem_lens_d, caps_d,
                   caps_d.stride(0) if train else 0, lens1_d, q_z, eps_p, ss_arr, dis_arr, logits, outputs, seqs, slp,
                   attw, pm, pl, pz, putt, hfin, hp, cp, saved, saved_b, scratch, scratch_b, *dims, model.start_idx,
                   model.end_idx, _lib.current_stream(), model._aux_stream(), int(method), float(temp), noise, keep,
-                  float(drop_p))
+                  float(drop_p), _lib.call_flags())
         ctx.model, ctx.saved, ctx.dims, ctx.dis_arr = model, saved, dims, dis_arr
         ctx.emb_keep, ctx.emb_p = keep, float(drop_p)
         # outputs kept as plain ctx attributes would form tensor -> grad_fn -> ctx -> tensor cycles that are never collected
@@ -87,10 +88,11 @@ class _DecodeFn(torch.autograd.Function):
         scratch = scratch_buffer(scratch_b, dev, tag="decode")
         ups = [c(t) for t in (d_logits, d_outputs, d_pm, d_pl, d_pz, d_putt)]
         main, aux = _lib.current_stream(), model._aux_stream()
+        flags = _lib.call_flags(defer=model.defer_param_grads)
         _lib.call("acvae_decode_bwd", ptr_table(params), ptr_table(grads), mem, mem_lens_d, lens1_d, eps_p, ctx.dis_arr,
                   outputs, attw, pl, *ups, d_mem, d_qz, ctx.saved, ctx.saved.numel(), scratch, scratch_b, *ctx.dims, main,
-                  aux, ctx.emb_keep, ctx.emb_p)
-        defers = bool(_lib.lib().acvae_decode_bwd_defers(ctx.dis_arr, Tc, main, aux))   # a yes / no answer, not a status
+                  aux, ctx.emb_keep, ctx.emb_p, flags)
+        defers = bool(_lib.lib().acvae_decode_bwd_defers(ctx.dis_arr, Tc, main, aux, flags))   # a yes / no answer, not a status
         if model._grad_ready_cb is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -133,9 +135,9 @@ class Hybrid_VAEModel(CaptionModel):
         self._encproj_cache = {}
         self.use_side_stream = os.environ.get("ACVAE_SIDE_STREAM", "1") != "0"
         # the decode backward leaves its parameter gradients trailing on the second stream beside the encoder backward
-        # (_DecodeFn.backward joins it); ACVAE_DECODE_DEFER=0 keeps everything on the main stream
-        if os.environ.get("ACVAE_DECODE_DEFER", "1") != "0":
-            _lib.lib().acvae_set_decode_defer(1)
+        # (_DecodeFn.backward joins it; ACVAE_FLAG_DEFER_PARAM_GRADS per call); ACVAE_DECODE_DEFER=0 or
+        # model.defer_param_grads = False keeps everything on the main stream
+        self.defer_param_grads = True
         self.staged = None         # device copies of caps / cap_lens-1 made by the last training forward
         self.noise = None          # optional replay: dict(eps_q=[N,Tc,E], eps_p=[Tc,N,E]) consumed by the next forward
         self._grad_views = None    # {param: flat-gradient view}, set by the train-step harness
@@ -314,6 +316,12 @@ class Hybrid_VAEModel(CaptionModel):
             for r, beam in enumerate(chosen):
                 out[i, r, :len(beam["seq"])] = torch.from_numpy(beam["seq"])
         return {"seqs": out.to(dev)}
+
+    def check_persistent_launches(self, device=None):
+        """Raise if a persistent decode / posterior launch on the model's device gave up (its outputs are NaN then).  Call
+        behind a synchronisation point; TrainStep does at its in-flight event."""
+        dev = device if device is not None else next(self.parameters()).device
+        _lib.check_persist_status(dev)
 
     def _side_stream(self, main):
         if getattr(self, "_side", None) is None or self._side.device != main.device:

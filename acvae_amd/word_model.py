@@ -1,5 +1,6 @@
-"""Mirror of ``models/word_model.py`` ``CaptionModel`` (:14-65): class constants, constructor and the
-``forward`` arity contract (4 inputs = training, 2 inputs = inference)."""
+"""Base of the caption models, after ``models/word_model.py`` ``CaptionModel`` (:14-44): the vocabulary index
+constants the rest of the path relies on and the (encoder, decoder) pair.  The ``forward`` arity contract of :46-65
+(4 inputs = training, 2 inputs = inference) is implemented by ``Hybrid_VAEModel.forward``, the only model of this path."""
 import torch.nn as nn
 
 
@@ -22,17 +23,3 @@ class CaptionModel(nn.Module):
     def set_index(cls, start_idx, end_idx):
         cls.start_idx = start_idx
         cls.end_idx = end_idx
-
-    def forward(self, *input, **kwargs):
-        """models/word_model.py:46-65"""
-        if len(input) == 4:
-            feats, feat_lens, caps, cap_lens = input
-            encoded = self.encoder(feats, feat_lens)
-            output = self.train_forward(encoded, caps, cap_lens, **kwargs)
-        elif len(input) == 2:
-            feats, feat_lens = input
-            encoded = self.encoder(feats, feat_lens)
-            output = self.inference_forward(encoded, **kwargs)
-        else:
-            raise Exception("Number of input should be either 4 (feats, feat_lens, caps, cap_lens) or 2 (feats, feat_lens)")
-        return output

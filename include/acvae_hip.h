@@ -9,10 +9,18 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless its name ends in _host.
  *   - the caller owns every buffer, workspaces included; the library never allocates or frees device
- *     memory.  Mutable state inside the library, all of it: (1) a per-THREAD, per-device pool of 64 HIP events used
- *     for the fork / join edges of the two-stream calls (thread_local: concurrent calls from different host threads
- *     share nothing, so every entry point is re-entrant across threads and streams); (2) the opt-in timing ring
- *     (acvae_prof_*, mutex-guarded, empty unless enabled).  Run-time switches are read once from the environment.
+ *     memory (no hipMalloc / hipFree anywhere in csrc/; tests/test_abi_cpu.py greps for it).
+ *   - Mutable state inside the library, ALL of it:
+ *       (1) a per-THREAD, per-device pool of 64 HIP events used for the fork / join edges of the two-stream calls
+ *           (thread_local: concurrent calls from different host threads share nothing, so every entry point is
+ *           re-entrant across threads and streams);
+ *       (2) the opt-in timing ring (acvae_prof_*, mutex-guarded, empty unless enabled);
+ *       (3) one slot per DEVICE for the persistent launches (csrc/decode_persist.hip), mutex-guarded: the HIP event that
+ *           chains a device's persistent launches behind each other, the device's CU count, which kernels had their
+ *           dynamic-LDS limit raised there, and the status pointer registered with acvae_persist_status_register.
+ *     There are no process-global behaviour switches: what used to be acvae_set_decode_persist / _decode_defer /
+ *     _attn_split are per-call `flags` (ACVAE_FLAG_*).  The only environment variables the library reads are the A/B
+ *     switches of the encoder driver (ACVAE_CONV_WINO, ... listed in DESIGN.md), each read once.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises.
  *   - return 0 on success, a negative ACVAE_E* code for bad arguments, or a positive hipError_t.
  *   - fp32 everywhere ("dtype f32"), token ids / lengths int64 (as torch.long).
@@ -25,8 +33,28 @@
 extern "C" {
 #endif
 
-#define ACVAE_ABI_VERSION 2
+#define ACVAE_ABI_VERSION 3
 int acvae_abi_version(void);
+
+/* Per-call option bits (`flags`, the last argument of the entry points that take them; 0 = defaults). */
+#define ACVAE_FLAG_NO_PERSIST 1          /* decode / posterior: the per-step launches instead of the persistent kernels */
+#define ACVAE_FLAG_DEFER_PARAM_GRADS 2   /* acvae_decode_bwd: parameter gradients trail on aux_stream (see there) */
+#define ACVAE_FLAG_NO_ATTN_SPLIT 4       /* acvae_attn_fwd: never the split-over-frames form */
+#define ACVAE_FLAG_TEST_STALL 8          /* test aid: a persistent launch is queued one workgroup short with a short spin
+                                            bound, so that its roles give up as they would if part of the grid were not
+                                            resident; exercises the abort -> NaN -> status path below */
+
+/* Persistent launches (the teacher-forced decode loop and the posterior BiGRU, forward and backward: one launch each whose
+ * workgroups hand results to each other and therefore must ALL be resident).  The library (1) takes that path only when the
+ * occupancy calculator says the whole grid fits the current device, (2) chains a device's persistent launches behind each
+ * other so that two never share the chip, and (3) bounds every wait: a launch that still cannot finish (another PROCESS
+ * holds the CUs) gives up, a one-workgroup tail kernel behind it overwrites its outputs with NaN and sets status words
+ * the caller registered for the device:
+ *   status_words_host: 8 uint32 in page-locked, device-visible host memory owned by the caller (hipHostMalloc /
+ *   torch pin_memory), zeroed by the caller; word k (0 decode fwd, 1 decode bwd, 2 posterior fwd, 3 posterior bwd) and word 4
+ *   ("any") become 1.  The caller reads them at a point where the stream has drained (acvae_amd: TrainStep's in-flight event,
+ *   Hybrid_VAEModel.check_persistent_launches) and raises.  NULL unregisters.  Without a registered pointer only the NaNs tell. */
+int acvae_persist_status_register(int device, void* status_words_host);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic dense products on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replace torch.nn.Linear /
@@ -56,11 +84,18 @@ int acvae_transpose(const float* in, int64_t ld_in, float* out, int64_t ld_out, 
  * ------------------------------------------------------------------------------------------- */
 /* acvae_attn_fwd with N * Tq <= 128 query rows and S > 16 splits the frames of a row over workgroups (one decode step of the
  * step API / beam search / sampled decode; results equal to the one-workgroup form up to the summation order of the softmax
- * denominator and the context).  0 switches that form off (tests, A/B timing). */
-int acvae_set_attn_split(int on);
+ * denominator and the context) - when the caller hands over `ws` of acvae_attn_fwd_workspace_bytes (0: the shape never
+ * splits).  Its first 1024 bytes are arrival counters: ZERO them once (hipMemsetAsync) before the first call; every call
+ * leaves them zero, so stream-ordered calls may reuse the workspace; calls that can run side by side need one each.
+ * ws == NULL or ACVAE_FLAG_NO_ATTN_SPLIT: the one-workgroup form. */
+int64_t acvae_attn_fwd_workspace_bytes(int N, int Tq, int S, int A, int E);
 int acvae_attn_fwd(const float* qproj, int64_t q_sn, int64_t q_sj, const float* encproj, const float* enc,
                    const int64_t* lens, const float* v, float* ctx, int64_t c_sn, int64_t c_sj, float* weights,
-                   int64_t w_sn, int64_t w_sj, int N, int Tq, int S, int A, int E, void* stream);
+                   int64_t w_sn, int64_t w_sj, int N, int Tq, int S, int A, int E, void* ws, int64_t ws_bytes, void* stream,
+                   int flags);
+/* Test aid: y[i] = the tanh the attention kernels evaluate (hardware exp2 / rcp form, absolute error <= 2e-7; a library built
+ * with -DACVAE_EXACT_TANH uses tanhf instead, for parity debugging). */
+int acvae_tanh_att(const float* x, float* y, int64_t n, void* stream);
 /* Backward of the above for upstream dctx (attention weights carry no gradient on this path).
  * dencproj [N,S,A] and denc [N,S,E] are ACCUMULATED into (+=); dv_part [N,A] is accumulated into;
  * dqproj rows are written.  `ws`: scratch of acvae_attn_bwd_workspace_bytes(N,Tq,S,A). */
@@ -313,20 +348,18 @@ int64_t acvae_posterior_scratch_bytes(int N, int Tc, int E, int Hq, int V);
 int acvae_posterior_fwd(const void* const* params, const int64_t* caps, int64_t ld_caps, const int64_t* lens1,
                         const float* eps_q, float* q_means, float* q_logs, float* q_z, float* q_means_utt,
                         void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int Tc, int E,
-                        int Hq, int V, void* stream);
+                        int Hq, int V, void* stream, int flags);
 int acvae_posterior_bwd(const void* const* params, void* const* grads, const int64_t* lens1, const float* eps_q,
                         const float* q_logs, const float* d_q_means, const float* d_q_logs, const float* d_q_z,
                         const float* d_q_means_utt, void* saved, int64_t saved_bytes, void* scratch,
-                        int64_t scratch_bytes, int N, int Tc, int E, int Hq, int V, void* stream);
+                        int64_t scratch_bytes, int N, int Tc, int E, int Hq, int V, void* stream, int flags);
 
 /* The teacher-forced decode loop (all words known, no step feeds the prior's z to the decoder: acvae_decode_fwd with every
  * ss flag set and every dis flag clear) runs as ONE persistent launch (csrc/decode_persist.hip) when N <= 32, S <= 512,
- * E is a power of two in 32..2048 and H, A are multiples of 32; its results are bit-identical to the per-step path.
- * The posterior's packed BiGRU (acvae_posterior_fwd / _bwd) runs the same way - one launch per pass for both directions - when
- * N <= 32 and Hq is a multiple of 32 up to 512.
- * on = 0 forces the per-step paths (A/B, parity tests), 1 re-enables them; returns the previous setting (-1: the
- * environment's ACVAE_DECODE_PERSIST had not been consulted yet).  Replaces nothing in the reference (scheduling only). */
-int acvae_set_decode_persist(int on);
+ * E is a power of two in 32..2048, H, A are multiples of 32 and the whole grid fits the device at once; its results are
+ * bit-identical to the per-step path.  The posterior's packed BiGRU (acvae_posterior_fwd / _bwd) runs the same way - one
+ * launch per pass for both directions - when N <= 32 and Hq is a multiple of 32 up to 512.  ACVAE_FLAG_NO_PERSIST forces the
+ * per-step paths (A/B, parity tests).  Replaces nothing in the reference (scheduling only). */
 
 /* A4+A5+A6+A7 (+A12 when caps == NULL): the step-by-step decode of Hybrid_VAEModel
  * models/vae_model.py:700-730,792-869 with PriorRNN (text_encoder.py:247-268),
@@ -352,7 +385,7 @@ int acvae_decode_fwd(const void* const* params, const float* mem_in, const int64
                      float* sampled_logprobs, float* attn_w, float* p_means, float* p_logs, float* p_z,
                      float* p_means_utt, float* h_final, float* hp_final, float* cp_final, void* saved,
                      int64_t saved_bytes, void* scratch, int64_t scratch_bytes, int N, int Tc, int S, int E, int H,
-                     int A, int V, int Eenc, int start_idx, int end_idx, void* stream, void* aux_stream);
+                     int A, int V, int Eenc, int start_idx, int end_idx, void* stream, void* aux_stream, int flags);
 /* The same with sample_next_word's method (models/word_model.py:173-207) chosen by the caller: ACVAE_SAMPLE_GREEDY
  * (= acvae_decode_fwd), or GUMBEL / MULTINOMIAL with `temp` and `sample_noise` [Tc,N,V] (see acvae_sample_next_word; the
  * per-step draws of the reference in step order).  seqs / sampled_logprobs then hold the sampled words; with
@@ -368,26 +401,25 @@ int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, con
                              float* cp_final, void* saved, int64_t saved_bytes, void* scratch, int64_t scratch_bytes,
                              int N, int Tc, int S, int E, int H, int A, int V, int Eenc, int start_idx, int end_idx,
                              void* stream, void* aux_stream, int sample_method, float temp, const float* sample_noise,
-                             const uint8_t* emb_keep, float emb_drop_p);
+                             const uint8_t* emb_keep, float emb_drop_p, int flags);
 /* Backward for upstream gradients of logits / outputs / p_means / p_logs / p_z / p_means_utt (each may be
  * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E].
- * Stream contract: d_mem_in is ordered on `stream` when the call returns.  When acvae_decode_bwd_defers() says 1 for the
- * same flags / streams (a second stream is given and no step fed the prior's z to the decoder), everything d_mem_in
- * does not depend on - the parameter gradients and d_q_z - is queued on `aux_stream` behind the call, so that it runs
- * beside whatever `stream` does next (the encoder backward): the caller joins aux_stream before those results are read
- * on another stream, and keeps saved / scratch / outputs / the upstream gradients untouched until aux_stream has
- * drained.  Otherwise (0) everything is ordered on `stream` on return.  Opt-in: 0 unless ACVAE_DECODE_DEFER=1 or
- * acvae_set_decode_defer(1) (returns the previous setting, -1 = never set; Hybrid_VAEModel, which joins the second stream
- * at the end of the backward pass, sets it unless ACVAE_DECODE_DEFER=0: -0.07 ms per step on the reference configuration). */
-int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream);
-int acvae_set_decode_defer(int on);
+ * Stream contract: d_mem_in is ordered on `stream` when the call returns.  With ACVAE_FLAG_DEFER_PARAM_GRADS, when
+ * acvae_decode_bwd_defers says 1 for the same flags / streams (a second stream is given and no step fed the prior's z to the
+ * decoder), everything d_mem_in does not depend on - the parameter gradients and d_q_z - is queued on `aux_stream` behind
+ * the call, so that it runs beside whatever `stream` does next (the encoder backward): the caller joins aux_stream before
+ * those results are read on another stream, and keeps saved / scratch / outputs / the upstream gradients untouched until
+ * aux_stream has drained.  Without the flag (0) everything is ordered on `stream` on return.  Hybrid_VAEModel, which joins
+ * the second stream at the end of the backward pass, passes it unless ACVAE_DECODE_DEFER=0 (-0.07 ms per step on the
+ * reference configuration). */
+int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream, int flags);
 int acvae_decode_bwd(const void* const* params, void* const* grads, const float* mem_in, const int64_t* mem_lens,
                      const int64_t* lens1, const float* eps_p, const int* dis_flags_host, const float* outputs,
                      const float* attn_w, const float* p_logs, const float* d_logits, const float* d_outputs_ext,
                      const float* d_p_means, const float* d_p_logs, const float* d_p_z, const float* d_p_means_utt,
                      float* d_mem_in, float* d_q_z, void* saved, int64_t saved_bytes, void* scratch,
                      int64_t scratch_bytes, int N, int Tc, int S, int E, int H, int A, int V, int Eenc, void* stream,
-                     void* aux_stream, const uint8_t* emb_keep, float emb_drop_p);
+                     void* aux_stream, const uint8_t* emb_keep, float emb_drop_p, int flags);
 /* float caption ids (collate pads with torch.zeros -> float32, caption_dataset.py:293) -> int64 */
 int acvae_caps_to_long(const float* caps, int64_t* out, int64_t n, void* stream);
 

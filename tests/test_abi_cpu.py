@@ -15,7 +15,7 @@ def test_build_and_symbols():
     so = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(so, name), f"{name} declared in include/acvae_hip.h but not exported"
-    assert _lib.lib().acvae_abi_version() == 2
+    assert _lib.lib().acvae_abi_version() == 3
 
 
 def test_bad_arguments_are_reported_not_thrown():
@@ -23,7 +23,27 @@ def test_bad_arguments_are_reported_not_thrown():
     # null pointers / bad dims -> negative code, no launch attempted (safe without a GPU)
     assert lib.acvae_reparam_fwd(None, 0, None, 0, None, None, None, 0, None, 0, 4, 4, None) == -1
     assert lib.acvae_gemm_nt(None, 0, None, 0, None, None, 0, 4, 4, 4, 0, None) == -1
-    assert lib.acvae_attn_fwd(None, 0, 0, None, None, None, None, None, 0, 0, None, 0, 0, 1, 1, 1, 1, 1, None) == -1
+    assert lib.acvae_attn_fwd(None, 0, 0, None, None, None, None, None, 0, 0, None, 0, 0, 1, 1, 1, 1, 1, None, 0, None, 0) == -1
+    assert lib.acvae_persist_status_register(-1, None) == -1
+    # workspace sizes are host arithmetic: 0 where the split-over-frames form never runs, counters + partials where it does
+    assert lib.acvae_attn_fwd_workspace_bytes(32, 21, 62, 512, 512) == 0
+    assert lib.acvae_attn_fwd_workspace_bytes(16, 1, 187, 512, 512) == 1024 + 16 * 12 * 516 * 4
+
+
+def test_library_owns_no_device_memory_and_no_behaviour_switches():
+    """SURVEY 8(b) Ownership: the caller owns every buffer, workspaces included - no hipMalloc / hipFree (nor the managed /
+    async / host-allocating variants) anywhere in csrc/, and no process-global acvae_set_* switches in the ABI."""
+    import pathlib
+    import re
+    root = pathlib.Path(__file__).resolve().parents[1]
+    banned = re.compile(r"\bhip(Malloc\w*|Free\w*|HostMalloc|HostAlloc|MallocManaged|MemPool\w*)\s*\(")
+    for path in sorted((root / "acvae_amd" / "csrc").glob("*")):
+        if path.suffix in (".hip", ".h"):
+            code = re.sub(r"//[^\n]*", "", path.read_text())
+            assert not banned.search(code), f"{path.name} allocates or frees memory"
+    protos, _ = _lib.parse_header()
+    assert not [n for n in protos if n.startswith("acvae_set_")]
+    assert "ACVAE_DEV_LIB" not in (root / "acvae_amd" / "_lib.py").read_text()
 
 
 def test_product_never_reaches_into_the_oracle():

@@ -162,7 +162,11 @@ def test_loss_vs_oracle_at_config2_full_size(B, T):
     if (B, T) == (16, 3000):
         assert out["attn_weights"].shape == (16, 187, L - 1)
         w_got, w_want = out["attn_weights"].detach().cpu(), ores["out"]["attn_weights"].detach()
-        assert torch.allclose(w_got, w_want, rtol=1e-4, atol=2e-5), float((w_got - w_want).abs().max())   # measured 2.2e-5
+        # rtol 1e-4 / atol 1e-5 where the summation order changes
+        viol = (w_got - w_want).abs() - (1e-5 + 1e-4 * w_want.abs())
+        i = int(viol.argmax())
+        assert float(viol.max()) <= 0, ("attn_weights", float(w_got.reshape(-1)[i]), float(w_want.reshape(-1)[i]),
+                                        float((w_got - w_want).abs().max()), int((viol > 0).sum()))
     lens1 = np.asarray(cl) - 1
     ce = LabelSmoothingLoss(V, 0.1).masked(out["logits"], caps[:, 1:].to(torch.long), lens1)
     kl = Normal_kl_loss()(out["q_means"], out["q_logs"], out["p_means"], out["p_logs"])

@@ -434,6 +434,6 @@ def test_bigru_seq_and_posterior_golden_g5():
     utt = torch.empty(n, 2 * E, device="cuda")
     caps_d = caps.long().cuda().contiguous()
     _lib.call("acvae_posterior_fwd", ptr_table(table), caps_d, caps_d.stride(0), lens1.cuda(), T(g["eps"]).cuda().contiguous(),
-              qm, ql, qz, utt, saved, sb, scratch, cb, n, Tc, E, E, V, S())
+              qm, ql, qz, utt, saved, sb, scratch, cb, n, Tc, E, E, V, S(), 0)
     for got, key in ((qm, "q_means"), (ql, "q_logs"), (qz, "q_z"), (utt, "q_means_utt")):
         np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=1e-4, atol=1e-5, err_msg=key)

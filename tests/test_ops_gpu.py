@@ -96,7 +96,8 @@ def _attn_hip(st, h_dec, h_enc, lens):
     qproj = torch.empty(N, A, device="cuda")
     _lib.call("acvae_gemm_nt", dev(h_dec), Hd, wd, Hd, None, qproj, A, N, A, Hd, 0, S())
     ctx = torch.empty(N, E, device="cuda"); w = torch.empty(N, S_, device="cuda")
-    _lib.call("acvae_attn_fwd", qproj, A, 0, encproj, enc, dev(lens), dev(v), ctx, E, 0, w, S_, 0, N, 1, S_, A, E, S())
+    _lib.call("acvae_attn_fwd", qproj, A, 0, encproj, enc, dev(lens), dev(v), ctx, E, 0, w, S_, 0, N, 1, S_, A, E, None, 0,
+              S(), 0)
     return ctx, w, (qproj, encproj, enc, dev(v))
 
 
@@ -132,7 +133,7 @@ def test_attention_backward_vs_oracle_autograd():
     q, p, e = dev(Q.detach()), dev(P.detach()), dev(h_enc.detach())
     c = torch.empty(N, Tq, E, device="cuda"); w = torch.empty(N, Tq, S_, device="cuda")
     _lib.call("acvae_attn_fwd", q, Tq * A, A, p, e, dev(lens), dev(v.detach()), c, Tq * E, E, w, Tq * S_, S_, N, Tq,
-              S_, A, E, S())
+              S_, A, E, None, 0, S(), 0)
     close(c, ctx.detach()); close(w, wts.detach())
     dq = torch.empty(N, Tq, A, device="cuda")
     dP = torch.zeros(N, S_, A, device="cuda"); dH = torch.zeros(N, S_, E, device="cuda")
@@ -240,9 +241,10 @@ def mse_check(out):
                                          (2, 1, 300, 96, 256)])
 def test_attention_split_over_frames_matches_one_workgroup_per_row(N, Tq, S_, A, E):
     """acvae_attn_fwd with few query rows splits a row's frames over workgroups and combines the per-split softmax pieces
-    (models/attn_model.py:29-45 is one softmax over S): against the one-workgroup-per-row kernel (switched by
-    acvae_set_attn_split) on ragged lengths - weights and context to fp32 summation-order tolerance, masked frames exactly 0,
-    rows summing to 1; twice in a row and on two streams at once (the per-stream scratch and its self-resetting counters)."""
+    (models/attn_model.py:29-45 is one softmax over S) when the caller hands over a workspace: against the one-workgroup-per-
+    row kernel (no workspace / ACVAE_FLAG_NO_ATTN_SPLIT) on ragged lengths - weights and context to fp32 summation-order
+    tolerance, masked frames exactly 0, rows summing to 1; twice in a row on one workspace (its counters reset themselves) and
+    on two streams at once with a workspace each.  The workspace is the CALLER's: the library allocates nothing."""
     g = torch.Generator().manual_seed(N * 1000 + S_)
     f = lambda *s: torch.randn(*s, generator=g).cuda()
     q, p, e, v = f(N, Tq, A), f(N, S_, A), f(N, S_, E), f(A)
@@ -250,27 +252,31 @@ def test_attention_split_over_frames_matches_one_workgroup_per_row(N, Tq, S_, A,
     if N > 2:
         lens[1] = 1
     lens_d = lens.cuda()
-    def run(stream=None):
+    wsb = _lib.call("acvae_attn_fwd_workspace_bytes", N, Tq, S_, A, E)
+    assert wsb > 1024
+    ws_a = torch.zeros(wsb, dtype=torch.uint8, device="cuda")
+    ws_b = torch.zeros(wsb, dtype=torch.uint8, device="cuda")
+    def run(ws, stream=None, flags=0):
         c, w = torch.empty(N, Tq, E, device="cuda"), torch.empty(N, Tq, S_, device="cuda")
         st = S() if stream is None else stream.cuda_stream
-        _lib.call("acvae_attn_fwd", q, Tq * A, A, p, e, lens_d, v, c, Tq * E, E, w, Tq * S_, S_, N, Tq, S_, A, E, st)
+        _lib.call("acvae_attn_fwd", q, Tq * A, A, p, e, lens_d, v, c, Tq * E, E, w, Tq * S_, S_, N, Tq, S_, A, E, ws,
+                  0 if ws is None else ws.numel(), st, flags)
         return c, w
-    was = _lib.lib().acvae_set_attn_split(0)
-    try:
-        c0, w0 = run()
-    finally:
-        _lib.lib().acvae_set_attn_split(1)
-    try:
-        c1, w1 = run()
-        c2, w2 = run()
-        torch.cuda.synchronize()
-        s2 = torch.cuda.Stream()
-        s2.wait_stream(torch.cuda.current_stream())
-        c3, w3 = run(s2)
-        c4, w4 = run()
-        torch.cuda.synchronize()
-    finally:
-        _lib.lib().acvae_set_attn_split(was)
+    c0, w0 = run(None)
+    c0b, w0b = run(ws_a, flags=_lib.FLAG_NO_ATTN_SPLIT)
+    assert torch.equal(c0, c0b) and torch.equal(w0, w0b)
+    with pytest.raises(RuntimeError, match="EWORKSPACE"):
+        _lib.call("acvae_attn_fwd", q, Tq * A, A, p, e, lens_d, v, c0, Tq * E, E, w0, Tq * S_, S_, N, Tq, S_, A, E, ws_a, 1024,
+                  S(), 0)
+    c1, w1 = run(ws_a)
+    c2, w2 = run(ws_a)
+    torch.cuda.synchronize()
+    assert int(ws_a[:1024].view(torch.int32).abs().max()) == 0        # the counters are zero again
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    c3, w3 = run(ws_b, s2)
+    c4, w4 = run(ws_a)
+    torch.cuda.synchronize()
     for c, w in ((c1, w1), (c2, w2), (c3, w3), (c4, w4)):
         assert torch.equal(c, c1) and torch.equal(w, w1)              # the same arithmetic whichever workgroup combines
         torch.testing.assert_close(w, w0, rtol=2e-5, atol=1e-7)
@@ -278,6 +284,25 @@ def test_attention_split_over_frames_matches_one_workgroup_per_row(N, Tq, S_, A,
         for n in range(N):
             assert float(w[n, :, int(lens[n]):].abs().max()) == 0.0 if int(lens[n]) < S_ else True
         torch.testing.assert_close(w.sum(-1), torch.ones(N, Tq, device="cuda"), rtol=0, atol=1e-5)
+
+
+def test_tanh_of_the_attention_scores_elementwise():
+    """tanh_att (csrc/common.h: 1 - 2 / (e^{2x} + 1) on the hardware exp2 / rcp) against tanh in fp64, element by element,
+    over [-20, 20] and around zero (|x| < 1e-4, where the form cancels and its error is absolute, not relative): bound
+    2e-7 absolute (a library built with ACVAE_EXACT_TANH=1 uses tanhf and passes with a relative bound too).
+    models/attn_model.py:33 applies tanh to every score term."""
+    xs = torch.cat([torch.linspace(-20, 20, 400001), torch.linspace(-1e-4, 1e-4, 20001), torch.tensor([0.0, 44.0, -44.0, 90.0, -90.0]),
+                    torch.randn(100000, generator=torch.Generator().manual_seed(3)) * 3]).float()
+    y = torch.empty_like(xs, device="cuda")
+    _lib.call("acvae_tanh_att", xs.cuda(), y, xs.numel(), S())
+    ref = torch.tanh(xs.double())
+    err = (y.cpu().double() - ref).abs()
+    assert float(err.max()) <= 2e-7, float(err.max())
+    assert bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
+    small = xs.abs() < 1e-4
+    assert float(err[small].max()) <= 1.2e-7          # one rounding of 1 - 2/(e+1) near zero
+    # odd symmetry to rounding and monotone where fp32 can tell neighbours apart
+    assert float((y[:400001] + y[:400001].flip(0)).abs().max()) <= 2.4e-7
 
 
 def test_loss_assembly_equals_the_tensor_expression():

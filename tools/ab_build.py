@@ -1,6 +1,6 @@
 """Builds the HIP library of another revision into tools/lab/libacvae_<name>.so (A/B timing inside ONE gpurun call - two boxes
 differ by several per cent): `python tools/ab_build.py <git-rev> <name>`, then on the GPU box
-`python bench.py ...` against `ACVAE_DEV_LIB=tools/lab/libacvae_<name>.so python bench.py ...`."""
+`python bench.py ...` against `python bench.py --lib tools/lab/libacvae_<name>.so ...` (tools/ab_bench.sh)."""
 import os, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,8 +2,8 @@
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acvae_amd import _lib
-if os.environ.get("ACVAE_DEV_LIB"):          # dev hook of tools/ablate.sh: time an ablation build of the library
-    _lib.LIB_PATH = os.environ["ACVAE_DEV_LIB"]
+if os.environ.get("ACVAE_DEV_LIB"):          # this TOOL's hook (tools/lab_wino.py, ablations): time another build of the library
+    _lib.use_library(os.environ["ACVAE_DEV_LIB"])
 from acvae_amd.encoder import Cnn10, Cnn14_16k
 B, T = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5

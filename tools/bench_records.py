@@ -53,8 +53,10 @@ def c4():
     lens = torch.full((N,), S, dtype=torch.long, device="cuda")
     ctx, w = torch.empty(N, E, device="cuda"), torch.empty(N, S, device="cuda")
     st = _lib.current_stream()
+    aws, aws_b = _lib.attn_fwd_workspace(N, 1, S, A, E, "cuda")
+    aflags = [0]
     def fwd():
-        _lib.call("acvae_attn_fwd", qproj, A, A, encproj, enc, lens, v, ctx, E, E, w, S, S, N, 1, S, A, E, st)
+        _lib.call("acvae_attn_fwd", qproj, A, A, encproj, enc, lens, v, ctx, E, E, w, S, S, N, 1, S, A, E, aws, aws_b, st, aflags[0])
     wsb = _lib.call("acvae_attn_bwd_workspace_bytes", N, 1, S, A)
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
     dctx, dq = f(N, E), torch.empty(N, A, device="cuda")
@@ -63,9 +65,9 @@ def c4():
         _lib.call("acvae_attn_bwd", dctx, E, E, qproj, A, A, encproj, enc, lens, v, w, S, S, dq, A, A, dencp, denc, dv, ws,
                   wsb, N, 1, S, A, E, st)
     def fwd_one_wg():
-        was = _lib.lib().acvae_set_attn_split(0)
+        aflags[0] = _lib.FLAG_NO_ATTN_SPLIT
         fwd()
-        _lib.lib().acvae_set_attn_split(was)
+        aflags[0] = 0
     for name, fn, nbytes in (("attn_fwd", fwd, N * S * (A + E) * 4),
                              ("attn_fwd_one_workgroup_per_row", fwd_one_wg, N * S * (A + E) * 4),
                              ("attn_bwd", bwd, N * S * (2 * A + 3 * E) * 4)):     # bwd: reads encproj, enc; r/w dencproj, denc

@@ -27,8 +27,8 @@ def build():
         if "pd_wait(" in l and "__device__" not in l and "for (int t" not in l:
             out.append("    PD_TR(%d);" % min(waits, 5)); waits += 1
     s = "\n".join(out)
-    s = s.replace('extern "C" int acvae_set_decode_persist(int on) {', 'extern "C" int acvae_pd_trace(unsigned long long* buf) { return (int)hipMemcpyToSymbol('
-                  'HIP_SYMBOL(g_pd_trace), &buf, sizeof(buf)); }\nextern "C" int acvae_set_decode_persist(int on) {')
+    s = s.replace('extern "C" int acvae_persist_status_register(int device, void* status_words_host) {', 'extern "C" int acvae_pd_trace(unsigned long long* buf) { return (int)hipMemcpyToSymbol('
+                  'HIP_SYMBOL(g_pd_trace), &buf, sizeof(buf)); }\nextern "C" int acvae_persist_status_register(int device, void* status_words_host) {')
     s = s.replace('#include "../../include/acvae_hip.h"', f'#include "{ROOT}/include/acvae_hip.h"')
     os.makedirs(LAB, exist_ok=True)
     src = os.path.join(LAB, "decode_persist_trace.hip"); open(src, "w").write(s)
@@ -39,11 +39,13 @@ def build():
 
 
 def run():
-    os.environ["ACVAE_DEV_LIB"] = LIB
+    os.environ["ACVAE_DEV_LIB"] = LIB       # this tool's own variable; handed to the package with use_library() below
     sys.path.insert(0, ROOT)
     import numpy as np, torch, random
     import bench
     from acvae_amd import _lib
+    if os.environ.get("ACVAE_DEV_LIB"):
+        _lib.use_library(os.environ["ACVAE_DEV_LIB"])
     model = bench.build_model().cuda().train()
     feats, caps, fl, cl = bench.synthetic(1)
     f = feats.cuda(); Tc = 21
@@ -70,11 +72,13 @@ def run():
 
 
 def run_bwd():
-    os.environ["ACVAE_DEV_LIB"] = LIB
+    os.environ["ACVAE_DEV_LIB"] = LIB       # this tool's own variable; handed to the package with use_library() below
     sys.path.insert(0, ROOT)
     import numpy as np, torch, random
     import bench
     from acvae_amd import _lib
+    if os.environ.get("ACVAE_DEV_LIB"):
+        _lib.use_library(os.environ["ACVAE_DEV_LIB"])
     from acvae_amd.trainer import TrainStep
     model = bench.build_model().cuda().train()
     ts = TrainStep(model, bench.V)

@@ -127,6 +127,8 @@ def time_one():
     import torch
     sys.path.insert(0, ROOT)
     from acvae_amd import _lib
+    if os.environ.get("ACVAE_DEV_LIB"):         # this tool's own variable (set per lab build by the parent process)
+        _lib.use_library(os.environ["ACVAE_DEV_LIB"])
     S = _lib.current_stream
     out = []
     for (H, W, Cin, Cout) in [(1000, 64, 64, 64), (500, 32, 128, 128), (125, 8, 512, 512)]:
