@@ -129,6 +129,7 @@ class TrainStep:
         self.step_count = 0
         self.max_steps_in_flight = int(os.environ.get("ACVAE_STEPS_IN_FLIGHT", "2"))
         self._in_flight = []
+        self._copy_stream = None
         self._flatten()
         # Buckets in flat order, each announced from inside the backward as soon as its gradients are queued:
         #   0 decoder + prior + heads (everything acvae_decode_bwd writes, 76 MB at V=5000): behind the decode backward,
@@ -277,8 +278,36 @@ class TrainStep:
         loss = combine_losses(ce, kl, mse, kl_weight, self.alpha if self.alpha is not None else 0.0)    # ce + w kl + alpha mse
         return loss, {"ce": ce.detach(), "kl": kl.detach(), "mse": None if mse is None else mse.detach()}, out
 
+    def prefetch(self, feats_host):
+        """Queue the upload of a LATER step's feature batch now, on a copy stream of its own: the 8 MB host-to-device copy
+        that Runner._forward makes in front of every step (`feats = batch[0].to(device)`, runners/pytorch_runner_vae.py:80)
+        then travels beside the step that is running instead of in front of the next encoder.  Returns the device tensor to
+        hand to step(); step() makes its stream wait for the copy.  Page-locked input is copied from where it lies;
+        pageable input is staged through the package's page-locked ring first (a host memcpy).  Typical loop:
+            nxt = ts.prefetch(batch0)
+            for batch in batches[1:] + [None]:
+                cur, nxt = nxt, (ts.prefetch(batch) if batch is not None else None)
+                ts.step(cur, ...)"""
+        dev = self.flat_p.device
+        t = torch.as_tensor(feats_host)
+        if t.is_cuda:
+            return t
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._copy_stream):
+            d = t.to(dev, non_blocking=True) if t.is_pinned() else _lib.h2d(t.float(), dev)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        d._acvae_ready = ev
+        return d
+
     def step(self, feats, feat_lens, caps, cap_lens, ss_ratio=1.0, dis_ratio=0, kl_weight=0.5):
         self.sync_buffers()
+        ready = getattr(feats, "_acvae_ready", None)
+        if ready is not None:                       # a batch uploaded by prefetch(): order this step behind its copy
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ready)
+            feats.record_stream(cur)
         self._decode_event = self._text_event = None
         self._decode_deferred = self._projemb_seen = False
         for p in self.order:
