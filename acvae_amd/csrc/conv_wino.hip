@@ -153,13 +153,22 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
 
 // Epilogue of both forward kernels: At . A in registers, the two position halves of a tile meet through LDS (`ex`: 8 KB per
 // wavefront, partner = vw ^ 1), raw output + BatchNorm partial sums.  vw = role index of the wavefront (XH = vw & 1).
+// Round 4: the epilogue was ~1100 instructions per wavefront (a tile-coordinate computation, a 64-bit address and a bounds
+// branch for each of a lane's 16 tiles) = 2.7 us of a 22 us workgroup on the 64-channel layers.  The 16 tiles of a lane are
+// four groups (k = r >> 2) of four tiles whose coordinates differ by a WAVE-UNIFORM step (wino_tile: cell = T[2k + h] + (r & 3),
+// T a multiple of 4): so the lane computes four byte offsets into its clip, the per-tile steps live in SGPRs, and the stores are
+// buffer stores (32-bit lane offset + scalar offset) against a descriptor of the CLIP whose size makes the hardware drop rows
+// past the clip's end - no address arithmetic, no branch per tile.  The LDS exchange moves both pixels of a tile in one
+// 8-byte access.
 template <int XH>
 __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 (&acc)[8], float* ex_mine, const float* ex_partner,
                                               float* red, int mh, int nh, int li, int h, int lane, int n, int ty0, int bm,
                                               int bn) {
   const int tid = threadIdx.x;
-  const int H = p.H, W = p.W;
-  float keep[16][2];
+  const int H = p.H, W = p.W, Cout = p.Cout;
+  float2 keep[16];
+  float2* exm = reinterpret_cast<float2*>(ex_mine);
+  const float2* exp_ = reinterpret_cast<const float2*>(ex_partner);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float hl[2][2];
@@ -169,31 +178,45 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
       hl[xl][0] = m0 + m1 + m2;
       hl[xl][1] = m1 - m2 - m3;
     }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float s = hl[0][b] + hl[1][b];
-      keep[r][b] = XH ? -s : s;
-      ex_mine[(r * 2 + b) * 64 + lane] = hl[1][b];
-    }
+    const float s0 = hl[0][0] + hl[1][0], s1 = hl[0][1] + hl[1][1];
+    keep[r] = make_float2(XH ? -s0 : s0, XH ? -s1 : s1);
+    exm[r * 64 + lane] = make_float2(hl[1][0], hl[1][1]);
   }
   __syncthreads();
   const int cout = bn * WN_TN + nh * 32 + li;
+  // per group k: pixel (y, x) of the tile with r & 3 == 0 (y already the output row XH of the tile), byte offset into the clip
+  int yk[4], voff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int tyl, tx;
+    wino_tile(mh, 8 * k + 4 * h, p.tw_shift, tyl, tx);
+    yk[k] = 2 * (ty0 + tyl) + XH;
+    voff[k] = ((yk[k] * W + 2 * tx) * Cout + cout) * 4;
+  }
+  // wave-uniform step of tile j = r & 3 inside a group: TW >= 4: two pixels to the right per tile; TW = 2 (wino_tile: the
+  // tile column is bit 0 of the rank, bit 1 selects the tile row two further down): x + 2 (j & 1), y + 4 (j >> 1)
+  int dyj[4], soff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dyj[j] = p.tw_shift == 1 ? 4 * (j >> 1) : 0;
+    const int dx = p.tw_shift == 1 ? 2 * (j & 1) : 2 * j;
+    soff[j] = (dyj[j] * W + dx) * Cout * 4;
+  }
+  const int pix = Cout * 4;                                  // bytes from a pixel to its right neighbour
+  // descriptor of clip n: stores whose offset lies past H * W * Cout * 4 bytes (rows >= H of a partial block) are dropped
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)n * H * W * Cout, 0, H * W * Cout * 4, 0x00020000);
   float s = 0.f, qq = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    int tyl, tx;
-    wino_tile(mh, (r & 3) + 8 * (r >> 2) + 4 * h, p.tw_shift, tyl, tx);
-    const int y = 2 * (ty0 + tyl) + XH;       // this wave finishes output row XH of its tiles
-    const int x = 2 * tx;
-    const float o0 = keep[r][0] + ex_partner[(r * 2 + 0) * 64 + lane];
-    const float o1 = keep[r][1] + ex_partner[(r * 2 + 1) * 64 + lane];
-    if (y < H) {
-      float* out = p.Y + ((long)(n * H + y) * W + x) * p.Cout + cout;
-      out[0] = o0;
-      out[p.Cout] = o1;
-      s += o0 + o1;
-      qq += o0 * o0 + o1 * o1;
-    }
+    const int k = r >> 2, j = r & 3;
+    const float2 pr = exp_[r * 64 + lane];
+    const float o0 = keep[r].x + pr.x, o1 = keep[r].y + pr.y;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), yrs, voff[k], soff[j], 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), yrs, voff[k], soff[j] + pix, 0);
+    const bool ok = yk[k] + dyj[j] < H;
+    const float a0 = ok ? o0 : 0.f, a1 = ok ? o1 : 0.f;
+    s += a0 + a1;
+    qq += a0 * a0 + a1 * a1;
   }
   if (p.partials) {
     s += __shfl_xor(s, 32, 64);
@@ -454,10 +477,35 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   }
   __syncthreads();          // the epilogue reuses the window buffers
 
+  // ---------------------------------------------------------------- prefetch for the workgroup that follows on this XCD
+  // A workgroup's prologue waits out one HBM round trip for the first stage of its window (2-3 us under load: the tensor was
+  // written by the previous kernel and is far larger than the caches) and, with one workgroup per CU, nothing runs under it.
+  // The XCD works through its run of tiles in dispatch order, 32 CUs at a time: the workgroup that starts when this one ends
+  // is, three times out of four, tile t + 32 of the run (in-kernel timeline, tools/lab_wino.py full) - and whichever CU of
+  // the XCD gets that tile, it reads through the same L2.  So, with its own loads done, every workgroup touches the first
+  // 128-byte line of each window pixel of tile t + 32 (channels 0-31: stages 0 and 1; one dword load per pixel, the value is
+  // discarded at the end of the epilogue): the line is on its way into the XCD's L2 while this epilogue runs.
+  // Only where the operand carries no activation: the BatchNorm + ReLU build of this kernel sits exactly at 256 registers and
+  // its main loop lost 2-6 % with the prefetch in the program (measured, same session: 5280 -> 5580 cycles per chunk on the
+  // 64-channel layer) - more than the shorter prologue gives back; the plain build gains 1-4 % per call on the 64 / 128-channel
+  // layers (prologue 2.7 -> 1.7 us; profiles/r04_wino_lab.txt).
+  float pfv = 0.f;
+  if (!ACT) {
+    const int nn_ = (int)gridDim.y;
+    const int t2 = bm * nn_ + bn + 32 * ((int)gridDim.x * nn_ >= 256 ? 1 : 0);
+    const int bm2 = t2 / nn_;
+    const int n2 = bm2 / p.bpc, ty2 = (bm2 - n2 * p.bpc) * R;
+    const int ry = tid / W2, rx = tid - ry * W2;
+    const int y = 2 * ty2 - 1 + ry, x = rx - 1;
+    if (bm2 < (int)gridDim.x && bm2 != bm && ry < 2 * R + 2 && y >= 0 && y < H && x >= 0 && x < W)
+      pfv = p.X[((long)(n2 * H + y) * W + x) * C];        // default cache policy: the line is to stay in L2
+  }
+
   // ---------------------------------------------------------------- epilogue
   float* exb = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
   wino_epilogue<XH>(p, acc, exb + (wave & 3) * 2048, exb + ((wave & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw0), mh, nh, li, h,
                     lane, n, ty0, bm, bn);
+  if (!ACT) asm volatile("" :: "v"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved
 }
 
 // ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift)

@@ -36,8 +36,8 @@ VARIANTS["stamps"] = [
     (PRE_LOOP, "  const long long lab_t1 = clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
      "  const long long lab_t2 = clock64();\n  float* exb"),
-    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    o[0] = (float)(lab_t1 - lab_t0); o[1] = (float)(lab_t2 - lab_t1); o[2] = (float)(clock64() - lab_t2); o[3] = (float)nchunk;\n  }\n}\n\n// ACT: the operand"),
 ]
 # in-kernel clock: s_memtime (shader cycles) against s_memrealtime (100 MHz) around the main loop -> [workgroup][wave][4] =
@@ -46,8 +46,8 @@ VARIANTS["clock"] = [
     (PRE_LOOP, "  const long long lab_c0 = clock64(), lab_r0 = wall_clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
      "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n  float* exb"),
-    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    o[0] = (float)(lab_c1 - lab_c0); o[1] = (float)(lab_r1 - lab_r0); o[2] = (float)nchunk; o[3] = 0.f;\n  }\n}\n\n// ACT: the operand"),
 ]
 # workgroup timeline: [workgroup][wave][4] = start, end (100-MHz wall clock, low 24 bits as float), CU key (XCC id << 8 | HW_ID[15:8]), 0
@@ -55,8 +55,8 @@ VARIANTS["timeline"] = [
     ("      out[0] = o0;\n      out[p.Cout] = o1;\n", "      asm volatile(\"\" :: \"v\"(out), \"v\"(o0), \"v\"(o1));\n"),     # no output stores: the stamps go into Y
     ("  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
      "  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
-    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
      "    o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = 0.f;\n  }\n}\n\n// ACT: the operand"),
 ]
@@ -68,17 +68,24 @@ VARIANTS["full"] = [
     (PRE_LOOP, "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
      "  const long long lab_c2 = clock64(), lab_r2 = wall_clock64();\n  float* exb"),
-    ("                    lane, n, ty0, bm, bn);\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  if (lane == 0 && wave < 2) {\n    float* o = p.lab + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 2 + wave) * 4;\n"
+    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
+     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  if (lane == 0 && wave < 2) {\n    float* o = p.lab + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 3 + wave) * 4;\n"
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
      "    if (wave == 0) { o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = (float)nchunk; }\n"
      "    else { o[0] = (float)(lab_r1 & 0xffffff); o[1] = (float)(lab_r2 & 0xffffff); o[2] = (float)(lab_c2 - lab_c1); o[3] = 0.f; }\n  }\n}\n\n// ACT: the operand"),
 ]
 VARIANTS["full"] += [
+    ("#pragma unroll\n  for (int g = 0; g < 4; ++g) B[g] = load_b(0, g);\n  issue_raw(0);\n  stage_scsh();\n  read_scsh(0);\n  put_raw(raw0);\n",
+     "  const long long lab_ra = wall_clock64();\n#pragma unroll\n  for (int g = 0; g < 4; ++g) B[g] = load_b(0, g);\n  issue_raw(0);\n  stage_scsh();\n  read_scsh(0);\n  put_raw(raw0);\n"
+     "  asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");\n  const long long lab_rb = wall_clock64();\n"),
+    ("    else { o[0] = (float)(lab_r1 & 0xffffff);", "    if (wave == 2) { o[0] = (float)(lab_ra & 0xffffff); o[1] = (float)(lab_rb & 0xffffff); o[2] = 0.f; o[3] = 0.f; }\n    else if (wave == 1) { o[0] = (float)(lab_r1 & 0xffffff);"),
+    ("if (lane == 0 && wave < 2) {", "if (lane == 0 && wave < 3) {"),
     ("  float* partials;      // [blocks][2][Cout] or nullptr", "  float* partials;\n  float* lab;"),
     ("p.Y = Y; p.partials = partials;", "p.Y = Y; p.partials = partials; p.lab = g_lab;"),
     ("constexpr int WN_THREADS = 512;\n", "float* g_lab = nullptr;\nconstexpr int WN_THREADS = 512;\n"),
 ]
+NOPF = [("      pfv = p.X[((long)(n2 * H + y) * W + x) * C];        // default cache policy: the line is to stay in L2", "      pfv = 1.f;")]
+VARIANTS["fullnopf"] = VARIANTS["full"] + NOPF
 VARIANTS["mfmaonly"] = VARIANTS["nob"] + VARIANTS["noraw"] + VARIANTS["nod"]
 # no transforms either: what the bare MFMA stream (plus barrier and loop control) takes
 NOTRANS = [("    wino_htrans_ip(t1, v1);\n", "#pragma unroll\n    for (int j = 0; j < 4; ++j) v1[j] = t1[j];\n"),
@@ -111,7 +118,7 @@ def build(name):
         src = src.replace(old, new)
     os.makedirs(LAB, exist_ok=True)
     cpp = os.path.join(LAB, f"conv_wino_{name}.hip")
-    if name == "full":
+    if name in ("full", "fullnopf"):
         src += '\nextern "C" void acvae_lab_set(float* p) { g_lab = p; }\n'
     open(cpp, "w").write(src.replace('#include "../../include/acvae_hip.h"', f'#include "{ROOT}/include/acvae_hip.h"'))
     obj = os.path.join(LAB, f"conv_wino_{name}.o")
@@ -167,10 +174,10 @@ def time_one():
                   f"workgroup {sum(durs) / len(durs):.1f} us (max {max(durs):.1f}); gap between two on one CU {sum(gaps) / max(1, len(gaps)):.2f} us (max {max(gaps or [0]):.1f}); "
                   f"last end {float(en.max()):.1f} us; main loop {float(t[:, 3].floor().mean()) * 0.01:.1f} us real per workgroup [after {warm} warm-up launches]")
           continue
-        if os.environ.get("ACVAE_DEV_LIB", "").endswith("_full.so"):
+        if os.environ.get("ACVAE_DEV_LIB", "").endswith(("_full.so", "_fullnopf.so")):
             import ctypes
             nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
-            labbuf = torch.zeros(nwg, 2, 4, device="cuda")
+            labbuf = torch.zeros(nwg, 3, 4, device="cuda")
             raw = ctypes.CDLL(os.environ["ACVAE_DEV_LIB"])
             raw.acvae_lab_set.argtypes = [ctypes.c_void_p]; raw.acvae_lab_set(labbuf.data_ptr())
             for kind in ("dgrad", "fwd_act"):
@@ -195,8 +202,21 @@ def time_one():
                 counts = [len(v) for v in per.values()]
                 print(f"{Cin}->{Cout}@{W} {kind}: call {a.elapsed_time(b) * 50:.0f} us (mean of 20); {nwg} workgroups on {len(cus)} CUs ({min(counts)}..{max(counts)} per CU); "
                       f"first start..last end {float(en.max()):.1f} us; workgroup {float((en - st).mean()):.1f} us = prologue {float((l0 - st).mean()):.1f} + main loop {float((l1 - l0).mean()):.1f} "
-                      f"+ epilogue {float((en - l1).mean()):.1f}; main loop {float(cyc.mean()):.0f} cycles = {float(cyc.mean()) / nch:.0f} per chunk, clock {float((cyc / ((l1 - l0) * 1e3)).mean()):.3f} GHz; "
+                      f"+ epilogue {float((en - l1).mean()):.1f} [prologue: addresses {float(((t[:, 2, 0] - t0) * 0.01 - st).mean()):.2f}, first stage loaded + staged {float(((t[:, 2, 1] - t[:, 2, 0]) * 0.01).mean()):.2f}, barrier + reads + transform {float((l0 - (t[:, 2, 1] - t0) * 0.01).mean()):.2f}]; main loop {float(cyc.mean()):.0f} cycles = {float(cyc.mean()) / nch:.0f} per chunk, clock {float((cyc / ((l1 - l0) * 1e3)).mean()):.3f} GHz; "
                       f"gap between two on one CU {sum(gaps) / max(1, len(gaps)):.2f} us (max {max(gaps or [0]):.1f}); start spread of the first round {sorted(st.tolist())[min(len(cus), nwg) - 1]:.1f} us")
+                # which workgroup follows which on a CU: distance in dispatch order inside the XCD (block id >> 3)
+                from collections import Counter
+                byc = {}
+                for i in range(nwg):
+                    byc.setdefault(int(cu[i]), []).append((float(st[i]), i))
+                dist = Counter()
+                for v in byc.values():
+                    v.sort()
+                    for (s0, i0), (s1, i1) in zip(v, v[1:]):
+                        dist[(i1 >> 3) - (i0 >> 3)] += 1
+                tot = sum(dist.values())
+                print("    successor on the same CU, distance in the XCD's dispatch order: " +
+                      ", ".join(f"{d}: {c / tot:.0%}" for d, c in dist.most_common(6)))
             continue
         if os.environ.get("ACVAE_DEV_LIB", "").endswith("_clock.so"):
             for _ in range(300):                      # the clock settles after a second or two of back-to-back launches
