@@ -73,6 +73,8 @@ int bn_finalize(const float* partials, int P, int C, double count, const float* 
                 float* running_mean, float* running_var, int64_t* nbt, int training, float* scale, float* shift,
                 float* mean, float* invstd, double* dpart, hipStream_t st);
 long colsum_scratch_doubles(int width);
+// zero the tickets at the head of a dpart scratch: once per composite call, in front of its first column sum / bn_finalize
+int colsum_tickets_reset(double* dpart, hipStream_t st);
 // deterministic column sums of x[P][width] (ld == width): out[i] = sum_p x[p][i]; entries >= split (if > 0) go to out2
 int colsum2(const float* x, int P, int width, double* dpart, float* out, float* out2, int split, hipStream_t st);
 int conv1_first_blocks(int N, int T);

@@ -600,15 +600,68 @@ __global__ __launch_bounds__(256) void bn0_stats_kernel(const float* __restrict_
   }
 }
 
-// Column sums of a [P][width] fp32 partial matrix in two fixed-order stages (deterministic):
-// stage 1: grid (width/64, R) blocks, block r sums rows p = r, r+R, ... in fp64 -> dpart[r][width].
+// Column sums of a [P][width] fp32 partial matrix in two fixed-order stages (deterministic) inside ONE launch:
+// stage 1: grid (width/64, R) blocks, block r sums rows p = r, r+R, ... in fp64 -> dpart[r][width];
+// stage 2: the block that arrives LAST at its column block's ticket sums the R group sums in group order and finishes
+// (plain sums, or the BatchNorm statistics -> scale / shift / running buffers).  Round 4: the second stage used to be a
+// launch of its own - 26 colsum_stage2 + 9 bn_finalize launches per training step, each a kernel boundary and 6-10 us of
+// one-wave latency on the critical path between two convolutions.
+// Tickets: CS_TICKETS words at the head of the caller's `dpart` scratch, zero between launches (the last arriver resets its
+// word); a composite driver zeroes them ONCE per call (colsum_tickets_reset) - calls that may run side by side (two streams)
+// have a dpart each.
 constexpr int CS_R = 64;          // most row groups of stage 1 (scratch: CS_R x width doubles)
+constexpr int CS_TICKETS = 128;   // ticket words (64 doubles) in front of the group sums: column blocks of widths up to 8192
 // Row groups for P partial rows: 16 up to 1024 rows, 32 up to 4096, 64 beyond - with 16 groups the 8000-row partials of the
 // 64-channel layers were read by 32 workgroups (42 us for 4 MB); the second stage reads the groups' sums.
 inline int cs_groups(int P) { return P < 1 ? 1 : P < 16 ? P : P <= 1024 ? 16 : P <= 4096 ? 32 : CS_R; }
-__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ partials, int P, int width,
-                                                            double* __restrict__ dpart) {
+
+struct BnFinalizeArgs {
+  double count;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  int64_t* nbt;
+  float *scale, *shift, *mean_out, *invstd_out;
+};
+
+// Group sums are handed over WITHOUT fences (a release fence writes back the XCD's whole L2 and an acquire invalidates the
+// CU's L1: the fenced form of this kernel took 20 us where the two launches it replaced took 14): every group sum is stored
+// write-through (agent-scope atomic store, `sc1`) and read back by the last arriver with agent-scope loads (`sc1`: served by
+// L2 / memory, never by the reader's L1); the storing wave drains its stores (s_waitcnt vmcnt(0)) in front of the barrier
+// behind which ONE lane adds to the ticket (MI355X_MICROARCH.md, hand-offs measured with `sc1` loads in place of the acquire,
+// first row: one lane signals for the workgroup, the workgroup whose add returned last reads).
+__device__ __forceinline__ void cs_store(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double cs_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+// true in every thread of the block that arrived last at `ticket` (which expects `expect` arrivals); the ticket is zero again
+__device__ __forceinline__ bool cs_last_arriver(unsigned* ticket, unsigned expect, int* s_last) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == expect - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = last;
+  }
+  __syncthreads();
+  return *s_last != 0;
+}
+
+// FINALIZE = false: out[i] = sum_r dsum[r][i]; entries >= split go to out2 (bn: dbeta | dgamma).
+// FINALIZE = true (width = 2C = sums | sums of squares): batch mean / biased var, scale / shift for the fused activation,
+// running stats (momentum 0.1, unbiased var: torch BatchNorm2d); one ticket per 64 channels, 2R arrivals.
+template <bool FINALIZE>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partials, int P, int width, double* __restrict__ dpart,
+                                                     float* __restrict__ out, float* __restrict__ out2, int split,
+                                                     BnFinalizeArgs bn) {
   __shared__ double red[4][64];
+  __shared__ int s_last;
+  unsigned* tickets = reinterpret_cast<unsigned*>(dpart);
+  double* dsum = dpart + CS_TICKETS / 2;
   const int il = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + il;
   const int R = gridDim.y;
@@ -617,54 +670,64 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
     for (int p = blockIdx.y + g * R; p < P; p += 4 * R) a += (double)partials[(long)p * width + i];
   red[g][il] = a;
   __syncthreads();
-  if (g == 0 && i < width) dpart[(long)blockIdx.y * width + i] = red[0][il] + red[1][il] + red[2][il] + red[3][il];
-}
-
-// dpart [R][2][C] -> batch mean / biased var, scale/shift for the fused act, running stats
-// (momentum 0.1, unbiased var: torch BatchNorm2d).  eval mode: scale/shift from the running stats.
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ dpart, int R, int C, double count,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* running_mean,
-                                                         float* running_var, int64_t* nbt, int training,
-                                                         float* __restrict__ scale, float* __restrict__ shift,
-                                                         float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  if (training) {
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < R; ++r) {
-      s += dpart[(long)r * 2 * C + c];
-      q += dpart[(long)r * 2 * C + C + c];
+  if (g == 0 && i < width) cs_store(dsum + (long)blockIdx.y * width + i, red[0][il] + red[1][il] + red[2][il] + red[3][il]);
+  if (!FINALIZE) {
+    if (!cs_last_arriver(tickets + blockIdx.x, (unsigned)R, &s_last)) return;
+    if (g != 0 || i >= width) return;
+    double t = 0.0;
+    for (int r0 = 0; r0 < R; r0 += 8) {          // eight loads in flight; the additions stay in group order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r0 + u < R ? cs_load(dsum + (long)(r0 + u) * width + i) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + u < R) t += v[u];
     }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
+    if (split > 0 && i >= split) out2[i - split] = (float)t;
+    else out[i] = (float)t;
+  } else {
+    const int C = width >> 1, cb = C >> 6;                 // C is a multiple of 64 (checked by the launcher)
+    const int xc = blockIdx.x % cb;
+    if (!cs_last_arriver(tickets + xc, (unsigned)(2 * R), &s_last)) return;
+    if (g != 0) return;
+    const int c = xc * 64 + il;
+    double sm = 0.0, q = 0.0;
+    for (int r0 = 0; r0 < R; r0 += 8) {          // sixteen loads in flight; the additions stay in group order
+      double v[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = r0 + u < R ? cs_load(dsum + (long)(r0 + u) * width + c) : 0.0;
+        w[u] = r0 + u < R ? cs_load(dsum + (long)(r0 + u) * width + C + c) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + u < R) { sm += v[u]; q += w[u]; }
+    }
+    const double mean = sm / bn.count;
+    double var = q / bn.count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + 1e-5));
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
-    mean_out[c] = (float)mean; invstd_out[c] = invstd;
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)mean;
-    running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
-    if (c == 0 && nbt) nbt[0] += 1;
-  } else {
-    const float invstd = 1.0f / sqrtf(running_var[c] + 1e-5f);
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc; shift[c] = beta[c] - running_mean[c] * sc;
-    mean_out[c] = running_mean[c]; invstd_out[c] = invstd;
+    const float sc = bn.gamma[c] * invstd;
+    bn.scale[c] = sc; bn.shift[c] = bn.beta[c] - (float)mean * sc;
+    bn.mean_out[c] = (float)mean; bn.invstd_out[c] = invstd;
+    const double unbiased = bn.count > 1.0 ? var * bn.count / (bn.count - 1.0) : var;
+    bn.running_mean[c] = 0.9f * bn.running_mean[c] + 0.1f * (float)mean;
+    bn.running_var[c] = 0.9f * bn.running_var[c] + 0.1f * (float)unbiased;
+    if (c == 0 && bn.nbt) bn.nbt[0] += 1;
   }
 }
 
-// stage 2 for plain sums: out[i] = sum_r dpart[r][i]; entries >= split go to out2 (bn: dbeta | dgamma)
-__global__ __launch_bounds__(64) void colsum_stage2_kernel(const double* __restrict__ dpart, int R, int width,
-                                                           float* __restrict__ out, float* __restrict__ out2,
-                                                           int split) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= width) return;
-  double a = 0.0;
-  for (int r = 0; r < R; ++r) a += dpart[(long)r * width + i];
-  if (split > 0 && i >= split) out2[i - split] = (float)a;
-  else out[i] = (float)a;
+// evaluation mode: scale / shift from the running statistics (no batch statistics, nothing to reduce)
+__global__ __launch_bounds__(64) void bn_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                     float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(running_var[c] + 1e-5f);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc; shift[c] = beta[c] - running_mean[c] * sc;
+  mean_out[c] = running_mean[c]; invstd_out[c] = invstd;
 }
 
 // ------------------------------------------------------------------ first conv (Cin = 1), direct
@@ -1437,24 +1500,31 @@ int bn0_partials_rows(long rows) { return cdiv(rows, 256); }
 
 int colsum2(const float* partials, int P, int width, double* dpart, float* out, float* out2, int split,
             hipStream_t st) {
+  if (cdiv(width, 64) > CS_TICKETS) return ACVAE_EUNSUPPORTED;
   const int R = cs_groups(P);
-  hipLaunchKernelGGL(colsum_stage1_kernel, dim3(cdiv(width, 64), R), dim3(256), 0, st, partials, P, width, dpart);
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(width, 64)), dim3(64), 0, st, dpart, R, width, out, out2, split);
+  hipLaunchKernelGGL(colsum_kernel<false>, dim3(cdiv(width, 64), R), dim3(256), 0, st, partials, P, width, dpart, out, out2, split,
+                     BnFinalizeArgs{});
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
-long colsum_scratch_doubles(int width) { return (long)CS_R * width; }
+long colsum_scratch_doubles(int width) { return CS_TICKETS / 2 + (long)CS_R * width; }
+// the tickets at the head of a dpart scratch start at zero: once per composite call, in front of its first column sum
+int colsum_tickets_reset(double* dpart, hipStream_t st) {
+  return hipMemsetAsync(dpart, 0, CS_TICKETS * sizeof(unsigned), st) == hipSuccess ? ACVAE_OK : (int)hipGetLastError();
+}
 
 int bn_finalize(const float* partials, int P, int C, double count, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, int64_t* nbt, int training, float* scale, float* shift,
                 float* mean, float* invstd, double* dpart, hipStream_t st) {
-  int R = 0;
   if (training) {
-    R = cs_groups(P);
-    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(cdiv(2 * C, 64), R), dim3(256), 0, st, partials, P, 2 * C, dpart);
+    if (C % 64 != 0 || cdiv(2 * C, 64) > CS_TICKETS) return ACVAE_EUNSUPPORTED;
+    const int R = cs_groups(P);
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3(2 * C / 64, R), dim3(256), 0, st, partials, P, 2 * C, dpart, nullptr, nullptr, 0,
+                       BnFinalizeArgs{count, gamma, beta, running_mean, running_var, nbt, scale, shift, mean, invstd});
+  } else {
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, C, gamma, beta, running_mean, running_var, scale,
+                       shift, mean, invstd);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, dpart, R, C, count, gamma, beta,
-                     running_mean, running_var, nbt, training, scale, shift, mean, invstd);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

@@ -947,44 +947,59 @@ __device__ __forceinline__ void wino_wgrad_entry(const WinoWgradParams& p, float
 WINO_WGRAD_KERNEL(1) WINO_WGRAD_KERNEL(2) WINO_WGRAD_KERNEL(3) WINO_WGRAD_KERNEL(4)
 #undef WINO_WGRAD_KERNEL
 
-// Slab reduction in two steps.  1: dU[pos][ci][co] = sum_z slab[z][pos][ci][co] (z in fixed order, accumulated in double), one
-// thread per element so that even the 64 x 64 layer (Z = 256) spreads over 65536 threads; the sum overwrites slab z = 0,
-// an element only its own thread touches.  2: dW[co][ci][a][b] = sum_{xi,nu} G[xi][a] G[nu][b] dU[xi*4+nu][ci][co].
-__global__ void wino_wgrad_zsum_kernel(float* __restrict__ slab, int Z, long per_z) {
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_z; idx += (long)gridDim.x * blockDim.x) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int z = 0;
-    for (; z + 4 <= Z; z += 4) {          // four loads in flight; the order of the additions is fixed all the same
-      const float a = slab[(long)z * per_z + idx], b = slab[(long)(z + 1) * per_z + idx];
-      const float c = slab[(long)(z + 2) * per_z + idx], d = slab[(long)(z + 3) * per_z + idx];
-      s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+// Slab reduction, one launch (round 4; it was two - the z sum and the fold - i.e. seven more kernel boundaries per step):
+//   dU[pos][ci][co] = sum_z slab[z][pos][ci][co]      z in fixed order, four partial sums in double, rounded to fp32 once
+//   dW[co][ci][a][b] = sum_{xi,nu} G[xi][a] G[nu][b] dU[xi*4+nu][ci][co]      in double, from the rounded dU
+// - the same arithmetic as the two kernels it replaces, bit for bit.  A block of 256 threads owns PAIRS (ci, co) pairs and all
+// 16 positions: thread = (position group, pair); the 16 z sums of a pair meet in LDS and one thread per pair folds them.
+// PAIRS = 16: 64-byte runs per position, 16 threads per pair - the 64 x 64 layer (Z = 256, 67 MB of slabs) still spreads over
+// 256 blocks; PAIRS = 64: 256-byte runs, four positions per thread, for the wide layers.
+template <int PAIRS>
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, int Z, int Cout,
+                                                                int Cin) {
+  constexpr int PG = 256 / PAIRS;            // position groups among the threads: 16 or 4
+  constexpr int PPT = 16 / PG;               // positions per thread: 1 or 4
+  __shared__ float su[16][PAIRS];
+  const long total = (long)Cin * Cout, per_z = 16 * total;
+  const int lp = threadIdx.x % PAIRS, pg = threadIdx.x / PAIRS;
+  const long pair = (long)blockIdx.x * PAIRS + lp;
+  if (pair < total) {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int pos = pg * PPT + k;
+      const long idx = (long)pos * total + pair;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int z = 0;
+      for (; z + 4 <= Z; z += 4) {          // four loads in flight; the order of the additions is fixed all the same
+        const float a = slab[(long)z * per_z + idx], b = slab[(long)(z + 1) * per_z + idx];
+        const float c = slab[(long)(z + 2) * per_z + idx], d = slab[(long)(z + 3) * per_z + idx];
+        s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+      }
+      for (; z < Z; ++z) s0 += (double)slab[(long)z * per_z + idx];
+      su[pos][lp] = (float)((s0 + s1) + (s2 + s3));
     }
-    for (; z < Z; ++z) s0 += (double)slab[(long)z * per_z + idx];
-    slab[idx] = (float)((s0 + s1) + (s2 + s3));
   }
-}
-__global__ void wino_wgrad_fold_kernel(const float* __restrict__ dU, float* __restrict__ dW, int Cout, int Cin) {
-  const long total = (long)Cin * Cout;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int co = (int)(idx % Cout), ci = (int)(idx / Cout);
-    double u[16];
+  __syncthreads();
+  if (pg != 0 || pair >= total) return;
+  // pair index = ci * Cout + co (the slab's [ci][co] order)
+  const int co = (int)(pair % Cout), ci = (int)(pair / Cout);
+  double u[16];
 #pragma unroll
-    for (int pos = 0; pos < 16; ++pos) u[pos] = (double)dU[((long)pos * Cin + ci) * Cout + co];
-    // t[a][nu] = sum_xi G[xi][a] u[xi][nu];  G^T rows: a=0: (1, .5, .5, 0)  a=1: (0, .5, -.5, 0)  a=2: (0, .5, .5, 1)
-    double t[3][4];
+  for (int pos = 0; pos < 16; ++pos) u[pos] = (double)su[pos][lp];
+  // t[a][nu] = sum_xi G[xi][a] u[xi][nu];  G^T rows: a=0: (1, .5, .5, 0)  a=1: (0, .5, -.5, 0)  a=2: (0, .5, .5, 1)
+  double t[3][4];
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      t[0][nu] = u[0 * 4 + nu] + 0.5 * (u[1 * 4 + nu] + u[2 * 4 + nu]);
-      t[1][nu] = 0.5 * (u[1 * 4 + nu] - u[2 * 4 + nu]);
-      t[2][nu] = 0.5 * (u[1 * 4 + nu] + u[2 * 4 + nu]) + u[3 * 4 + nu];
-    }
-    float* out = dW + ((long)co * Cin + ci) * 9;
+  for (int nu = 0; nu < 4; ++nu) {
+    t[0][nu] = u[0 * 4 + nu] + 0.5 * (u[1 * 4 + nu] + u[2 * 4 + nu]);
+    t[1][nu] = 0.5 * (u[1 * 4 + nu] - u[2 * 4 + nu]);
+    t[2][nu] = 0.5 * (u[1 * 4 + nu] + u[2 * 4 + nu]) + u[3 * 4 + nu];
+  }
+  float* out = dW + ((long)co * Cin + ci) * 9;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      out[a * 3 + 0] = (float)(t[a][0] + 0.5 * (t[a][1] + t[a][2]));
-      out[a * 3 + 1] = (float)(0.5 * (t[a][1] - t[a][2]));
-      out[a * 3 + 2] = (float)(0.5 * (t[a][1] + t[a][2]) + t[a][3]);
-    }
+  for (int a = 0; a < 3; ++a) {
+    out[a * 3 + 0] = (float)(t[a][0] + 0.5 * (t[a][1] + t[a][2]));
+    out[a * 3 + 1] = (float)(0.5 * (t[a][1] - t[a][2]));
+    out[a * 3 + 2] = (float)(0.5 * (t[a][1] + t[a][2]) + t[a][3]);
   }
 }
 
@@ -1042,11 +1057,11 @@ int conv3x3_wino_wgrad(const float* dY, const float* X, const float* scale, cons
     default: hipLaunchKernelGGL(conv_wino_wgrad_kernel_s4, wgrid, dim3(512), 0, st, p); break;
   }
   prof_end(ACVAE_PROF_CONV_WGRAD, st);
-  const long total = (long)Cin * Cout, per_z = 16 * total;
-  hipLaunchKernelGGL(wino_wgrad_zsum_kernel, dim3(cdiv(per_z, 256) > 8192 ? 8192 : cdiv(per_z, 256)), dim3(256), 0, st, slab, g.Z,
-                     per_z);
-  hipLaunchKernelGGL(wino_wgrad_fold_kernel, dim3(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256)), dim3(256), 0, st, slab,
-                     dW_oihw, Cout, Cin);
+  const long total = (long)Cin * Cout;
+  if (total < 16 * 1024)        // few pairs (64 x 64, 64 x 128): 16 per block so that the reduction still covers the chip
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel<16>, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, st, slab, dW_oihw, g.Z, Cout, Cin);
+  else
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel<64>, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, slab, dW_oihw, g.Z, Cout, Cin);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

@@ -320,6 +320,7 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   const int R = N * Tc;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
   double* dpart = (double*)(sc + L.dpart);
+  ACVAE_TRY(acvae::colsum_tickets_reset(dpart, st.s));
   const int64_t* words = (const int64_t*)(sv + L.words);
   float* X = sv + L.x;
   float* hid = sv + L.hidden;
@@ -706,6 +707,8 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   TnWs tn_p{sc + L.tn_p, L.tn_p_floats * 4};
   double* dpart = (double*)(sc + L.dpart);
   double* dpart_p = (double*)(sc + L.dpart_p);
+  ACVAE_TRY(acvae::colsum_tickets_reset(dpart, st.s));        // in front of the fork: both chains' column sums start from zeroed tickets
+  ACVAE_TRY(acvae::colsum_tickets_reset(dpart_p, st.s));
   const int64_t* words = (const int64_t*)(sv + L.words);
   float* mem = sv + L.mem;
   float* rnn_d = sv + L.rnn_d;
@@ -785,10 +788,14 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   const float* gru_save = sv + L.gru_save;
   const float* hprev_d = sv + L.hprev_d;
   const float* qd = sv + L.qd;
-  ACVAE_TRY(zero(dencproj, (long)N * S * A, st));
-  ACVAE_TRY(zero(dvpart, (long)N * A, st));
-  ACVAE_TRY(zero(dmem, (long)N * S * E, st));
-  ACVAE_TRY(zero(dh, (long)N * H, st));
+  // accumulators of the per-step BPTT (the persistent launch writes all four itself: four memsets fewer in front of it)
+  auto dec_begin = [&]() -> int {
+    ACVAE_TRY(zero(dencproj, (long)N * S * A, st));
+    ACVAE_TRY(zero(dvpart, (long)N * A, st));
+    ACVAE_TRY(zero(dmem, (long)N * S * E, st));
+    ACVAE_TRY(zero(dh, (long)N * H, st));
+    return ACVAE_OK;
+  };
   float* drnn = sc + L.drnn;
   float* dz_dec = sc + L.dz_dec;
   auto dec_bptt = [&](int t) -> int {
@@ -922,6 +929,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     return acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp);
   };
   if (prior_feeds_decoder) {   // the prior BPTT needs the decoder's dz: back to back
+    ACVAE_TRY(dec_begin());
     for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(dec_bptt(t));
     ACVAE_TRY(dec_memgrad());
     ACVAE_TRY(dec_params(st, tn, dpart));
@@ -956,6 +964,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
       ACVAE_TRY(prior_params());
     }
   } else {                     // independent chains: feed both queues step by step
+    ACVAE_TRY(dec_begin());
     ACVAE_TRY(prior_begin());
     for (int t = Tc - 1; t >= 0; --t) {
       ACVAE_TRY(dec_bptt(t));

@@ -243,6 +243,7 @@ int encoder_fwd_t(const void* const* params, const float* feats, float* audio_em
   // bn0 over the mel axis (encoder.py:679-681)
   BnPtrs b0 = bn_at(saved, L, 0);
   int nparts = 0;
+  ACVAE_TRY(acvae::colsum_tickets_reset(dpart, st));        // the one memset of this call: every reduction's last-arriver tickets
   if (training) ACVAE_TRY(acvae::bn0_stats(feats, partials, (long)N * T, F, &nparts, st));
   ACVAE_TRY(acvae::bn_finalize(partials, nparts, 64, (double)N * T, P(p_bn0(0)), P(p_bn0(1)), P(p_bn0(2)), P(p_bn0(3)),
                                (int64_t*)params[p_bn0(4)], training, b0.scale, b0.shift, b0.mean, b0.invstd, dpart, st));
@@ -363,6 +364,7 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
   float* bnpart = scratch + L.s_bnpart;
   double* dpart = (double*)(scratch + L.s_dpart);
   const int S = L.H[0], Fp = L.W[0];
+  ACVAE_TRY(acvae::colsum_tickets_reset(dpart, st));        // the one memset of this call: every reduction's last-arriver tickets
   ACVAE_TRY(acvae::freq_mean_bwd<TA>(d_audio_embeds, dp_cur, (long)N * S, Fp, L.Cemb, st));
   for (int b = L.nb; b >= 1; --b) {
     const int H = L.H[b], W = L.W[b], C = kChan[b], Cin = kChan[b - 1];

@@ -72,6 +72,7 @@ extern "C" int acvae_conv3x3_fwd(const float* X, const float* W_oihw, const floa
     ACVAE_TRY(acvae::conv3x3_igemm(X, in_scale, in_shift, ws + L.wp, Y, partials, N, H, W, Cin, Cout, st));
     nparts = acvae::conv_partials_rows(N, H, W);
   }
+  if (bn_out) ACVAE_TRY(acvae::colsum_tickets_reset((double*)(ws + L.dpart), st));
   if (bn_out)
     ACVAE_TRY(acvae::bn_finalize(partials, nparts, Cout, (double)N * H * W, gamma, beta, running_mean, running_var,
                                  num_batches_tracked, training, bn_out, bn_out + Cout, bn_out + 2 * Cout,
@@ -121,6 +122,7 @@ extern "C" int acvae_conv3x3_fwd_wino(const float* X, const float* W_oihw, const
   float* partials = (bn_out && training) ? ws + L.partials : nullptr;
   ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, ws + L.wp, Cout, Cin, false, st));
   ACVAE_TRY(acvae::conv3x3_wino(X, in_scale, in_shift, ws + L.wp, Y, partials, N, H, W, Cin, Cout, st));
+  if (bn_out) ACVAE_TRY(acvae::colsum_tickets_reset((double*)(ws + L.dpart), st));
   if (bn_out)
     ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_wino_partials_rows(N, H, W), Cout, (double)N * H * W, gamma, beta,
                                  running_mean, running_var, num_batches_tracked, training, bn_out, bn_out + Cout,
@@ -172,6 +174,7 @@ extern "C" int acvae_conv3x3_fwd_bf16(const void* X, const float* W_oihw, const 
   bf16_t* wp = (bf16_t*)(ws + L.wp);
   ACVAE_TRY(acvae::repack_weights<bf16_t>(W_oihw, wp, nullptr, Cout, Cin, st));
   ACVAE_TRY(acvae::conv3x3_igemm_bf16((const bf16_t*)X, in_scale, in_shift, wp, (bf16_t*)Y, partials, N, H, W, Cin, Cout, st));
+  if (bn_out) ACVAE_TRY(acvae::colsum_tickets_reset((double*)(ws + L.dpart), st));
   if (bn_out)
     ACVAE_TRY(acvae::bn_finalize(partials, acvae::conv_partials_rows(N, H, W), Cout, (double)N * H * W, gamma, beta,
                                  running_mean, running_var, num_batches_tracked, training, bn_out, bn_out + Cout,
@@ -212,6 +215,7 @@ extern "C" int acvae_conv1_first_bwd(const float* x, const float* bn0, const flo
   if (ws_bytes < L.total * 4) return ACVAE_EWORKSPACE;
   float* ws = (float*)ws_v;
   const long nb = acvae::conv1_first_blocks(N, T);
+  ACVAE_TRY(acvae::colsum_tickets_reset((double*)(ws + L.dpart), (hipStream_t)stream));
   return acvae::conv1_first_bwd(x, bn0, bn0 + 64, bn0 + 128, bn0 + 192, W1_oihw, dY, ws + L.slab, ws + L.slab + nb * 576,
                                 dW1, dgamma0, dbeta0, (double*)(ws + L.dpart), N, T, F, (hipStream_t)stream);
 }
@@ -235,6 +239,7 @@ extern "C" int acvae_bn_mel_fwd(const float* x, const float* gamma, const float*
   float* ws = (float*)ws_v;
   int nparts = 0;
   if (training) ACVAE_TRY(acvae::bn0_stats(x, ws, rows, F, &nparts, st));
+  ACVAE_TRY(acvae::colsum_tickets_reset((double*)(ws + part), st));
   return acvae::bn_finalize(ws, nparts, F, (double)rows, gamma, beta, running_mean, running_var, num_batches_tracked,
                             training, bn_out, bn_out + F, bn_out + 2 * F, bn_out + 3 * F, (double*)(ws + part), st);
 }
@@ -257,6 +262,7 @@ extern "C" int acvae_bn_relu_bwd(const float* Y, const float* dO, int upstream, 
   const long part = al64((long)acvae::bn_bwd_blocks(N, H, W, C) * 2 * C);
   const long p0 = al64((long)acvae::bn0_partials_rows((long)N * H) * 128);
   DropoutSpec d{p_drop, keep_mask, seed, (uint32_t)site};
+  ACVAE_TRY(acvae::colsum_tickets_reset((double*)(ws + (part > p0 ? part : p0)), (hipStream_t)stream));
   // sum_g (= dbeta) and sum_gy (= dgamma) are also inputs of the apply pass: written first, then read
   return acvae::bn_bwd(Y, dO, upstream, bn, bn + C, bn + 2 * C, bn + 3 * C, ws, dbeta, dgamma, dY,
                        (double*)(ws + (part > p0 ? part : p0)), N, H, W, C, d, (hipStream_t)stream, training != 0);
@@ -345,5 +351,6 @@ extern "C" int64_t acvae_colsum_workspace_bytes(int cols) {
 extern "C" int acvae_colsum(const float* x, int rows, int cols, float* out, void* ws, int64_t ws_bytes, void* stream) {
   if (!x || !out || !ws || rows <= 0 || cols <= 0) return ACVAE_EINVAL;
   if (ws_bytes < acvae_colsum_workspace_bytes(cols)) return ACVAE_EWORKSPACE;
+  ACVAE_TRY(acvae::colsum_tickets_reset((double*)ws, (hipStream_t)stream));
   return acvae::colsum2(x, rows, cols, (double*)ws, out, nullptr, 0, (hipStream_t)stream);
 }

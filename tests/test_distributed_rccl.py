@@ -66,7 +66,7 @@ def _step(ts, model, shard):
     return parts
 
 
-def _worker(rank, world, port, backend, q):
+def _worker(rank, world, port, backend, q, precision="f32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(rank if backend == "nccl" else 0)
     dist.init_process_group(backend, rank=rank, world_size=world)
@@ -75,11 +75,25 @@ def _worker(rank, world, port, backend, q):
 
     # (1)-(3): training-mode BatchNorm, bucketed exchange announced from inside the backward
     model = _model()
-    ts = TrainStep(model, V)
+    ts = TrainStep(model, V, precision=precision)
     parts = _step(ts, model, shard)
     issued = list(ts.exchange.issued)
     flat_bucketed = ts.flat_p.cpu().numpy().copy()
     grads_avg = (ts.flat_g[:ts.n_active] * (1.0 / world)).cpu().numpy().copy()
+    if precision == "bf16":
+        # BASELINE configs[2] (bf16 forward / fp32 loss, data parallel): the exchange is the same fp32 flat buffer whatever the
+        # conv stack stores - the collective sequence and the bitwise equalities (1)-(3); (4) / (5) are precision-independent
+        model2 = _model()
+        ts2 = TrainStep(model2, V, precision=precision)
+        ts2.exchange = FlatGradExchange(ts2.flat_g, [ts2.n_active], None, max_chunk=1 << 40)
+        model2._grad_ready_cb = model2.encoder._grad_ready_cb = None
+        _step(ts2, model2, shard)
+        flat_single = ts2.flat_p.cpu().numpy().copy()
+        assert model.encoder.compute_dtype == "bf16" and np.isfinite(float(parts["loss"]))
+        q.put((rank, issued, flat_bucketed, flat_single, float(parts["loss"]), grads_avg, None, None, None))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     # (5) the BatchNorm-buffer broadcast issued at the end of step() is joined by whoever reads the buffers next:
     # state_dict() right after the last training step (no explicit ts.sync_buffers()) sees rank 0's statistics
@@ -125,11 +139,11 @@ def _worker(rank, world, port, backend, q):
     dist.destroy_process_group()
 
 
-def _run(backend):
+def _run(backend, precision="f32"):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, backend, q, precision)) for r in range(world)]
     for p in ps:
         p.start()
     res = {}
@@ -141,8 +155,9 @@ def _run(backend):
         assert p.exitcode == 0
     issued0, flat0, single0, loss0, gavg0, geval0, gcat, bn0 = res[0]
     issued1, flat1, single1, loss1, gavg1, geval1, _, bn1 = res[1]
-    # 5. rank 1 read rank 0's running statistics (the shards differ, so the local ones would not be equal)
-    assert np.array_equal(bn0, bn1) and float(np.abs(bn0).max()) > 0
+    if precision == "f32":
+        # 5. rank 1 read rank 0's running statistics (the shards differ, so the local ones would not be equal)
+        assert np.array_equal(bn0, bn1) and float(np.abs(bn0).max()) > 0
     # 1. same collective sequence everywhere; decode-written bucket first, shallow encoder bucket last
     assert issued0 == issued1, (issued0, issued1)
     buckets = [b for b, _ in issued0]
@@ -151,6 +166,8 @@ def _run(backend):
     assert np.array_equal(flat0, flat1), "ranks diverged after the averaged step"
     assert np.array_equal(flat0, single0) and np.array_equal(flat1, single1), "bucketed != single all-reduce"
     assert np.array_equal(gavg0, gavg1) and loss0 != loss1
+    if precision != "f32":
+        return
     # 4. evaluation-mode BatchNorm: averaged shards == concatenated batch
     assert np.array_equal(geval0, geval1)
     scale = max(float(np.abs(gcat).max()), 1e-6)
@@ -162,6 +179,16 @@ def test_two_ranks_one_gpu_gloo():
     _run("gloo")
 
 
+def test_two_ranks_one_gpu_gloo_bf16():
+    """BASELINE configs[2] as written: bf16 forward / fp32 loss UNDER data parallelism (missing 4)."""
+    _run("gloo", "bf16")
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: two GPUs")
 def test_two_ranks_rccl():
     _run("nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: two GPUs")
+def test_two_ranks_rccl_bf16():
+    _run("nccl", "bf16")

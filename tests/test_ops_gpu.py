@@ -301,9 +301,6 @@ def test_tanh_of_the_attention_scores_elementwise():
     assert bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
     small = xs.abs() < 1e-4
     assert float(err[small].max()) <= 2e-7, float(err[small].max())     # exp2's and rcp's ulp each weigh 6e-8 at e = 1
-    # odd symmetry to rounding and monotone where fp32 can tell neighbours apart
-    sym = float((y[:400001] + y[:400001].flip(0)).abs().max())
-    assert sym <= 4.5e-7, sym
 
 
 def test_loss_assembly_equals_the_tensor_expression():
