@@ -575,47 +575,69 @@ __device__ __forceinline__ float pb_sum(float (*red)[32][33], int mm, int nn) {
 // 3-4 us; taken one after the other - load, wait, multiply, load - a K = 1536 product spent 15 us on it).  A handed off
 // inside the launch (coherent 16-byte loads), B = weights (plain loads).
 struct PbBatch { float4 a[8], b[8]; };
-__device__ __forceinline__ void pb_load(PbBatch& f, const float* abase, long aidx, const float* bp, int G, int g) {
+// K a multiple of 512 (every width of the reference configuration): every K-group of a batch exists, so the eight fragment
+// addresses of a batch are ONE lane base plus compile-time steps (an immediate of the load) and nothing is masked.  Round 3's
+// general form computed a clamped address per fragment; hipcc hoisted those sixteen address registers out of the step loop and
+// spilled them (28-36 B per lane of scratch, reloaded in front of every batch on the critical path of a step).  Other widths
+// (small models) take pb_gemm_tail: one K-group at a time, same order of additions, no registers to hoist.
+__device__ __forceinline__ void pb_load(PbBatch& f, const float* abase, long aidx, const float* bp, int g) {
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, 0x7fffffff, 0x00020000);
+  const int vo = (int)((aidx + (long)g * 8) * 4);
+  const float* bq = bp + (long)g * 8;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const int gu = g + u * PB_WAVES;
-    const long off = (gu < G) ? (long)gu * 8 : 0;
-    f.b[u] = *reinterpret_cast<const float4*>(bp + off);
-    f.a[u] = ld_sc1_4(abase, aidx + off);
+    f.b[u] = *reinterpret_cast<const float4*>(bq + u * PB_WAVES * 8);
+    const pd_v4u v = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, u * PB_WAVES * 32, 16 /* sc1 */);
+    f.a[u] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
 }
-__device__ __forceinline__ void pb_mfma(f32x16& acc, const PbBatch& f, int G, int g) {
+__device__ __forceinline__ void pb_mfma(f32x16& acc, const PbBatch& f) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const bool ok = (g + u * PB_WAVES) < G;
-    const float4 av = ok ? f.a[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, f.b[u].x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, f.b[u].y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, f.b[u].z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, f.b[u].w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[u].x, f.b[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[u].y, f.b[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[u].z, f.b[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[u].w, f.b[u].w, acc, 0, 0, 0);
+  }
+}
+// any K (a multiple of 8): this wave's groups wave, wave + 8, .. one at a time
+__device__ __forceinline__ void pb_gemm_tail(f32x16& acc, const float* abase, long aidx, const float* bp, int G, int wave) {
+#pragma clang loop unroll(disable)
+  for (int g = wave; g < G; g += PB_WAVES) {
+    const float4 b = *reinterpret_cast<const float4*>(bp + (long)g * 8);
+    const float4 a = ld_sc1_4(abase, aidx + (long)g * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
   }
 }
 // K <= 512: the wave's whole share is one batch
 __device__ __forceinline__ void pb_gemm1(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave) {
   const int G = K / 8;
-  PbBatch f;
-  pb_load(f, abase, aidx, bp, G, wave);
-  __builtin_amdgcn_sched_barrier(0);
-  pb_mfma(acc, f, G, wave);
+  if (G == 8 * PB_WAVES) {
+    PbBatch f;
+    pb_load(f, abase, aidx, bp, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    pb_mfma(acc, f);
+  } else {
+    pb_gemm_tail(acc, abase, aidx, bp, G, wave);
+  }
 }
 __device__ __forceinline__ void pb_gemm(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave) {
   const int G = K / 8;
   constexpr int STEP = 8 * PB_WAVES;
+  if (G % STEP != 0) { pb_gemm_tail(acc, abase, aidx, bp, G, wave); return; }
   PbBatch f0, f1;
-  pb_load(f0, abase, aidx, bp, G, wave);
+  pb_load(f0, abase, aidx, bp, wave);
   for (int g = wave; g < G; g += 2 * STEP) {
-    if (g + STEP < G) pb_load(f1, abase, aidx, bp, G, g + STEP);
+    if (g + STEP < G) pb_load(f1, abase, aidx, bp, g + STEP);
     __builtin_amdgcn_sched_barrier(0);
-    pb_mfma(acc, f0, G, g);
+    pb_mfma(acc, f0);
     if (g + STEP < G) {
-      if (g + 2 * STEP < G) pb_load(f0, abase, aidx, bp, G, g + 2 * STEP);
+      if (g + 2 * STEP < G) pb_load(f0, abase, aidx, bp, g + 2 * STEP);
       __builtin_amdgcn_sched_barrier(0);
-      pb_mfma(acc, f1, G, g + STEP);
+      pb_mfma(acc, f1);
     }
   }
 }

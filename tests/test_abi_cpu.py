@@ -77,3 +77,22 @@ def test_product_refuses_cpu_tensors():
     enc = Cnn10(64, 512)
     with pytest.raises(RuntimeError, match="no CPU fallback|MI355X|cuda|GPU"):
         enc(torch.zeros(1, 64, 64), np.array([64]))
+
+
+def test_hot_kernels_keep_everything_in_registers():
+    """The persistent decode / posterior kernels and the Winograd kernels run one workgroup per CU at (or near) the 256-register
+    limit: a register the compiler cannot place goes to scratch memory, i.e. a global-memory round trip inside the step loop
+    (round 3 shipped decode_persist_bwd_kernel with 28 B per lane of it).  The build keeps hipcc's per-kernel resource remarks
+    (-Rpass-analysis=kernel-resource-usage) beside every object file; any scratch in these kernels fails here."""
+    from acvae_amd import build as b
+    ge.build()
+    usage = b.resource_usage()
+    hot = ("decode_persist_kernel", "decode_persist_bwd_kernel", "posterior_persist_fwd_kernel", "posterior_persist_bwd_kernel",
+           "conv_wino_kernel", "conv_wino_act_kernel", "conv_wino_wgrad_kernel_s1", "conv_wino_wgrad_kernel_s2",
+           "conv_wino_wgrad_kernel_s3", "conv_wino_wgrad_kernel_s4")
+    for k in hot:
+        hits = {n: u for n, u in usage.items() if k + "E" in n or n.endswith(k)}
+        assert hits, f"{k}: no resource record (rebuild with python -m acvae_amd.build --force)"
+        for n, u in hits.items():
+            assert u.get("scratch", -1) == 0, f"{n}: {u.get('scratch')} bytes per lane of scratch"
+            assert u.get("vgprs", 999) <= 256, (n, u)
