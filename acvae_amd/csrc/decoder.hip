@@ -146,10 +146,13 @@ struct DecLayout {
   // saved
   long words, mem, encproj_d, encproj_p, qd, qp, attw_p, rnn_d, rnn_p, gru_save, hprev_d, lstm_save, c_all, hp_all,
       hpprev, lse, pool_arg, pool_hid, unfinished, saved_total;
+  // saved as well (round 4): the transposed weights of the backward's dX = dY . W products, made by the FORWARD on its second
+  // stream beside the persistent launch instead of in front of the BPTT on the backward's critical path
+  long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo;
   // fwd scratch
   long skws, skws_p, gi_d, gh_d, gates_p, ml, h0, pd_cnt, attfws_d, attfws_p, attfws_bytes, scratch_fwd;
   // bwd scratch
-  long wt_cls, wt_dih, wt_dhh, wt_datt, wt_pih, wt_phh, wt_pml, wt_patt, wt_mlo, wt_ln;
+  long wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a, pd_part,
       dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, pd_cnt_b, scratch_bwd;
   // bwd scratch private to the prior chain (it may run on the second stream)
@@ -171,6 +174,9 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   L.lstm_save = s.take(R * 5 * Hp); L.c_all = s.take(R * Hp); L.hp_all = s.take(R * Hp); L.hpprev = s.take(R * Hp);
   L.lse = s.take(R); L.pool_arg = s.take((long)N * H); L.pool_hid = s.take((long)N * H);
   L.unfinished = s.take(N);
+  L.wt_cls = s.take((long)H * V + 64); L.wt_dih = s.take((long)3 * E * 3 * H); L.wt_dhh = s.take((long)H * 3 * H);
+  L.wt_datt = s.take((long)(E + H) * A); L.wt_pih = s.take((long)3 * E * 4 * Hp); L.wt_phh = s.take((long)Hp * 4 * Hp);
+  L.wt_pml = s.take((long)Hp * 2 * E); L.wt_patt = s.take((long)2 * E * E); L.wt_mlo = s.take((long)H * 2 * E);
   L.saved_total = s.off;
   Bump f;
   L.skws = f.take(acvae_skinny_ws_floats());   // same offsets in the forward and backward scratch maps
@@ -186,9 +192,6 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   Bump b;
   b.take(acvae_skinny_ws_floats());            // skinny split-K workspaces first (L.skws, L.skws_p)
   b.take(acvae_skinny_ws_floats());
-  L.wt_cls = b.take((long)H * V + 64); L.wt_dih = b.take((long)3 * E * 3 * H); L.wt_dhh = b.take((long)H * 3 * H);
-  L.wt_datt = b.take((long)(E + H) * A); L.wt_pih = b.take((long)3 * E * 4 * Hp); L.wt_phh = b.take((long)Hp * 4 * Hp);
-  L.wt_pml = b.take((long)Hp * 2 * E); L.wt_patt = b.take((long)2 * E * E); L.wt_mlo = b.take((long)H * 2 * E);
   L.wt_ln = b.take((long)Eenc * E);
   L.d_out = b.take(R * H); L.dgi = b.take(R * 3 * H); L.dgh = b.take(R * 3 * H); L.dqd = b.take(R * A);
   L.dencproj = b.take((long)N * S * (A > E ? A : E)); L.dvpart = b.take((long)N * (A > E ? A : E));
@@ -579,6 +582,22 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
                              hprev_d + (long)t * H, (long)Tc * H, nullptr, t, N, H, st));
     return ACVAE_OK;
   };
+  // the backward's transposed weights (one launch for the nine): queued on the prior chain's stream where that stream has
+  // nothing else to do - beside the persistent launch / behind the prior chain - and joined with it before the call returns
+  auto transposes = [&](hipStream_t ts) -> int {
+    if (!train) return ACVAE_OK;
+    TransposeBatch tb;
+    tb.add(P(TP_DEC_CLS_W), H, sv + L.wt_cls, V, V, H);                     // [H][V]
+    tb.add(P(TP_DEC_WIH), 3 * E, sv + L.wt_dih, 3 * H, 3 * H, 3 * E);       // [3E][3H]
+    tb.add(P(TP_DEC_WHH), H, sv + L.wt_dhh, 3 * H, 3 * H, H);               // [H][3H]
+    tb.add(P(TP_DEC_ATT_W), E + H, sv + L.wt_datt, A, A, E + H);            // [H+E][A]: rows 0:H query half, H: memory half
+    tb.add(P(TP_P_WIH), 3 * E, sv + L.wt_pih, 4 * Hp, 4 * Hp, 3 * E);       // [3E][4Hp]
+    tb.add(P(TP_P_WHH), Hp, sv + L.wt_phh, 4 * Hp, 4 * Hp, Hp);             // [Hp][4Hp]
+    tb.add(P(TP_P_ML_W), Hp, sv + L.wt_pml, 2 * E, 2 * E, Hp);              // [Hp][2E]
+    tb.add(P(TP_P_ATT_W), 2 * E, sv + L.wt_patt, E, E, 2 * E);              // [2E][E]
+    tb.add(P(TP_MLO_W), H, sv + L.wt_mlo, 2 * E, 2 * E, H);                 // [H][2E]
+    return acvae_transpose_batch(tb, ts);
+  };
   float* lse = sv + L.lse;
   auto classify = [&](int t0, int cnt) -> int {
     const int M = rows_of(cnt);
@@ -627,8 +646,9 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
         ACVAE_TRY(dec_step(t));
       }
     }
+    ACVAE_TRY(transposes(sp.s));          // persistent path: sp has been idle since the join in front of the launch
     ACVAE_TRY(classify(0, Tc));
-    if (!prior_feeds_decoder) ACVAE_TRY(fork.join());
+    ACVAE_TRY(fork.join());
   } else {
     for (int t = 0; t < Tc; ++t) {
       ACVAE_TRY(acvae::select_word(caps, ld_caps, seqs, Tc, words, Tc, t, train && ss_flags_host[t], start_idx, N, st));
@@ -639,13 +659,18 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
       ACVAE_TRY(classify(t, 1));
       if (!train) ACVAE_TRY(acvae::finish_rows(seqs, Tc, unfinished, t, end_idx, N, st));
     }
+    ACVAE_TRY(transposes(st.s));
   }
   // h_{t-1} of the prior LSTM for its weight gradient (one shifted copy of hp_all after the loop instead of a copy per step)
-  ACVAE_TRY(acvae::copy_rows(hpprev, (long)Tc * Hp, nullptr, 0, N, Hp, st));
-  if (Tc > 1) ACVAE_TRY(acvae::copy_rows(hpprev + Hp, (long)Tc * Hp, hp_all, (long)Tc * Hp, N, (Tc - 1) * Hp, st));
-  if (h_final) ACVAE_TRY(acvae::copy_rows(h_final, H, outputs + (long)(Tc - 1) * H, (long)Tc * H, N, H, st));
-  if (hp_final) ACVAE_TRY(acvae::copy_rows(hp_final, Hp, hp_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp, st));
-  if (cp_final) ACVAE_TRY(acvae::copy_rows(cp_final, Hp, c_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp, st));
+  {                    // (and the final states) - five small copies in one launch
+    acvae::CopyRowsBatch cb;
+    cb.add(hpprev, (long)Tc * Hp, nullptr, 0, N, Hp);
+    if (Tc > 1) cb.add(hpprev + Hp, (long)Tc * Hp, hp_all, (long)Tc * Hp, N, (Tc - 1) * Hp);
+    if (h_final) cb.add(h_final, H, outputs + (long)(Tc - 1) * H, (long)Tc * H, N, H);
+    if (hp_final) cb.add(hp_final, Hp, hp_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp);
+    if (cp_final) cb.add(cp_final, Hp, c_all + (long)(Tc - 1) * Hp, (long)Tc * Hp, N, Hp);
+    ACVAE_TRY(acvae::copy_rows_batch(cb, st));
+  }
   if (train) {  // p_means_utt = mean_log_out(mean_with_lens + max_with_lens of the GRU outputs), vae_model.py:722-728
     float* hidp = sv + L.pool_hid;
     ACVAE_TRY(acvae::pool_fwd(outputs, (long)Tc * H, H, lens1, hidp, (int*)(sv + L.pool_arg), N, Tc, H, st));
@@ -714,25 +739,10 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   float* rnn_d = sv + L.rnn_d;
   float* rnn_p = sv + L.rnn_p;
 
-  // transposed weights for the dX = dY . W products
-  const int Vp = (V + 3) & ~3;
-  float *wt_cls = sc + L.wt_cls, *wt_dih = sc + L.wt_dih, *wt_dhh = sc + L.wt_dhh, *wt_datt = sc + L.wt_datt;
-  float *wt_pih = sc + L.wt_pih, *wt_phh = sc + L.wt_phh, *wt_pml = sc + L.wt_pml, *wt_patt = sc + L.wt_patt;
-  float *wt_mlo = sc + L.wt_mlo, *wt_ln = sc + L.wt_ln;
-  (void)Vp;
-  {   // one launch for the nine (they sit in front of the BPTT on the critical path: 9 x 7 us as separate launches)
-    TransposeBatch tb;
-    tb.add(P(TP_DEC_CLS_W), H, wt_cls, V, V, H);                     // [H][V]
-    tb.add(P(TP_DEC_WIH), 3 * E, wt_dih, 3 * H, 3 * H, 3 * E);       // [3E][3H]
-    tb.add(P(TP_DEC_WHH), H, wt_dhh, 3 * H, 3 * H, H);               // [H][3H]
-    tb.add(P(TP_DEC_ATT_W), E + H, wt_datt, A, A, E + H);            // [H+E][A]: rows 0:H query half, H: memory half
-    tb.add(P(TP_P_WIH), 3 * E, wt_pih, 4 * Hp, 4 * Hp, 3 * E);       // [3E][4Hp]
-    tb.add(P(TP_P_WHH), Hp, wt_phh, 4 * Hp, 4 * Hp, Hp);             // [Hp][4Hp]
-    tb.add(P(TP_P_ML_W), Hp, wt_pml, 2 * E, 2 * E, Hp);              // [Hp][2E]
-    tb.add(P(TP_P_ATT_W), 2 * E, wt_patt, E, E, 2 * E);              // [2E][E]
-    tb.add(P(TP_MLO_W), H, wt_mlo, 2 * E, 2 * E, H);                 // [H][2E]
-    ACVAE_TRY(acvae_transpose_batch(tb, st.s));
-  }
+  // transposed weights for the dX = dY . W products: made by the forward (acvae_decode_fwd, training mode) into `saved`
+  float *wt_cls = sv + L.wt_cls, *wt_dih = sv + L.wt_dih, *wt_dhh = sv + L.wt_dhh, *wt_datt = sv + L.wt_datt;
+  float *wt_pih = sv + L.wt_pih, *wt_phh = sv + L.wt_phh, *wt_pml = sv + L.wt_pml, *wt_patt = sv + L.wt_patt;
+  float *wt_mlo = sv + L.wt_mlo, *wt_ln = sc + L.wt_ln;
   int64_t* words_c = (int64_t*)(sc + L.words_c);
   ACVAE_TRY(acvae::gather_words(words, Tc, 1, words_c, N, Tc, st));
   ACVAE_TRY(fork.begin());

@@ -32,4 +32,13 @@ int pool_bwd(const float* d, const int64_t* lens, const int* argmax, float* dx, 
 int colsum_rows(const float* x, long ld, int rows, int cols, float* out, int accumulate, hipStream_t st);
 int add_rows(float* dst, long ld_d, const float* src, long ld_s, int rows, int cols, hipStream_t st);
 int copy_rows(float* dst, long ld_d, const float* src, long ld_s, int rows, int cols, hipStream_t st);
+// up to 8 copy_rows jobs (src == nullptr: zero fill) in ONE launch; the jobs must not overlap
+struct CopyRowsBatch {
+  static constexpr int MAXJ = 8;
+  float* dst[MAXJ]; const float* src[MAXJ]; long ld_d[MAXJ], ld_s[MAXJ]; int rows[MAXJ], cols[MAXJ]; int n = 0;
+  void add(float* d, long ldd, const float* s, long lds, int r, int c) {
+    dst[n] = d; src[n] = s; ld_d[n] = ldd; ld_s[n] = lds; rows[n] = r; cols[n] = c; ++n;
+  }
+};
+int copy_rows_batch(const CopyRowsBatch& b, hipStream_t st);
 }  // namespace acvae

@@ -276,10 +276,35 @@ __global__ void copy_rows_kernel(float* __restrict__ dst, long ld_d, const float
   }
 }
 
+// several copy_rows jobs in one launch (blockIdx.y = job): the decode forward ended in five 5-us copies of a few KB each
+__global__ void copy_rows_batch_kernel(acvae::CopyRowsBatch b) {
+  const int j = blockIdx.y;
+  const long total = (long)b.rows[j] * b.cols[j];
+  const int cols = b.cols[j];
+  float* dst = b.dst[j];
+  const float* src = b.src[j];
+  const long ld_d = b.ld_d[j], ld_s = b.ld_s[j];
+  for (long i = blockIdx.x * (long)TH + threadIdx.x; i < total; i += (long)gridDim.x * TH) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[r * ld_d + c] = src ? src[r * ld_s + c] : 0.f;
+  }
+}
+
 }  // namespace
 
 namespace acvae {
 #define LAUNCH(k, g, ...) hipLaunchKernelGGL(k, dim3(g), dim3(TH), 0, st, __VA_ARGS__)
+int copy_rows_batch(const CopyRowsBatch& b, hipStream_t st) {
+  if (b.n <= 0) return ACVAE_OK;
+  long most = 1;
+  for (int j = 0; j < b.n; ++j) {
+    if (!b.dst[j] || b.rows[j] <= 0 || b.cols[j] <= 0) return ACVAE_EINVAL;
+    const long t = (long)b.rows[j] * b.cols[j];
+    if (t > most) most = t;
+  }
+  hipLaunchKernelGGL(copy_rows_batch_kernel, dim3(grid1(most), b.n), dim3(TH), 0, st, b);
+  ACVAE_LAUNCH_CHECK(); return ACVAE_OK;
+}
 
 int caps_to_long(const float* caps, int64_t* out, long n, hipStream_t st) {
   LAUNCH(caps_to_long_kernel, grid1(n), caps, out, n);

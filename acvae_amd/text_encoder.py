@@ -65,6 +65,7 @@ class _PosteriorFn(torch.autograd.Function):
         _lib.persist_status(dev)                 # the device's status words are registered before the first persistent launch
         _lib.call("acvae_posterior_fwd", ptr_table(params), caps_d, caps_d.stride(0), lens1_d, eps_q, qm, ql, qz, utt,
                   saved, saved_b, scratch, scratch_b, N, Tc, E, Hq, V, _lib.current_stream(), _lib.call_flags())
+        ctx.set_materialize_grads(False)         # unused outputs arrive as None in backward (no zero-fill launches)
         ctx.mod, ctx.saved, ctx.dims = mod, saved, (N, Tc, E, Hq, V)
         # an OUTPUT kept as a plain ctx attribute forms a tensor -> grad_fn -> ctx -> tensor cycle that is never collected
         ctx.save_for_backward(lens1_d, eps_q, ql)

@@ -59,6 +59,7 @@ class _DecodeFn(torch.autograd.Function):
                   attw, pm, pl, pz, putt, hfin, hp, cp, saved, saved_b, scratch, scratch_b, *dims, model.start_idx,
                   model.end_idx, _lib.current_stream(), model._aux_stream(), int(method), float(temp), noise, keep,
                   float(drop_p), _lib.call_flags())
+        ctx.set_materialize_grads(False)         # outputs the loss does not use (outputs, p_z, ..) arrive as None, not as zero tensors
         ctx.model, ctx.saved, ctx.dims, ctx.dis_arr = model, saved, dims, dis_arr
         ctx.emb_keep, ctx.emb_p = keep, float(drop_p)
         # outputs kept as plain ctx attributes would form tensor -> grad_fn -> ctx -> tensor cycles that are never collected
