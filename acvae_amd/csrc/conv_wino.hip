@@ -78,7 +78,24 @@ struct WinoParams {
   int tw_shift;         // TW = W/2 = 1 << tw_shift
   int R;                // tile rows per workgroup = 64 / TW
   int bpc;              // workgroups (row blocks) per clip = ceil(ceil(H/2) / R)
+  // divisions of the prologue as multiply-shifts (the launcher computes the constants; every wavefront of every workgroup
+  // ran ~7 integer divisions by run-time values, ~30 instructions each, before its first load - round 4 timeline: 0.8 us of a
+  // 22 us workgroup on the 64-channel layers)
+  unsigned w2_magic;    // x / (W + 2) = (x * w2_magic) >> 16 for x < 1024
+  unsigned bpc_magic;   // x / bpc = umulhi(x, bpc_magic) for x < 2^20, bpc >= 2
+  int nn_shift;         // log2(Cout / 64) when that is a power of two, else -1 (generic division)
 };
+__device__ __forceinline__ int wino_div_w2(int x, const WinoParams& p) { return (int)(((unsigned)x * p.w2_magic) >> 16); }
+// (row block, column block) of this workgroup: mfma_tile.h xcd_tile with the launcher's constants instead of divisions
+__device__ __forceinline__ void wino_xcd_tile(const WinoParams& p, int nm, int nn, int& bm, int& bn) {
+  const int total = nm * nn;
+  const int b = blockIdx.x + blockIdx.y * nm;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  const int t = xcd * q + (xcd < r ? xcd : r) + idx;   // XCD x owns q (+1 if x < r) consecutive tiles, N fastest inside the run
+  if (p.nn_shift >= 0) { bn = t & (nn - 1); bm = t >> p.nn_shift; }
+  else { bn = t % nn; bm = t / nn; }
+}
 
 // The transform adds as v_pk_add_f32: two values per VALU issue slot.  In-kernel counters and the A/B below say the SIMD's issue
 // slots are what a chunk runs out of (every instruction a wavefront issues, MFMA or not, costs its cycles; halving the 64 adds
@@ -160,11 +177,13 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
 // buffer stores (32-bit lane offset + scalar offset) against a descriptor of the CLIP whose size makes the hardware drop rows
 // past the clip's end - no address arithmetic, no branch per tile.  The LDS exchange moves both pixels of a tile in one
 // 8-byte access.
-template <int XH>
+// STATS: the launch also returns the BatchNorm partial sums of its raw output (forward convolutions); the data gradient's
+// build leaves the 112 instructions of the sums out of its epilogue.
+template <int XH, bool STATS>
 __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 (&acc)[8], float* ex_mine, const float* ex_partner,
                                               float* red, int mh, int nh, int li, int h, int lane, int n, int ty0, int bm,
                                               int bn) {
-  const int tid = threadIdx.x;
+  const int tid = (mh * 2 + XH + nh * 4) * 64 + lane;          // = threadIdx.x, from the values taken afresh behind the main loop
   const int H = p.H, W = p.W, Cout = p.Cout;
   float2 keep[16];
   float2* exm = reinterpret_cast<float2*>(ex_mine);
@@ -213,12 +232,14 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
     const float o0 = keep[r].x + pr.x, o1 = keep[r].y + pr.y;
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), yrs, voff[k], soff[j], 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), yrs, voff[k], soff[j] + pix, 0);
-    const bool ok = yk[k] + dyj[j] < H;
-    const float a0 = ok ? o0 : 0.f, a1 = ok ? o1 : 0.f;
-    s += a0 + a1;
-    qq += a0 * a0 + a1 * a1;
+    if (STATS) {
+      const bool ok = yk[k] + dyj[j] < H;
+      const float a0 = ok ? o0 : 0.f, a1 = ok ? o1 : 0.f;
+      s += a0 + a1;
+      qq += a0 * a0 + a1 * a1;
+    }
   }
-  if (p.partials) {
+  if (STATS && p.partials) {
     s += __shfl_xor(s, 32, 64);
     qq += __shfl_xor(qq, 32, 64);
     if (h == 0) {
@@ -238,17 +259,18 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
 }
 
 // XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
-template <int XH, bool ACT>
+template <int XH, bool ACT, bool STATS>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1,
                                                float4* scsh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same value as a scalar (for the code behind the main loop)
   const int li = lane & 31, h = lane >> 5;
   // wavefront roles: XH = wave & 1, mh = tile half, nh = column half
   const int mh = (wave >> 1) & 1, nh = wave >> 2;
   int bm, bn;
-  xcd_tile(gridDim.x, gridDim.y, bm, bn);
+  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);
   const int RW = wino_row_pitch(p.tw_shift), R = p.R;
-  const int n = bm / p.bpc, ty0 = (bm - n * p.bpc) * R;
+  const int n = p.bpc == 1 ? bm : (int)__umulhi((unsigned)bm, p.bpc_magic), ty0 = (bm - n * p.bpc) * R;   // (2^32 / 1 does not fit the constant)
   const int H = p.H, W = p.W, C = p.C;
 
   // ---------------------------------------------------------------- staging items of this thread (fixed over stages)
@@ -263,7 +285,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     const int e = tid + WN_THREADS * j;
     const bool lv = e < nitems;
     const int px = e >> 2;
-    const int ry = px / W2, rx = px - ry * W2;
+    const int ry = wino_div_w2(px, p), rx = px - ry * W2;
     const int y = 2 * ty0 - 1 + ry, x = rx - 1;
     const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
     goff[j] = ok ? (unsigned)((((long)(n * H + y) * W + x) * C) + q * 4) : 0u;     // always a legal address
@@ -476,6 +498,13 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     }
   }
   __syncthreads();          // the epilogue reuses the window buffers
+  // Lane and wavefront coordinates are taken afresh here (lane id from mbcnt, the wave index kept as a scalar): carried over
+  // from the top of the kernel they are live across the main loop, which has no register to spare (the BatchNorm + ReLU build
+  // spilled one of them).
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int li_e = lane_e & 31, h_e = lane_e >> 5;
+  const int tid_e = wave_s * 64 + lane_e;
+  const int mh_e = (wave_s >> 1) & 1, nh_e = wave_s >> 2;
 
   // ---------------------------------------------------------------- prefetch for the workgroup that follows on this XCD
   // A workgroup's prologue waits out one HBM round trip for the first stage of its window (2-3 us under load: the tensor was
@@ -493,38 +522,44 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   if (!ACT) {
     const int nn_ = (int)gridDim.y;
     const int t2 = bm * nn_ + bn + 32 * ((int)gridDim.x * nn_ >= 256 ? 1 : 0);
-    const int bm2 = t2 / nn_;
-    const int n2 = bm2 / p.bpc, ty2 = (bm2 - n2 * p.bpc) * R;
-    const int ry = tid / W2, rx = tid - ry * W2;
+    const int bm2 = p.nn_shift >= 0 ? t2 >> p.nn_shift : t2 / nn_;
+    const int n2 = p.bpc == 1 ? bm2 : (int)__umulhi((unsigned)bm2, p.bpc_magic), ty2 = (bm2 - n2 * p.bpc) * R;
+    const int ry = wino_div_w2(tid_e, p), rx = tid_e - ry * W2;
     const int y = 2 * ty2 - 1 + ry, x = rx - 1;
     if (bm2 < (int)gridDim.x && bm2 != bm && ry < 2 * R + 2 && y >= 0 && y < H && x >= 0 && x < W)
       pfv = p.X[((long)(n2 * H + y) * W + x) * C];        // default cache policy: the line is to stay in L2
   }
 
   // ---------------------------------------------------------------- epilogue
-  float* exb = reinterpret_cast<float*>(wave < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
-  wino_epilogue<XH>(p, acc, exb + (wave & 3) * 2048, exb + ((wave & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw0), mh, nh, li, h,
-                    lane, n, ty0, bm, bn);
+  float* exb = reinterpret_cast<float*>(wave_s < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
+  wino_epilogue<XH, STATS>(p, acc, exb + (wave_s & 3) * 2048, exb + ((wave_s & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw0), mh_e,
+                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);
   if (!ACT) asm volatile("" :: "v"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved
 }
 
-// ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift)
-template <bool ACT>
+// ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift); STATS: BatchNorm partial sums of the output.
+// Three builds: the data gradient (neither), a block's first convolution (statistics), its second one (both).
+template <bool ACT, bool STATS>
 __device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1,
                                                 float4* scsh) {
-  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT>(p, raw0, raw1, bw0, bw1, scsh);
-  else conv_wino_body<0, ACT>(p, raw0, raw1, bw0, bw1, scsh);
+  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT, STATS>(p, raw0, raw1, bw0, bw1, scsh);
+  else conv_wino_body<0, ACT, STATS>(p, raw0, raw1, bw0, bw1, scsh);
 }
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(WinoParams p) {
   __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
   __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  conv_wino_entry<false>(p, raw0, raw1, bw0, bw1, nullptr);
+  conv_wino_entry<false, false>(p, raw0, raw1, bw0, bw1, nullptr);
+}
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_stats_kernel(WinoParams p) {
+  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
+  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
+  conv_wino_entry<false, true>(p, raw0, raw1, bw0, bw1, nullptr);
 }
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_act_kernel(WinoParams p) {
   __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
   __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
   __shared__ float4 scsh[2 * WN_MAXC / 4];
-  conv_wino_entry<true>(p, raw0, raw1, bw0, bw1, scsh);
+  conv_wino_entry<true, true>(p, raw0, raw1, bw0, bw1, scsh);
 }
 
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
@@ -639,9 +674,15 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   p.tw_shift = __builtin_ctz(TW);
   p.R = WN_TILES / TW;
   p.bpc = cdiv(cdiv(H, 2), p.R);
+  p.w2_magic = 65536u / (unsigned)(W + 2) + 1u;                       // exact for x < 1024 (W + 2 <= 66)
+  p.bpc_magic = (unsigned)((0x100000000ULL + (unsigned)p.bpc - 1) / (unsigned)p.bpc);   // ceil(2^32 / bpc): exact for x * bpc < 2^32
+  const int nn = Cout / WN_TN;
+  p.nn_shift = (nn & (nn - 1)) == 0 ? __builtin_ctz(nn) : -1;
+  if ((long)N * p.bpc >= (1L << 20)) return ACVAE_EUNSUPPORTED;
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
   if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  else if (partials) hipLaunchKernelGGL(conv_wino_stats_kernel, grid, dim3(WN_THREADS), 0, st, p);
   else hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
   prof_end(ACVAE_PROF_CONV_IGEMM, st);
   ACVAE_LAUNCH_CHECK();

@@ -31,14 +31,14 @@ VARIANTS = {
 }
 # phase stamps (s_memtime): [workgroup][wave][4] = prologue, main loop, epilogue, chunks; written over the start of Y after the epilogue
 VARIANTS["stamps"] = [
-    ("  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
-     "  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const long long lab_t0 = clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_t0 = clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
     (PRE_LOOP, "  const long long lab_t1 = clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
      "  const long long lab_t2 = clock64();\n  float* exb"),
-    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
-     "    o[0] = (float)(lab_t1 - lab_t0); o[1] = (float)(lab_t2 - lab_t1); o[2] = (float)(clock64() - lab_t2); o[3] = (float)nchunk;\n  }\n}\n\n// ACT: the operand"),
+    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+     "    o[0] = (float)(lab_t1 - lab_t0); o[1] = (float)(lab_t2 - lab_t1); o[2] = (float)(clock64() - lab_t2); o[3] = (float)nchunk;\n  }\n}\n\n// ACT: the operand carries"),
 ]
 # in-kernel clock: s_memtime (shader cycles) against s_memrealtime (100 MHz) around the main loop -> [workgroup][wave][4] =
 # cycles, 100-MHz ticks, chunks, 0 (MI355X_MICROARCH.md, DVFS give-back (6))
@@ -46,33 +46,33 @@ VARIANTS["clock"] = [
     (PRE_LOOP, "  const long long lab_c0 = clock64(), lab_r0 = wall_clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
      "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n  float* exb"),
-    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
-     "    o[0] = (float)(lab_c1 - lab_c0); o[1] = (float)(lab_r1 - lab_r0); o[2] = (float)nchunk; o[3] = 0.f;\n  }\n}\n\n// ACT: the operand"),
+    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+     "    o[0] = (float)(lab_c1 - lab_c0); o[1] = (float)(lab_r1 - lab_r0); o[2] = (float)nchunk; o[3] = 0.f;\n  }\n}\n\n// ACT: the operand carries"),
 ]
 # workgroup timeline: [workgroup][wave][4] = start, end (100-MHz wall clock, low 24 bits as float), CU key (XCC id << 8 | HW_ID[15:8]), 0
 VARIANTS["timeline"] = [
     ("      out[0] = o0;\n      out[p.Cout] = o1;\n", "      asm volatile(\"\" :: \"v\"(out), \"v\"(o0), \"v\"(o1));\n"),     # no output stores: the stamps go into Y
-    ("  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
-     "  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
-    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+    ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
-     "    o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = 0.f;\n  }\n}\n\n// ACT: the operand"),
+     "    o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = 0.f;\n  }\n}\n\n// ACT: the operand carries"),
 ]
 # timeline + phases in one launch (output stores kept): wave 0 = start, end, CU key, chunks; wave 1 = main loop start, end (100-MHz
 # ticks, low 24 bits), main-loop shader cycles, 0
 VARIANTS["full"] = [
-    ("  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
-     "  xcd_tile(gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
     (PRE_LOOP, "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
      "  const long long lab_c2 = clock64(), lab_r2 = wall_clock64();\n  float* exb"),
-    ("                    lane, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand",
-     "                    lane, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  if (lane == 0 && wave < 2) {\n    float* o = p.lab + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 3 + wave) * 4;\n"
+    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  if (lane == 0 && wave < 2) {\n    float* o = p.lab + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 3 + wave) * 4;\n"
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
      "    if (wave == 0) { o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = (float)nchunk; }\n"
-     "    else { o[0] = (float)(lab_r1 & 0xffffff); o[1] = (float)(lab_r2 & 0xffffff); o[2] = (float)(lab_c2 - lab_c1); o[3] = 0.f; }\n  }\n}\n\n// ACT: the operand"),
+     "    else { o[0] = (float)(lab_r1 & 0xffffff); o[1] = (float)(lab_r2 & 0xffffff); o[2] = (float)(lab_c2 - lab_c1); o[3] = 0.f; }\n  }\n}\n\n// ACT: the operand carries"),
 ]
 VARIANTS["full"] += [
     ("#pragma unroll\n  for (int g = 0; g < 4; ++g) B[g] = load_b(0, g);\n  issue_raw(0);\n  stage_scsh();\n  read_scsh(0);\n  put_raw(raw0);\n",
@@ -86,6 +86,7 @@ VARIANTS["full"] += [
 ]
 NOPF = [("      pfv = p.X[((long)(n2 * H + y) * W + x) * C];        // default cache policy: the line is to stay in L2", "      pfv = 1.f;")]
 VARIANTS["fullnopf"] = VARIANTS["full"] + NOPF
+VARIANTS["fullpfact"] = VARIANTS["full"] + [("  if (!ACT) {\n    const int nn_ = (int)gridDim.y;", "  {\n    const int nn_ = (int)gridDim.y;")]
 VARIANTS["mfmaonly"] = VARIANTS["nob"] + VARIANTS["noraw"] + VARIANTS["nod"]
 # no transforms either: what the bare MFMA stream (plus barrier and loop control) takes
 NOTRANS = [("    wino_htrans_ip(t1, v1);\n", "#pragma unroll\n    for (int j = 0; j < 4; ++j) v1[j] = t1[j];\n"),
@@ -118,7 +119,7 @@ def build(name):
         src = src.replace(old, new)
     os.makedirs(LAB, exist_ok=True)
     cpp = os.path.join(LAB, f"conv_wino_{name}.hip")
-    if name in ("full", "fullnopf"):
+    if name in ("full", "fullnopf", "fullpfact"):
         src += '\nextern "C" void acvae_lab_set(float* p) { g_lab = p; }\n'
     open(cpp, "w").write(src.replace('#include "../../include/acvae_hip.h"', f'#include "{ROOT}/include/acvae_hip.h"'))
     obj = os.path.join(LAB, f"conv_wino_{name}.o")
@@ -174,7 +175,7 @@ def time_one():
                   f"workgroup {sum(durs) / len(durs):.1f} us (max {max(durs):.1f}); gap between two on one CU {sum(gaps) / max(1, len(gaps)):.2f} us (max {max(gaps or [0]):.1f}); "
                   f"last end {float(en.max()):.1f} us; main loop {float(t[:, 3].floor().mean()) * 0.01:.1f} us real per workgroup [after {warm} warm-up launches]")
           continue
-        if os.environ.get("ACVAE_DEV_LIB", "").endswith(("_full.so", "_fullnopf.so")):
+        if os.environ.get("ACVAE_DEV_LIB", "").endswith(("_full.so", "_fullnopf.so", "_fullpfact.so")):
             import ctypes
             nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
             labbuf = torch.zeros(nwg, 3, 4, device="cuda")

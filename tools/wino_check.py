@@ -137,6 +137,7 @@ if __name__ == "__main__":
             for act in (False, True):
                 e = check(N, H, W, Cin, Cout, act, seed=i)
                 worst = max(worst, *e)
+                assert all(x == x for x in e), "NaN in a Winograd result"
         print("worst", worst)
     if "time" in what:
         bench()
