@@ -52,6 +52,14 @@ int conv3x3_wino_wgrad(const float* dY, const float* X, const float* scale, cons
 // T = float or bf16_t (storage type of activations / repacked weights; arithmetic is fp32 either way)
 template <class T>
 int repack_weights(const float* W_oihw, T* Wf, T* Wd, int Cout, int Cin, hipStream_t st);
+// several repacks (implicit-GEMM weight layouts: forward [cout][tap][cin], data gradient [cin][8 - tap][cout]) in one launch
+struct RepackBatch {
+  static constexpr int MAXL = 32;
+  const float* W[MAXL]; void* dst[MAXL]; int Cout[MAXL], Cin[MAXL], dgrad[MAXL]; long start[MAXL + 1]; int n = 0;
+  void add(const float* w, void* d, int cout, int cin, bool dg) { W[n] = w; dst[n] = d; Cout[n] = cout; Cin[n] = cin; dgrad[n] = dg ? 1 : 0; ++n; }
+};
+template <class T>
+int repack_weights_batch(RepackBatch& b, hipStream_t st);
 // storage-type overloads so that the encoder driver is one template
 inline int conv3x3_igemm(const bf16_t* X, const float* scale, const float* shift, const bf16_t* Wp, bf16_t* Y,
                          float* partials, int N, int H, int W, int Cin, int Cout, hipStream_t st) {

@@ -578,6 +578,29 @@ __global__ void repack_dgrad_kernel(const float* __restrict__ W, T* __restrict__
   }
 }
 
+// all layers' repacks in one launch (the bf16 encoder queued fourteen 7-us launches per step in front of its convolutions)
+template <class T>
+__global__ void repack_batch_kernel(acvae::RepackBatch b) {
+  const long total = b.start[b.n];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < b.n && i >= b.start[l + 1]) ++l;
+    const long k = i - b.start[l];
+    const int Cout = b.Cout[l], Cin = b.Cin[l];
+    const float* W = b.W[l];
+    T* out = reinterpret_cast<T*>(b.dst[l]);
+    if (!b.dgrad[l]) {
+      const int co = (int)(k / (9 * Cin)), rem = (int)(k % (9 * Cin));
+      const int tap = rem / Cin, ci = rem % Cin;
+      out[k] = (T)W[((long)co * Cin + ci) * 9 + tap];
+    } else {
+      const int ci = (int)(k / (9 * Cout)), rem = (int)(k % (9 * Cout));
+      const int tp = rem / Cout, co = rem % Cout;
+      out[k] = (T)W[((long)co * Cin + ci) * 9 + (8 - tp)];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm statistics
 // bn0 (models/encoder.py:679-681: BatchNorm2d(64) over the mel axis): per-mel sums over all (clip, frame).
 __global__ __launch_bounds__(256) void bn0_stats_kernel(const float* __restrict__ x, float* __restrict__ partials,
@@ -1486,6 +1509,21 @@ int repack_weights(const float* W_oihw, T* Wf, T* Wd, int Cout, int Cin, hipStre
 }
 template int repack_weights<float>(const float*, float*, float*, int, int, hipStream_t);
 template int repack_weights<bf16_t>(const float*, bf16_t*, bf16_t*, int, int, hipStream_t);
+template <class T>
+int repack_weights_batch(RepackBatch& b, hipStream_t st) {
+  if (b.n <= 0) return ACVAE_OK;
+  b.start[0] = 0;
+  for (int l = 0; l < b.n; ++l) {
+    if (!b.W[l] || !b.dst[l]) return ACVAE_EINVAL;
+    b.start[l + 1] = b.start[l] + (long)b.Cout[l] * b.Cin[l] * 9;
+  }
+  const long total = b.start[b.n];
+  hipLaunchKernelGGL(repack_batch_kernel<T>, dim3(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256)), dim3(256), 0, st, b);
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+template int repack_weights_batch<float>(RepackBatch&, hipStream_t);
+template int repack_weights_batch<bf16_t>(RepackBatch&, hipStream_t);
 
 int bn0_stats(const float* x, float* partials, long rows, int F, int* nparts, hipStream_t st) {
   if (F > 64) return ACVAE_EUNSUPPORTED;

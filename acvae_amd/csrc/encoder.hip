@@ -72,11 +72,10 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
     const long wtaps = esz == 4 ? 16 : 9;      // fp32: room for the 16 Winograd positions of conv_wino.hip
     L.wf1[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b - 1]));
     L.wf2[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b]));
-    L.wd1[b] = L.wd2[b] = -1;
-    if (esz == 4) {
-      L.wd1[b] = off; off = align4(off + (long)kChan[b] * 16 * kChan[b - 1]);
-      L.wd2[b] = off; off = align4(off + (long)kChan[b] * 16 * kChan[b]);
-    }
+    // the data gradient's filter images, built with the forward's in one launch and kept for the backward (fp32: Winograd
+    // images, 16 positions; bf16: the implicit GEMM's [cin][tap][cout] repack)
+    L.wd1[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b - 1]));
+    L.wd2[b] = off; off = align4(off + units((long)kChan[b] * wtaps * kChan[b]));
     if (act > max_act) max_act = act;
     if (pool > max_pool) max_pool = pool;
     const long part = (long)acvae::conv_partials_rows(N, h, w) * 2 * kChan[b];
@@ -151,7 +150,7 @@ int conv_fwd(const TA* X, const float* scale, const float* shift, const float* W
       return acvae::conv3x3_wino(X, scale, shift, wbuf, Y, partials, N, H, W, Cin, Cout, st);
     }
   }
-  ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, (TA*)wbuf, nullptr, Cout, Cin, st));
+  if (!ready) ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, (TA*)wbuf, nullptr, Cout, Cin, st));
   *nparts = acvae::conv_partials_rows(N, H, W);
   return acvae::conv3x3_igemm(X, scale, shift, (const TA*)wbuf, Y, partials, N, H, W, Cin, Cout, st);
 }
@@ -165,7 +164,7 @@ int conv_dgrad(const TA* dY, const float* W_oihw, TA* wbuf, TA* dX, int N, int H
       return acvae::conv3x3_wino(dY, nullptr, nullptr, (const float*)wbuf, dX, nullptr, N, H, W, Cout, Cin, st);
     }
   }
-  ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, nullptr, wbuf, Cout, Cin, st));
+  if (!ready) ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, nullptr, wbuf, Cout, Cin, st));
   return acvae::conv3x3_igemm(dY, nullptr, nullptr, (const TA*)wbuf, dX, nullptr, N, H, W, Cout, Cin, st);
 }
 
@@ -266,6 +265,23 @@ int encoder_fwd_t(const void* const* params, const float* feats, float* audio_em
       }
     }
     ACVAE_TRY(acvae::conv3x3_wino_weights_batch(wb, st));
+  }
+  {   // the layers that run as implicit GEMMs (bf16 storage; fp32 shapes the Winograd kernels do not take): their repacks too
+    acvae::RepackBatch rb;
+    for (int b = 1; b <= L.nb; ++b) {
+      const int C = kChan[b], Cin = kChan[b - 1];
+      if (b > 1 && !wready[b][0]) {
+        rb.add(P(p_conv(b, 1)), saved + L.wf1[b], C, Cin, false);
+        if (training) rb.add(P(p_conv(b, 1)), saved + L.wd1[b], C, Cin, true);
+        wready[b][0] = true;
+      }
+      if (!wready[b][1]) {
+        rb.add(P(p_conv(b, 2)), saved + L.wf2[b], C, C, false);
+        if (training) rb.add(P(p_conv(b, 2)), saved + L.wd2[b], C, C, true);
+        wready[b][1] = true;
+      }
+    }
+    ACVAE_TRY(acvae::repack_weights_batch<TA>(rb, st));
   }
   const TA* x_in = nullptr;
   for (int b = 1; b <= L.nb; ++b) {
@@ -377,9 +393,9 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
                             training != 0));
     ACVAE_TRY(conv_wgrad<TA>((const TA*)dya, Y1, n1.scale, n1.shift, G(p_conv(b, 2)), slab, N, H, W, C, C, st));
     // the data gradient's Winograd images were built by the training forward (same parameters: the optimiser runs after us)
-    const bool wd_ready = sizeof(TA) == 4 && training != 0;
-    ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd_ready && use_wino<TA>(H, W, C, C) ? (TA*)(saved + L.wd2[b]) : wd, dyb, N,
-                             H, W, C, C, st, wd_ready));
+    // (Winograd images where that path runs, implicit-GEMM repacks elsewhere - the forward chose with the same predicate)
+    const bool wd_ready = training != 0;
+    ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd_ready ? (TA*)(saved + L.wd2[b]) : wd, dyb, N, H, W, C, C, st, wd_ready));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
     ACVAE_TRY(acvae::bn_bwd<TA>(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
@@ -387,7 +403,9 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
     if (b > 1) {
       ACVAE_TRY(conv_wgrad<TA>((const TA*)dya, (const TA*)(saved + L.p[b - 1]), nullptr, nullptr, G(p_conv(b, 1)), slab, N, H,
                                W, Cin, C, st));
-      const bool r1 = wd_ready && use_wino<TA>(H, W, Cin, C) && use_wino<TA>(H, W, C, Cin);
+      // the forward built the data gradient's Winograd image only where BOTH directions take the Winograd path
+      const bool fw = use_wino<TA>(H, W, Cin, C), dw = use_wino<TA>(H, W, C, Cin);
+      const bool r1 = wd_ready && fw == dw;
       ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 1)), r1 ? (TA*)(saved + L.wd1[b]) : wd, dp_nxt, N, H, W, Cin, C, st, r1));
       TA* t = dp_cur; dp_cur = dp_nxt; dp_nxt = t;
     } else {

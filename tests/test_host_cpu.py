@@ -182,3 +182,42 @@ def test_sampler_matches_reference_fixture():
     random.seed(77)
     assert [list(p) for p in DS.CaptionSampler(src, shuffle=True)] == G["sampler_shuffled77"].tolist()
     assert [list(p) for p in DS.CaptionSampler(src, audio_subset_indices=[4, 2])] == G["sampler_subset42"].tolist()
+
+
+def test_overlap_report_on_a_synthetic_two_rank_trace(tmp_path):
+    """tools/overlap_report.py (what tools/scale_check.sh runs on the kernel trace of `bench.py --gpus N`): per RCCL kernel the
+    part no compute kernel of the rank covers, the tail behind the last backward kernel, and the assertion that the collectives
+    appear on exactly N ranks - on a hand-made trace whose answers are known."""
+    import csv
+    import importlib.util
+    import io
+    import pathlib
+    spec = importlib.util.spec_from_file_location("overlap_report", pathlib.Path(__file__).resolve().parents[1] / "tools" / "overlap_report.py")
+    orp = importlib.util.module_from_spec(spec); spec.loader.exec_module(orp)
+    cols = ["Kind", "Agent_Id", "Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Kernel_Id", "Kernel_Name", "Correlation_Id",
+            "Start_Timestamp", "End_Timestamp"]
+    for rank in range(2):
+        d = tmp_path / f"rank{rank}"
+        d.mkdir()
+        with open(d / "t_kernel_trace.csv", "w", newline="") as fh:
+            w = csv.writer(fh); w.writerow(cols)
+            t = 1000
+            for step in range(4):
+                rows = [("conv_wino_wgrad_kernel_s4(WinoWgradParams)", t, t + 500_000),
+                        ("ncclDevKernel_Generic(ncclDevKernelArgs)", t + 100_000, t + 300_000),          # fully covered
+                        ("conv_wino_kernel(WinoParams)", t + 500_000, t + 900_000),
+                        ("ncclDevKernel_Generic(ncclDevKernelArgs)", t + 800_000, t + 1_000_000),        # 100 us behind the backward
+                        ("adam_kernel(float*)", t + 1_000_000, t + 1_100_000)]
+                for name, s, e in rows:
+                    w.writerow(["KERNEL_DISPATCH", "Agent 2", 1, 0, 1, 0, 0, name, 0, s, e])
+                t += 2_000_000
+    ranks = orp.load(str(tmp_path))
+    assert len(ranks) == 2
+    buf = io.StringIO()
+    summ = orp.report(ranks, n_gpus=2, steps_from=1, out=buf)
+    for s in summ.values():
+        assert abs(s["comm_us"] - 400.0) < 1e-6 and abs(s["exposed_us"] - 100.0) < 1e-6 and abs(s["tail_us"] - 100.0) < 1e-6
+    assert "beside conv_wino_wgrad_kernel_s4" in buf.getvalue()
+    import pytest
+    with pytest.raises(AssertionError, match="expected 4"):
+        orp.report(ranks, n_gpus=4, out=io.StringIO())

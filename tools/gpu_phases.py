@@ -8,8 +8,9 @@ import bench
 from acvae_amd import _lib
 from acvae_amd.trainer import TrainStep
 
+DT = sys.argv[2] if len(sys.argv) > 2 else "f32"
 model = bench.build_model().cuda().train()
-ts = TrainStep(model, bench.V, lr=5e-4, max_grad_norm=1.0, smoothing=0.1, alpha=1.0)
+ts = TrainStep(model, bench.V, lr=5e-4, max_grad_norm=1.0, smoothing=0.1, alpha=1.0, precision=DT)
 feats, caps, feat_lens, cap_lens = bench.synthetic(1)
 feats = feats.cuda()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
