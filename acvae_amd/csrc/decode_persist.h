@@ -44,6 +44,11 @@ struct PbParams {
   const float *d_out, *d_p_z, *d_p_means, *d_p_logs;
   // written by the launch (dctx: [N, Tc, E], one slot per step)
   float *dgi, *dgh, *dqd, *dctx, *dencproj, *dmem, *dvpart, *dgates, *dml_all, *dhp;
+  // clips of more than 64 frames: the attention role runs as rc_splits workgroups per clip (set by the launcher); their shares
+  // of d qd [rc_splits][N][Tc][A] (RA adds them and writes the sum to dqd) and the forward's rnn_d ([N][Tc][3E]: ctx = columns E..2E)
+  float* dqd_part;
+  const float* ctx;
+  int rc_splits;
   // K-split partials handed over inside the launch (scratch, decode_persist_bwd_part_floats): dctx [ks_rb][N][E],
   // dhp [ks_pa][N][Hp], dml [ks_pa][N][2E]
   float *dctx_part, *dhp_part, *dml_part;
@@ -58,6 +63,7 @@ struct PbParams {
 namespace acvae {
 bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A);
 long decode_persist_bwd_counter_words(int Tc);
+int decode_persist_bwd_rc_splits(int S);     // attention workgroups per clip (64 frames each)
 int decode_persist_bwd(PbParams p, hipStream_t st, int flags);
 long decode_persist_bwd_part_floats(int N, int E, int H);
 bool decode_persist_ok(int N, int Tc, int S, int E, int H, int A);

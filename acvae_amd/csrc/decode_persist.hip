@@ -624,6 +624,58 @@ __device__ __forceinline__ void pb_gemm1(f32x16& acc, const float* abase, long a
     pb_gemm_tail(acc, abase, aidx, bp, G, wave);
   }
 }
+// K <= 512 with the handed-off operand arriving as `ns` (2 or 3) shares `sstride` floats apart (the attention role split
+// over the frames of a long clip): every share of a fragment is fetched in the same round trip, the shares are added in share
+// order; `keep` (lane's row of the summed operand, or null) receives the sum for the products behind the launch.
+__device__ __forceinline__ void pb_gemm1_shares(f32x16& acc, const float* abase, long aidx, long sstride, int ns, const float* bp,
+                                                int K, int wave, float* keep) {
+  const int G = K / 8;
+  if (G == 8 * PB_WAVES) {
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, 0x7fffffff, 0x00020000);
+    const int vo = (int)((aidx + (long)wave * 8) * 4);
+    const float* bq = bp + (long)wave * 8;
+    pd_v4u r[3][8];
+    float4 b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      b[u] = *reinterpret_cast<const float4*>(bq + u * PB_WAVES * 8);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        r[q][u] = __builtin_amdgcn_raw_buffer_load_b128(ars, vo + (int)((q < ns ? q : 0) * sstride * 4), u * PB_WAVES * 32, 16 /* sc1 */);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float4 v = make_float4(__uint_as_float(r[0][u].x), __uint_as_float(r[0][u].y), __uint_as_float(r[0][u].z), __uint_as_float(r[0][u].w));
+#pragma unroll
+      for (int q = 1; q < 3; ++q)
+        if (q < ns) {
+          v.x += __uint_as_float(r[q][u].x); v.y += __uint_as_float(r[q][u].y);
+          v.z += __uint_as_float(r[q][u].z); v.w += __uint_as_float(r[q][u].w);
+        }
+      if (keep) *reinterpret_cast<float4*>(keep + (wave + u * PB_WAVES) * 8) = v;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b[u].w, acc, 0, 0, 0);
+    }
+  } else {
+#pragma clang loop unroll(disable)
+    for (int g = wave; g < G; g += PB_WAVES) {
+      const float4 b = *reinterpret_cast<const float4*>(bp + (long)g * 8);
+      float4 v = ld_sc1_4(abase, aidx + (long)g * 8);
+      for (int q = 1; q < ns; ++q) {
+        const float4 w = ld_sc1_4(abase, aidx + q * sstride + (long)g * 8);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      if (keep) *reinterpret_cast<float4*>(keep + g * 8) = v;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc, 0, 0, 0);
+    }
+  }
+}
 __device__ __forceinline__ void pb_gemm(f32x16& acc, const float* abase, long aidx, const float* bp, int K, int wave) {
   const int G = K / 8;
   constexpr int STEP = 8 * PB_WAVES;
@@ -754,8 +806,11 @@ __device__ void role_ra(const PbParams& p, int slice, PbSmem& sm) {
       }
     }
     if (t < p.Tc - 1) {
-      if (!pd_wait(p.cnt + PB_C_RC * p.Tc + (t + 1), (unsigned)p.N, p.abort_word, p.spin_limit, &sm.flag)) return;
-      pb_gemm1(acc, p.dqd, (long)arow * p.Tc * A + (long)(t + 1) * A + 4 * lh, b_att, A, wave);   // A <= 512 (decode_persist_bwd_ok)
+      if (!pd_wait(p.cnt + PB_C_RC * p.Tc + (t + 1), (unsigned)(p.N * p.rc_splits), p.abort_word, p.spin_limit, &sm.flag)) return;
+      const long qidx = (long)arow * p.Tc * A + (long)(t + 1) * A + 4 * lh;
+      if (p.rc_splits == 1) pb_gemm1(acc, p.dqd, qidx, b_att, A, wave);   // A <= 512 (decode_persist_bwd_ok)
+      else pb_gemm1_shares(acc, p.dqd_part, qidx, (long)p.N * p.Tc * A, p.rc_splits, b_att, A, wave,
+                           (slice == 0 && li < p.N) ? p.dqd + qidx : nullptr);
       pb_stash(sm.red, acc, wave, li, lh);
       __syncthreads();
 #pragma unroll
@@ -815,11 +870,17 @@ __device__ void role_rb(const PbParams& p, int slice, PbSmem& sm) {
 }
 
 // ---------------------------------------------------------------- RC: attention backward of clip n (attention.hip: score / accum / reduce)
-// thread = channel a (A, E <= 512): the clip's projected memory in LDS, its memory rows and the running sums of d encproj for
-// all S <= 64 frames in registers.  The memory's own gradient, sum_t w[t][s] dctx[t][e], needs no recurrence: dctx is kept
-// per step and attn_dmem_kernel forms it behind the launch.
-__device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
-  const int S = p.S, A = p.A, E = p.E;
+// thread = channel a (A, E <= 512): the projected memory of the workgroup's frames in LDS, their memory rows and the running sums
+// of d encproj in registers - 64 frames per workgroup.  The memory's own gradient, sum_t w[t][s] dctx[t][e], needs no
+// recurrence: dctx is kept per step and attn_dmem_kernel forms it behind the launch.
+// Round 4: clips of more than 64 frames (BASELINE configs[3]: S = 187) are split over p.rc_splits = ceil(S / 64) workgroups,
+// share j owning frames 64 j .. 64 j + 63.  The softmax backward's only sum over ALL frames, sum_s w[s] dw[s], equals
+// <dctx, ctx> (dw[s] = dctx . mem[s], ctx = sum_s w[s] mem[s]: the forward's context, saved in rnn_d), so the shares never
+// talk to each other: each hands over its part of dq[t] and the reader (RA) adds the shares in share order.
+__device__ void role_rc(const PbParams& p, int n, int share, float* smem, int* s_flag) {
+  const int A = p.A, E = p.E;
+  const int s0 = share * 64, S = min(64, p.S - s0);          // this workgroup's frames: s0 .. s0 + S - 1
+  const bool split = p.rc_splits > 1;
   float* w_s = smem;                  // [64]
   float* ds_s = smem + 64;            // [64]
   float* dwred = smem + 128;          // [8][64]
@@ -829,7 +890,7 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
   const int a = threadIdx.x;
   const int len = (int)p.mem_lens[n];
   for (int i = threadIdx.x * 4; i < S * A; i += PB_THREADS * 4)
-    *reinterpret_cast<float4*>(Pl + i) = *reinterpret_cast<const float4*>(p.encproj + (long)n * S * A + i);
+    *reinterpret_cast<float4*>(Pl + i) = *reinterpret_cast<const float4*>(p.encproj + ((long)n * p.S + s0) * A + i);
   // dw[s] = dctx . mem[s] with lanes over the frames: thread (wave w, lane s) holds mem[s][64 w .. 64 w + 63] and sums its 64
   // products in registers - no cross-lane reduction (62 wave-wide shuffle reductions per step cost 8 us here); the eight
   // wave shares meet in LDS.  The running sums of d encproj stay per channel: thread a, all frames.
@@ -837,15 +898,23 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
 #pragma unroll
   for (int k = 0; k < 64; ++k) {
     const int e = wave * 64 + k;
-    m[k] = (lane < S && e < E) ? p.mem[((long)n * S + lane) * E + e] : 0.f;
+    m[k] = (lane < S && e < E) ? p.mem[((long)n * p.S + s0 + lane) * E + e] : 0.f;
     dPa[k] = 0.f;
   }
   const float va = a < A ? p.att_v[a] : 0.f;
   float dva = 0.f;
+  float* dq_out = split ? p.dqd_part + (long)share * p.N * p.Tc * A : p.dqd;
   __syncthreads();
   for (int t = p.Tc - 1; t >= 0; --t) {
     const float qa = a < A ? p.qd[(long)n * p.Tc * A + (long)t * A + a] : 0.f;
-    if (threadIdx.x < S) w_s[threadIdx.x] = p.attn_w[(long)n * p.Tc * S + (long)t * S + threadIdx.x];
+    if (threadIdx.x < S) w_s[threadIdx.x] = p.attn_w[(long)n * p.Tc * p.S + (long)t * p.S + s0 + threadIdx.x];
+    // split: the forward context of the step (lane l of wavefront 0: elements l, l + 64, ..), fetched ahead of the wait
+    float cx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (split && wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (lane + 64 * k < E) cx[k] = p.ctx[(long)n * p.Tc * 3 * E + (long)t * 3 * E + lane + 64 * k];
+    }
     if (!pd_wait(p.cnt + PB_C_RB * p.Tc + t, (unsigned)p.n_rb, p.abort_word, p.spin_limit, s_flag)) return;
     {   // the step's context gradient: the K-split partials of RB in split order; kept per step for attn_dmem_kernel
       float dc = 0.f;
@@ -855,7 +924,7 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
         for (int q = 0; q < 4; ++q)
           if (q < p.ks_rb) pv[q] = ld_sc1(p.dctx_part + ((long)q * p.N + n) * E + a);
         dc = ((pv[0] + pv[1]) + pv[2]) + pv[3];
-        p.dctx[(long)n * p.Tc * E + (long)t * E + a] = dc;
+        if (share == 0) p.dctx[(long)n * p.Tc * E + (long)t * E + a] = dc;
       }
       dc_s[a] = dc;
     }
@@ -879,8 +948,16 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
         for (int q = 0; q < 8; ++q) dw += dwred[q * 64 + s];
         w = w_s[s];
       }
-      const float dot = wave_sum(w * dw);
-      if (s < S) ds_s[s] = (s < len) ? w * (dw - dot) : 0.f;
+      float dot;
+      if (split) {                      // sum over ALL frames of the clip = <dctx, ctx>
+        float pd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pd += (lane + 64 * k < E) ? dc_s[lane + 64 * k] * cx[k] : 0.f;
+        dot = wave_sum(pd);
+      } else {
+        dot = wave_sum(w * dw);
+      }
+      if (s < S) ds_s[s] = (s0 + s < len) ? w * (dw - dot) : 0.f;
     }
     __syncthreads();
     float dq = 0.f;
@@ -896,15 +973,15 @@ __device__ void role_rc(const PbParams& p, int n, float* smem, int* s_flag) {
           dva += g * th;
         }
       }
-      st_sc1(p.dqd + (long)n * p.Tc * A + (long)t * A + a, dq);
+      st_sc1(dq_out + (long)n * p.Tc * A + (long)t * A + a, dq);
     }
     pd_arrive(p.cnt + PB_C_RC * p.Tc + t);          // (its barrier also protects w_s / ds_s / dwred against the next step's writes)
   }
   if (a < A) {
 #pragma unroll
     for (int k = 0; k < 64; ++k)
-      if (k < S) p.dencproj[((long)n * S + k) * A + a] = dPa[k];
-    p.dvpart[(long)n * A + a] = dva;
+      if (k < S) p.dencproj[((long)n * p.S + s0 + k) * A + a] = dPa[k];
+    p.dvpart[((long)share * p.N + n) * A + a] = dva;         // [rc_splits][N][A]: summed with the rows by the caller's column sum
   }
 }
 
@@ -1050,8 +1127,11 @@ __global__ __launch_bounds__(PB_THREADS) void decode_persist_bwd_kernel(PbParams
   b -= p.n_ra;
   if (b < p.n_rb) { role_rb(p, b, sm); return; }
   b -= p.n_rb;
-  if (b < p.N) { role_rc(p, b, reinterpret_cast<float*>(pb_smem_raw) + 4, reinterpret_cast<int*>(pb_smem_raw)); return; }
-  b -= p.N;
+  if (b < p.N * p.rc_splits) {
+    role_rc(p, b / p.rc_splits, b % p.rc_splits, reinterpret_cast<float*>(pb_smem_raw) + 4, reinterpret_cast<int*>(pb_smem_raw));
+    return;
+  }
+  b -= p.N * p.rc_splits;
   if (b < p.n_pa) { role_pa(p, b, sm); return; }
   b -= p.n_pa;
   role_pb(p, b, sm);
@@ -1376,22 +1456,24 @@ int decode_persist_fwd(PdParams p, hipStream_t st, int flags) {
 // ---- decode backward
 static size_t decode_bwd_shm(int S, int A) {
   size_t shm = sizeof(PbSmem);
-  const size_t att = (size_t)(4 + 128 + 512 + 512 + (long)S * A) * sizeof(float);
+  const size_t att = (size_t)(4 + 128 + 512 + 512 + (long)(S < 64 ? S : 64) * A) * sizeof(float);   // 64 frames per attention workgroup
   return att > shm ? att : shm;
 }
+int decode_persist_bwd_rc_splits(int S) { return (S + 63) / 64; }
 static void decode_bwd_splits(int E, int H, int& ks_rb, int& ks_pa) {
   // K-splits: one resident batch (K <= 512) per workgroup where the K of the product divides that way, at most 4
   ks_rb = (3 * H) % 512 == 0 && 3 * H / 512 <= 4 ? 3 * H / 512 : 1;
   ks_pa = E == 512 ? 2 : 1;               // K = 4Hp = 2048 = 2 x 1024 and 2E = 1024: the shapes the split products are written for
 }
 bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A) {
-  // the attention role keeps a clip's frames in 2 x 32 register slots and its channels in 512 thread columns
-  if (!(decode_fwd_shape_ok(N, Tc, S, E, H, A) && S <= 64 && E <= 512 && A <= 512 && H % 32 == 0 && H == E &&
-        (size_t)(4 + 128 + 512 + 512 + (long)S * A) * sizeof(float) <= 150 * 1024))
+  // an attention workgroup keeps 64 frames in 2 x 32 register slots and its channels in 512 thread columns; a clip takes up to
+  // three of them (S <= 192: BASELINE configs[3] has 187)
+  if (!(decode_fwd_shape_ok(N, Tc, S, E, H, A) && S <= 192 && E <= 512 && A <= 512 && H % 32 == 0 && H == E &&
+        decode_bwd_shm(S, A) <= 150 * 1024))
     return false;
   int ks_rb, ks_pa;
   decode_bwd_splits(E, H, ks_rb, ks_pa);
-  const int grid = H / 32 + (E / 32) * ks_rb + N + (E / 16) * ks_pa + E / 32;
+  const int grid = H / 32 + (E / 32) * ks_rb + N * decode_persist_bwd_rc_splits(S) + (E / 16) * ks_pa + E / 32;
   return persist_fits(decode_persist_bwd_kernel, PK_DECODE_BWD, grid, decode_bwd_shm(S, A));
 }
 long decode_persist_bwd_counter_words(int Tc) { return ((long)PB_C_COUNT * Tc + 1 + 3) & ~3L; }
@@ -1401,9 +1483,11 @@ int decode_persist_bwd(PbParams p, hipStream_t st, int flags) {
   if (!decode_persist_bwd_ok(p.N, p.Tc, p.S, p.E, p.H, p.A)) return ACVAE_EUNSUPPORTED;
   decode_bwd_splits(p.E, p.H, p.ks_rb, p.ks_pa);
   p.n_ra = p.H / 32; p.n_rb = (p.E / 32) * p.ks_rb; p.n_pa = (p.E / 16) * p.ks_pa; p.n_pb = p.E / 32;
+  p.rc_splits = decode_persist_bwd_rc_splits(p.S);
+  if (p.rc_splits > 1 && (!p.dqd_part || !p.ctx)) return ACVAE_EINVAL;
   const long words = decode_persist_bwd_counter_words(p.Tc);
   p.abort_word = p.cnt + (long)PB_C_COUNT * p.Tc;
-  int grid = p.n_ra + p.n_rb + p.N + p.n_pa + p.n_pb;
+  int grid = p.n_ra + p.n_rb + p.N * p.rc_splits + p.n_pa + p.n_pb;
   persist_test_stall(flags, grid, p.spin_limit);
   const long R = (long)p.N * p.Tc;
   PoisonList poison{};

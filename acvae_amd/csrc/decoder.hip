@@ -154,7 +154,7 @@ struct DecLayout {
   // bwd scratch
   long wt_ln;
   long d_out, dgi, dgh, dqd, dencproj, dvpart, dctx, dh_a, dh_b, dgates, dml_all, dml, dhp_a, dhp_b, dc_a, dc_b, dlz_a, pd_part,
-      dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, pd_cnt_b, scratch_bwd;
+      dlz_b, drnn, dz_dec, dqp, dmem, dhid, words_c, tn, dpart, attws, pd_cnt_b, pd_dqd, scratch_bwd;
   // bwd scratch private to the prior chain (it may run on the second stream)
   long dencproj_p, dvpart_p, dmem_p, drnn_p, tn_p, dpart_p, attws_p;
   long attws_bytes;
@@ -194,7 +194,8 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   b.take(acvae_skinny_ws_floats());
   L.wt_ln = b.take((long)Eenc * E);
   L.d_out = b.take(R * H); L.dgi = b.take(R * 3 * H); L.dgh = b.take(R * 3 * H); L.dqd = b.take(R * A);
-  L.dencproj = b.take((long)N * S * (A > E ? A : E)); L.dvpart = b.take((long)N * (A > E ? A : E));
+  L.dencproj = b.take((long)N * S * (A > E ? A : E));
+  L.dvpart = b.take((long)3 * N * (A > E ? A : E));             // up to three frame shares per clip (persistent BPTT, S > 64)
   L.dctx = b.take((long)N * E); L.dh_a = b.take((long)N * H); L.dh_b = b.take((long)N * H);
   L.dgates = b.take(R * 4 * Hp); L.dml_all = b.take(R * 2 * E); L.dml = b.take((long)N * 2 * E);
   L.dhp_a = b.take((long)N * Hp); L.dhp_b = b.take((long)N * Hp); L.dc_a = b.take((long)N * Hp);
@@ -227,6 +228,7 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   }
   L.pd_cnt_b = b.take(acvae::decode_persist_bwd_counter_words(Tc));   // arrival counters of the persistent BPTT launch
   L.pd_part = b.take(acvae::decode_persist_bwd_part_floats(N, E, H));  // its K-split partial tiles
+  L.pd_dqd = b.take(S > 64 && S <= 192 ? (long)acvae::decode_persist_bwd_rc_splits(S) * R * A : 0);   // d qd shares of the split attention role
   L.scratch_bwd = b.off;
   return ACVAE_OK;
 }
@@ -808,6 +810,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   };
   float* drnn = sc + L.drnn;
   float* dz_dec = sc + L.dz_dec;
+  int dv_rows = N;                 // rows of dvpart (the persistent BPTT of long clips writes one row per frame share)
   auto dec_bptt = [&](int t) -> int {
     ACVAE_TRY(acvae::gru_bwd(dh, H, d_out + (long)t * H, (long)Tc * H, gru_save + (long)t * 4 * H, (long)Tc * 4 * H,
                              hprev_d + (long)t * H, (long)Tc * H, dgi + (long)t * 3 * H, (long)Tc * 3 * H,
@@ -838,7 +841,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(gemm_tn(dqd, A, hprev_d, H, G(TP_DEC_ATT_W), E + H, A, H, R, ws, c));
     ACVAE_TRY(gemm_tn(dencproj, A, mem, E, G(TP_DEC_ATT_W) + H, E + H, A, E, N * S, ws, c));
     ACVAE_TRY(acvae::colsum2(dencproj, N * S, A, dp, G(TP_DEC_ATT_B), nullptr, 0, c));
-    ACVAE_TRY(acvae::colsum2(dvpart, N, A, dp, G(TP_DEC_ATT_V), nullptr, 0, c));
+    ACVAE_TRY(acvae::colsum2(dvpart, dv_rows, A, dp, G(TP_DEC_ATT_V), nullptr, 0, c));
     // d(rnn_input) for the embedding and z columns
     ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, c));                    // d emb
     if (emb_keep)          // back through the word-embedding dropout
@@ -964,8 +967,10 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     pb.dencproj = dencproj; pb.dmem = dmem; pb.dvpart = dvpart; pb.dgates = dgates; pb.dml_all = dml_all; pb.dhp = dhp;
     pb.dctx_part = sc + L.pd_part; pb.dhp_part = pb.dctx_part + 4L * N * E; pb.dml_part = pb.dhp_part + 4L * N * E;
     pb.cnt = (unsigned*)(sc + L.pd_cnt_b);
+    pb.dqd_part = sc + L.pd_dqd; pb.ctx = rnn_d + E;
     pb.N = N; pb.Tc = Tc; pb.S = S; pb.E = E; pb.H = H; pb.A = A;
     ACVAE_TRY(acvae::decode_persist_bwd(pb, st.s, flags));
+    dv_rows = N * acvae::decode_persist_bwd_rc_splits(S);
     ACVAE_TRY(dec_memgrad());
     if (fork.on()) ACVAE_TRY(Fork::edge(st.s, sp.s));     // the prior's batched work reads what the launch wrote
     ACVAE_TRY(prior_memgrad());

@@ -1,11 +1,11 @@
 """Driver-visible records of BASELINE configs[3] and configs[4], written as JSON under gpurun_out/
 (copy into profiles/):
 
-  r03_c4_t3000.json  configs[3]: long-audio stress B=16, T=3000 (S=187 encoder frames): full optimiser step ms (fp32 and
+  r04_c4_t3000.json  configs[3]: long-audio stress B=16, T=3000 (S=187 encoder frames): full optimiser step ms (fp32 and
                      bf16 conv stack) and the attention kernels' achieved bytes/s - per decode step the decoder attention
                      reads, for each of the 16 clips, encproj [S,A] + mem [S,E] fp32 once (2 * 187 * 512 * 4 B = 766 KB per
                      clip and step, served by L2 / Infinity Cache), measured with HIP events around acvae_attn_fwd / _bwd.
-  r03_infer_records.json     configs[4]: captions/s of the inference twin through evaluate(): greedy, N=5 z-samples per clip,
+  r04_infer_records.json     configs[4]: captions/s of the inference twin through evaluate(): greedy, N=5 z-samples per clip,
                      beam (3), diverse beam search (5 groups), and method="sample".
 """
 import json, os, sys, time
@@ -97,7 +97,7 @@ def c4():
                     d["kernel_calls"] = int(r["Calls"])
                     if "algorithmic_bytes" in d:
                         d["kernel_GB_per_s"] = d["algorithmic_bytes"] / d["kernel_us"] / 1e3
-    json.dump(rec, open(os.path.join(OUT, "r03_c4_attn_only.json" if which == "attn" else "r03_c4_t3000.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(OUT, "r03_c4_attn_only.json" if which == "attn" else "r04_c4_t3000.json"), "w"), indent=1)
     print(json.dumps(rec))
 
 
@@ -122,7 +122,7 @@ def infer():
         ncap = sum(len(p.get("captions", [0])) for p in out["predictions"])
         rec["runs"].append({"method": method, "beam_size_or_samples": bs, **extra, "clips": len(n_items), "captions": ncap,
                             "seconds": dt, "clips_per_s": len(n_items) / dt, "captions_per_s": ncap / dt})
-    json.dump(rec, open(os.path.join(OUT, "r03_infer_records.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(OUT, "r04_infer_records.json"), "w"), indent=1)
     print(json.dumps(rec))
 
 
