@@ -81,42 +81,65 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const float* __
   __syncthreads();
   const int tile = blockIdx.y * gridDim.x + blockIdx.x;
   float* my = slabs + ((long)tile * S + z) * 1024;
+  // Split-K hand-off without fences (round 4; an agent release fence writes back the XCD's whole L2 and the acquire
+  // invalidates the CU's L1 - measured on the column-sum kernel: 6-10 us per launch): the partial tile is stored write-through
+  // (8-byte agent-scope atomic stores, `sc1`), every wave drains its stores, ONE lane takes the ticket behind the barrier, and
+  // the block whose ticket came last reads all S partial tiles with agent-scope loads (`sc1`: never from its L1) - the first
+  // row of MI355X_MICROARCH.md's table of hand-offs measured with `sc1` loads in place of the acquire.
   if (S > 1) {
-    for (int e = threadIdx.x; e < 1024; e += SK_THREADS) {
-      float v = 0.f;
+    {
+      const int e = threadIdx.x * 2;                 // SK_THREADS = 512: one pair of neighbours per thread
+      float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-      for (int w = 0; w < SK_WAVES; ++w) v += red[w][e >> 5][e & 31];
-      my[e] = v;
+      for (int w = 0; w < SK_WAVES; ++w) { v0 += red[w][e >> 5][e & 31]; v1 += red[w][e >> 5][(e & 31) + 1]; }
+      const unsigned long long bits = (unsigned long long)__float_as_uint(v0) | ((unsigned long long)__float_as_uint(v1) << 32);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(my + e), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned t = __hip_atomic_fetch_add(&cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = (t == (unsigned)(S - 1));
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (last) __hip_atomic_store(&cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
+    // the S partial tiles in slice order, eight loads in flight
+    const float* base = slabs + (long)tile * S * 1024;
+    const int e = threadIdx.x * 2;
+    float v0 = 0.f, v1 = 0.f;
+    for (int q0 = 0; q0 < S; q0 += 8) {
+      unsigned long long b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        b[u] = q0 + u < S ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(base + (long)(q0 + u) * 1024 + e),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (q0 + u < S) { v0 += __uint_as_float((unsigned)b[u]); v1 += __uint_as_float((unsigned)(b[u] >> 32)); }
+    }
+    const int mm = e >> 5, m = m0 + mm;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int n = n0 + (e & 31) + k;
+      if (m < M && n < N) {
+        float v = k ? v1 : v0;
+        if (bias) v += bias[n];
+        float* p = C + (long)m * ldc + n;
+        if (accumulate) v += *p;
+        *p = v;
+      }
+    }
+    return;
   }
-  const float* base = slabs + (long)tile * S * 1024;
   for (int e = threadIdx.x; e < 1024; e += SK_THREADS) {
     const int mm = e >> 5, nn = e & 31;
     const int m = m0 + mm, n = n0 + nn;
     if (m < M && n < N) {
       float v = 0.f;
-      if (S > 1) {
-        for (int q = 0; q < S; ++q) v += base[(long)q * 1024 + e];
-      } else {
 #pragma unroll
-        for (int w = 0; w < SK_WAVES; ++w) v += red[w][mm][nn];
-      }
+      for (int w = 0; w < SK_WAVES; ++w) v += red[w][mm][nn];
       if (bias) v += bias[n];
       float* p = C + (long)m * ldc + n;
       if (accumulate) v += *p;

@@ -35,7 +35,8 @@ def counter(sub, name):
             if r["Counter_Name"] != name:
                 continue
             k = r["Kernel_Name"]
-            short = ("conv_wgrad" if ("conv_wgrad" in k or "conv_wino_wgrad" in k) else "conv_igemm" if ("conv_igemm" in k or "conv_wino_kernel" in k) else None)
+            short = ("conv_wgrad" if ("conv_wgrad" in k or "conv_wino_wgrad" in k) else "conv_igemm" if ("conv_igemm" in k or "conv_wino_kernel" in k or "conv_wino_act_kernel" in k
+                                                                               or "conv_wino_stats_kernel" in k) else None)
             if short:
                 per[short].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
@@ -55,7 +56,8 @@ for k in ("conv_igemm", "conv_wgrad"):
               "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
 wino = not bf16 and os.environ.get("ACVAE_CONV_WINO", "1") != "0"
 res["kernel"] = ("conv_igemm_bf16_kernel<128|64> (bf16 storage, v_mfma_f32_32x32x16_bf16)" if bf16 else
-                 "conv_wino_kernel (conv3x3 as Winograd F(2x2,3x3), forward + data gradient)" if wino else
+                 "conv_wino_kernel / _stats_kernel / _act_kernel (conv3x3 as Winograd F(2x2,3x3): data gradient / forward / forward with BatchNorm + ReLU "
+                 "on the operand; all 14 launches of a step averaged)" if wino else
                  "conv_igemm3_kernel<128|64> (conv3x3 implicit GEMM with horizontal-tap reuse, forward + data gradient)")
 res["hbm_bytes_per_launch"] = res["conv_igemm"]["hbm_bytes_per_launch"]
 # one read of the conv input + one write of its output + the weights, over the 14 launches of a step at B=32, T=1000
