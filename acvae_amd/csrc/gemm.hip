@@ -323,7 +323,10 @@ extern "C" int acvae_gemm_nt(const float* A, int64_t lda, const float* B, int64_
 
 static int tn_splits(int M, int N, int K) {
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-  int s = (int)(1024 / (tiles > 0 ? tiles : 1));
+  // one round of workgroups (256 CUs, two blocks per CU would fit): these products run on the second stream beside the
+  // MFMA-bound encoder backward, where more slices only mean more slab traffic (347 MB per step with the earlier target of
+  // 1024 workgroups, 139 MB now) and a reduce launch for the three largest products that no longer need one
+  int s = (int)(256 / (tiles > 0 ? tiles : 1));
   const int maxs = cdiv(K, 4 * BKT);  // at least 64 k per slice
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
