@@ -5,9 +5,13 @@
 //
 //   Y = At [ sum_ci (G g G^T) .* (Bt d B) ] A      d: 4x4 input window, g: 3x3 filter, Y: 2x2 outputs
 //
-// One workgroup = 64 output tiles (R tile rows x TW tile columns of ONE clip, TW = W/2, R = 64/TW) x 64 output channels
-// x all 16 transform positions: 16 GEMMs [64 tiles x Cin] x [Cin x 64] whose 65536 accumulators fill the accumulation
-// registers of the CU (8 wavefronts x 128).  Nothing transformed ever touches HBM or LDS:
+// One workgroup = 32 output tiles (R tile rows x TW tile columns of ONE clip, TW = W/2, R = 32/TW) x 64 output channels
+// x all 16 transform positions: 16 GEMMs [32 tiles x Cin] x [Cin x 64] on FOUR wavefronts of 128 accumulators (248-252
+// registers each), so that TWO workgroups share a CU (one wavefront of each per SIMD).  Until round 4 one workgroup of eight
+// wavefronts (64 tiles) had the CU to itself, and its prologue (first window from HBM: 1.4-2.6 us), its epilogue (2.0-2.4 us)
+// and the dispatch gap behind it (0.5 us) ran with the matrix pipes idle - 19 % of a 64-channel workgroup, 3 % of a
+// 512-channel one (in-kernel timeline, profiles/r04_wino_lab.txt).  With two independent workgroups per CU the one's
+// main loop runs under the other's prologue / epilogue.  Nothing transformed ever touches HBM or LDS:
 //   * the activation window (2R+2 pixel rows x W+2 columns, 16 channels per stage) is staged ONCE, with the previous
 //     layer's BatchNorm+ReLU and the zero padding applied on the way, into four (row parity, column parity) planes, so
 //     that the 16 tiles a 16-lane LDS read group serves are 16 consecutive 16-byte slots;
@@ -29,43 +33,46 @@
 namespace {
 using namespace mfma;
 
-constexpr int WN_THREADS = 512;
-constexpr int WN_TILES = 64;      // output tiles (2x2 pixels each) per workgroup
+constexpr int WN_THREADS = 256;
+constexpr int WN_TILES = 32;      // output tiles (2x2 pixels each) per workgroup
 constexpr int WN_TN = 64;         // output channels per workgroup
 // activation window in LDS, float4 slots: [quad WN_SQ][row parity WN_SR][column parity WN_SC][row (R+1)][col RW]; a plane
-// holds (R+1)*RW <= 99 slots.  The strides are padded so that the 16 lanes of a staging write (4 pixels x 4 quads) land in
+// holds (R+1)*RW <= 66 slots.  The strides are padded so that the 16 lanes of a staging write (4 pixels x 4 quads) land in
 // 16 different 16-byte bank groups: WN_SC = 2 (mod 4) spreads the 4 pixels, WN_SQ = 4 (mod 16) the quads.
-constexpr int WN_SC = 102, WN_SR = 2 * WN_SC, WN_SQ = 420;
+constexpr int WN_SC = 66, WN_SR = 2 * WN_SC, WN_SQ = 276;
 constexpr int WN_BCHUNK = 16 * 2 * 64;   // float4 per weight chunk image: [position][k half][column]
 constexpr int WN_MAXC = 2048;            // input channels whose BatchNorm scale / shift fit the LDS copy of the ACT kernel
+#ifndef WN_PF_DIST
+#define WN_PF_DIST 64                    // prefetch distance in the XCD's run of tiles (2 workgroups on each of its 32 CUs)
+#endif
 
-// LDS: four separate arrays, not one struct with a run-time buffer index: the compiler orders an LDS-DMA against later
-// LDS reads of the SAME wave by itself and waits (vmcnt) before any read it cannot prove disjoint from the DMA's
-// destination - with distinct __shared__ objects selected at compile time (loop unrolled over the buffer parities) the
-// reads of chunk c no longer wait for the DMA of chunk c + 1 issued just before them.
-constexpr int WN_RAWBUF = 4 * WN_SQ;        // float4 per stage buffer (26880 B); weight chunk buffer: [(pos*2 + h)*64 + col] (32768 B)
+// LDS: the two window buffers (one array, 2 x 17664 B); the epilogue's exchange (4 wavefronts x 8 KB) and the BatchNorm sums
+// (1 KB) reuse them behind the main loop.  With the ACT build's 16 KB of scale / shift: 51 KB per workgroup, two per CU.
+constexpr int WN_RAWBUF = 4 * WN_SQ;        // float4 per stage buffer
+constexpr int WN_EX_F4 = 4 * 512;           // float4 of the exchange area: [wavefront 4][row 32][lane 64] floats
+static_assert(WN_EX_F4 + 64 <= 2 * WN_RAWBUF, "exchange + sums must fit the window buffers");
 
-// Tile (row of the block, column) of MFMA row `row` (0..31, = lane & 31 of the A operand) of tile half mh.  A ds_read_b128
+// Tile (row of the block, column) of MFMA row `row` (0..31, = lane & 31 of the A operand).  A ds_read_b128
 // is served in four groups of 16 lanes - NOT consecutive ones: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32
 // (MI355X_MICROARCH.md, LDS table) - and the 16 tiles of a group must sit in 16 different 16-byte bank groups.  So the
 // lane is first mapped to (group, rank in the group); then TW >= 16: a group reads 16 neighbours of one tile row; TW < 16:
-// it reads 16/TW tile rows `rstep` apart, chosen with the row pitch RW so that their slots tile the 256-byte bank span
-// (TW = 8: RW = 10, rows r, r+4 -> 0 / 128 B; TW = 4: RW = 5, rows r+4k -> 64 B apart; TW = 2: RW = 3, rows r+2k -> 32 B).
-__device__ __forceinline__ void wino_tile(int mh, int row, int tw_shift, int& tyl, int& tx) {
+// group g reads the 16/TW tile rows g, g + 2, g + 4 ..., and the row pitch RW is chosen so that their slots tile the 256-byte
+// bank span (TW = 8: RW = 12, rows 2 apart -> 384 = 128 B mod 256; TW = 4: RW = 6 -> 192 B; TW = 2: RW = 3 -> 96 B steps).
+__device__ __forceinline__ void wino_tile(int row, int tw_shift, int& tyl, int& tx) {
   // 4-lane blocks 0..7 -> group * 16 + first rank: 0, 16, 20, 4, 24, 8, 12, 28
   const int cell = (int)((0x1c0c081804141000ULL >> (8 * (row >> 2))) & 0xff) + (row & 3);
   if (tw_shift >= 4) {
-    const int m = mh * 32 + cell;
-    tyl = m >> tw_shift;
-    tx = m & ((1 << tw_shift) - 1);
+    tyl = cell >> tw_shift;
+    tx = cell & ((1 << tw_shift) - 1);
   } else {
     const int g = cell >> 4, l16 = cell & 15;
     tx = l16 & ((1 << tw_shift) - 1);
-    const int rsel = l16 >> tw_shift;
-    tyl = tw_shift == 1 ? mh * 16 + g + 2 * rsel : mh * 2 + g + 4 * rsel;
+    tyl = g + 2 * (l16 >> tw_shift);
   }
 }
-__host__ __device__ __forceinline__ int wino_row_pitch(int tw_shift) { return tw_shift == 3 ? 10 : (1 << tw_shift) + 1; }
+__host__ __device__ __forceinline__ int wino_row_pitch(int tw_shift) {
+  return tw_shift == 3 ? 12 : tw_shift == 2 ? 6 : (1 << tw_shift) + 1;
+}
 
 struct WinoParams {
   const float* X;       // [N][H][W][C]
@@ -76,16 +83,15 @@ struct WinoParams {
   float* partials;      // [blocks][2][Cout] or nullptr
   int N, H, W, C, Cout;
   int tw_shift;         // TW = W/2 = 1 << tw_shift
-  int R;                // tile rows per workgroup = 64 / TW
+  int R;                // tile rows per workgroup = 32 / TW
   int bpc;              // workgroups (row blocks) per clip = ceil(ceil(H/2) / R)
   // divisions of the prologue as multiply-shifts (the launcher computes the constants; every wavefront of every workgroup
   // ran ~7 integer divisions by run-time values, ~30 instructions each, before its first load - round 4 timeline: 0.8 us of a
   // 22 us workgroup on the 64-channel layers)
-  unsigned w2_magic;    // x / (W + 2) = (x * w2_magic) >> 16 for x < 1024
+  int w_shift;          // W = 1 << w_shift
   unsigned bpc_magic;   // x / bpc = umulhi(x, bpc_magic) for x < 2^20, bpc >= 2
   int nn_shift;         // log2(Cout / 64) when that is a power of two, else -1 (generic division)
 };
-__device__ __forceinline__ int wino_div_w2(int x, const WinoParams& p) { return (int)(((unsigned)x * p.w2_magic) >> 16); }
 // (row block, column block) of this workgroup: mfma_tile.h xcd_tile with the launcher's constants instead of divisions
 __device__ __forceinline__ void wino_xcd_tile(const WinoParams& p, int nm, int nn, int& bm, int& bn) {
   const int total = nm * nn;
@@ -169,7 +175,7 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
 }
 
 // Epilogue of both forward kernels: At . A in registers, the two position halves of a tile meet through LDS (`ex`: 8 KB per
-// wavefront, partner = vw ^ 1), raw output + BatchNorm partial sums.  vw = role index of the wavefront (XH = vw & 1).
+// wavefront, partner = wave ^ 1), raw output + BatchNorm partial sums.
 // Round 4: the epilogue was ~1100 instructions per wavefront (a tile-coordinate computation, a 64-bit address and a bounds
 // branch for each of a lane's 16 tiles) = 2.7 us of a 22 us workgroup on the 64-channel layers.  The 16 tiles of a lane are
 // four groups (k = r >> 2) of four tiles whose coordinates differ by a WAVE-UNIFORM step (wino_tile: cell = T[2k + h] + (r & 3),
@@ -181,9 +187,8 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
 // build leaves the 112 instructions of the sums out of its epilogue.
 template <int XH, bool STATS>
 __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 (&acc)[8], float* ex_mine, const float* ex_partner,
-                                              float* red, int mh, int nh, int li, int h, int lane, int n, int ty0, int bm,
-                                              int bn) {
-  const int tid = (mh * 2 + XH + nh * 4) * 64 + lane;          // = threadIdx.x, from the values taken afresh behind the main loop
+                                              float* red, int nh, int li, int h, int lane, int n, int ty0, int bm, int bn) {
+  const int tid = (XH + nh * 2) * 64 + lane;          // = threadIdx.x, from the values taken afresh behind the main loop
   const int H = p.H, W = p.W, Cout = p.Cout;
   float2 keep[16];
   float2* exm = reinterpret_cast<float2*>(ex_mine);
@@ -208,7 +213,7 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int tyl, tx;
-    wino_tile(mh, 8 * k + 4 * h, p.tw_shift, tyl, tx);
+    wino_tile(8 * k + 4 * h, p.tw_shift, tyl, tx);
     yk[k] = 2 * (ty0 + tyl) + XH;
     voff[k] = ((yk[k] * W + 2 * tx) * Cout + cout) * 4;
   }
@@ -243,14 +248,14 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
     s += __shfl_xor(s, 32, 64);
     qq += __shfl_xor(qq, 32, 64);
     if (h == 0) {
-      red[((mh * 2 + XH) * 2 + 0) * 64 + nh * 32 + li] = s;
-      red[((mh * 2 + XH) * 2 + 1) * 64 + nh * 32 + li] = qq;
+      red[(XH * 2 + 0) * 64 + nh * 32 + li] = s;
+      red[(XH * 2 + 1) * 64 + nh * 32 + li] = qq;
     }
     __syncthreads();
     if (tid < WN_TN) {
       float ts = 0.f, tq = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
+      for (int w = 0; w < 2; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
       float* out = p.partials + (long)bm * 2 * p.Cout + bn * WN_TN + tid;
       out[0] = ts;
       out[p.Cout] = tq;
@@ -260,13 +265,12 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
 
 // XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
 template <int XH, bool ACT, bool STATS>
-__device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1,
-                                               float4* scsh) {
+__device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* scsh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same value as a scalar (for the code behind the main loop)
   const int li = lane & 31, h = lane >> 5;
-  // wavefront roles: XH = wave & 1, mh = tile half, nh = column half
-  const int mh = (wave >> 1) & 1, nh = wave >> 2;
+  // wavefront roles: XH = wave & 1, nh = column half
+  const int nh = wave >> 1;
   int bm, bn;
   wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);
   const int RW = wino_row_pitch(p.tw_shift), R = p.R;
@@ -274,10 +278,17 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   const int H = p.H, W = p.W, C = p.C;
 
   // ---------------------------------------------------------------- staging items of this thread (fixed over stages)
-  // item e = tid + 512 j -> window pixel e / 4, channel quad e % 4 (= tid % 4)
-  const int W2 = W + 2;
-  const int nitems = (2 * R + 2) * W2 * 4;
+  // item e = tid + 256 j -> pixel e / 4 of the window's W real columns, channel quad e % 4 (= tid % 4): at most 4 rows x 64
+  // columns x 4 quads = 4 items per thread.  The two padding columns of the window never change: zeroed once, below.
+  const int nitems = ((2 * R + 2) << p.w_shift) * 4;
   const int q = tid & 3;
+  for (int i = tid; i < (2 * R + 2) * 8; i += WN_THREADS) {
+    const int ry = i >> 3, side = (i >> 2) & 1, qq = i & 3;
+    const int rx = side ? W + 1 : 0;
+    const int slot = qq * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1);
+    raw0[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    raw1[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   unsigned goff[4];          // element offsets into X (host side: the tensor has < 2^32 elements)
   int loff[4];
 #pragma unroll
@@ -285,11 +296,11 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
     const int e = tid + WN_THREADS * j;
     const bool lv = e < nitems;
     const int px = e >> 2;
-    const int ry = wino_div_w2(px, p), rx = px - ry * W2;
-    const int y = 2 * ty0 - 1 + ry, x = rx - 1;
-    const bool ok = lv && y >= 0 && y < H && x >= 0 && x < W;
+    const int ry = px >> p.w_shift, x = px & (W - 1), rx = x + 1;
+    const int y = 2 * ty0 - 1 + ry;
+    const bool ok = lv && y >= 0 && y < H;
     goff[j] = ok ? (unsigned)((((long)(n * H + y) * W + x) * C) + q * 4) : 0u;     // always a legal address
-    // Which items are zero padding (left / right pad columns, rows above / below the clip) does not change over the stages of a
+    // Which items are zero padding (rows above / below the clip) does not change over the stages of a
     // workgroup: their slots are zeroed ONCE in both buffers here, and afterwards these items - like the ones past the
     // window - write a slot nobody reads.  The staging code then has neither a branch nor a mask.
     const int slot = q * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1);
@@ -347,7 +358,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
       const_cast<float*>(p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4)), 0, 0x7fffffff, 0x00020000);
   // ---------------------------------------------------------------- this lane's tile and fragment addresses
   int tyl_a, tx_a;
-  wino_tile(mh, li, p.tw_shift, tyl_a, tx_a);
+  wino_tile(li, p.tw_shift, tyl_a, tx_a);
   const int abase = tyl_a * RW + tx_a;
   int rowoff[3];      // window rows XH, XH+1, XH+2 of the tile: plane (row parity) and row index
 #pragma unroll
@@ -504,15 +515,15 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int li_e = lane_e & 31, h_e = lane_e >> 5;
   const int tid_e = wave_s * 64 + lane_e;
-  const int mh_e = (wave_s >> 1) & 1, nh_e = wave_s >> 2;
+  const int nh_e = wave_s >> 1;
 
   // ---------------------------------------------------------------- prefetch for the workgroup that follows on this XCD
   // A workgroup's prologue waits out one HBM round trip for the first stage of its window (2-3 us under load: the tensor was
   // written by the previous kernel and is far larger than the caches) and, with one workgroup per CU, nothing runs under it.
-  // The XCD works through its run of tiles in dispatch order, 32 CUs at a time: the workgroup that starts when this one ends
-  // is, three times out of four, tile t + 32 of the run (in-kernel timeline, tools/lab_wino.py full) - and whichever CU of
+  // The XCD works through its run of tiles in dispatch order, 32 CUs x 2 workgroups at a time: the workgroup that starts when
+  // this one ends is most often tile t + WN_PF_DIST of the run (in-kernel timeline, tools/lab_wino.py full) - and whichever CU of
   // the XCD gets that tile, it reads through the same L2.  So, with its own loads done, every workgroup touches the first
-  // 128-byte line of each window pixel of tile t + 32 (channels 0-31: stages 0 and 1; one dword load per pixel, the value is
+  // 128-byte line of each window pixel of that tile (channels 0-31: stages 0 and 1; one dword load per pixel, the value is
   // discarded at the end of the epilogue): the line is on its way into the XCD's L2 while this epilogue runs.
   // Only where the operand carries no activation: the BatchNorm + ReLU build of this kernel sits exactly at 256 registers and
   // its main loop lost 2-6 % with the prefetch in the program (measured, same session: 5280 -> 5580 cycles per chunk on the
@@ -521,18 +532,18 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   float pfv = 0.f;
   if (!ACT) {
     const int nn_ = (int)gridDim.y;
-    const int t2 = bm * nn_ + bn + 32 * ((int)gridDim.x * nn_ >= 256 ? 1 : 0);
+    const int t2 = bm * nn_ + bn + WN_PF_DIST * ((int)gridDim.x * nn_ >= 8 * WN_PF_DIST ? 1 : 0);
     const int bm2 = p.nn_shift >= 0 ? t2 >> p.nn_shift : t2 / nn_;
     const int n2 = p.bpc == 1 ? bm2 : (int)__umulhi((unsigned)bm2, p.bpc_magic), ty2 = (bm2 - n2 * p.bpc) * R;
-    const int ry = wino_div_w2(tid_e, p), rx = tid_e - ry * W2;
-    const int y = 2 * ty2 - 1 + ry, x = rx - 1;
-    if (bm2 < (int)gridDim.x && bm2 != bm && ry < 2 * R + 2 && y >= 0 && y < H && x >= 0 && x < W)
+    const int ry = tid_e >> p.w_shift, x = tid_e & (W - 1);
+    const int y = 2 * ty2 - 1 + ry;
+    if (bm2 < (int)gridDim.x && bm2 != bm && ry < 2 * R + 2 && y >= 0 && y < H)
       pfv = p.X[((long)(n2 * H + y) * W + x) * C];        // default cache policy: the line is to stay in L2
   }
 
   // ---------------------------------------------------------------- epilogue
-  float* exb = reinterpret_cast<float*>(wave_s < 4 ? bw0 : bw1);        // [wave & 3][32][64 lanes]: 32 KB per array
-  wino_epilogue<XH, STATS>(p, acc, exb + (wave_s & 3) * 2048, exb + ((wave_s & 3) ^ 1) * 2048, reinterpret_cast<float*>(raw0), mh_e,
+  float* exb = reinterpret_cast<float*>(raw0);        // [wave][32][64 lanes] over both window buffers (raw1 follows raw0), then the sums
+  wino_epilogue<XH, STATS>(p, acc, exb + wave_s * 2048, exb + (wave_s ^ 1) * 2048, reinterpret_cast<float*>(raw0 + WN_EX_F4),
                            nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);
   if (!ACT) asm volatile("" :: "v"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved
 }
@@ -540,26 +551,23 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 // ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift); STATS: BatchNorm partial sums of the output.
 // Three builds: the data gradient (neither), a block's first convolution (statistics), its second one (both).
 template <bool ACT, bool STATS>
-__device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw0, float4* raw1, float4* bw0, float4* bw1,
-                                                float4* scsh) {
-  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT, STATS>(p, raw0, raw1, bw0, bw1, scsh);
-  else conv_wino_body<0, ACT, STATS>(p, raw0, raw1, bw0, bw1, scsh);
+__device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw, float4* scsh) {
+  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh);
+  else conv_wino_body<0, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh);
 }
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(WinoParams p) {
-  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
-  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  conv_wino_entry<false, false>(p, raw0, raw1, bw0, bw1, nullptr);
+// (256 threads, 2 wavefronts per SIMD): at most 256 registers per wavefront, so that two workgroups share a CU
+__global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoParams p) {
+  __shared__ float4 raw[2 * WN_RAWBUF];
+  conv_wino_entry<false, false>(p, raw, nullptr);
 }
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_stats_kernel(WinoParams p) {
-  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
-  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
-  conv_wino_entry<false, true>(p, raw0, raw1, bw0, bw1, nullptr);
+__global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_stats_kernel(WinoParams p) {
+  __shared__ float4 raw[2 * WN_RAWBUF];
+  conv_wino_entry<false, true>(p, raw, nullptr);
 }
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_act_kernel(WinoParams p) {
-  __shared__ float4 raw0[WN_RAWBUF], raw1[WN_RAWBUF];
-  __shared__ float4 bw0[WN_BCHUNK], bw1[WN_BCHUNK];
+__global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_act_kernel(WinoParams p) {
+  __shared__ float4 raw[2 * WN_RAWBUF];
   __shared__ float4 scsh[2 * WN_MAXC / 4];
-  conv_wino_entry<true, true>(p, raw0, raw1, bw0, bw1, scsh);
+  conv_wino_entry<true, true>(p, raw, scsh);
 }
 
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
@@ -674,7 +682,7 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   p.tw_shift = __builtin_ctz(TW);
   p.R = WN_TILES / TW;
   p.bpc = cdiv(cdiv(H, 2), p.R);
-  p.w2_magic = 65536u / (unsigned)(W + 2) + 1u;                       // exact for x < 1024 (W + 2 <= 66)
+  p.w_shift = p.tw_shift + 1;
   p.bpc_magic = (unsigned)((0x100000000ULL + (unsigned)p.bpc - 1) / (unsigned)p.bpc);   // ceil(2^32 / bpc): exact for x * bpc < 2^32
   const int nn = Cout / WN_TN;
   p.nn_shift = (nn & (nn - 1)) == 0 ? __builtin_ctz(nn) : -1;

@@ -82,7 +82,7 @@ VARIANTS["full"] += [
     ("if (lane == 0 && wave < 2) {", "if (lane == 0 && wave < 3) {"),
     ("  float* partials;      // [blocks][2][Cout] or nullptr", "  float* partials;\n  float* lab;"),
     ("p.Y = Y; p.partials = partials;", "p.Y = Y; p.partials = partials; p.lab = g_lab;"),
-    ("constexpr int WN_THREADS = 512;\n", "float* g_lab = nullptr;\nconstexpr int WN_THREADS = 512;\n"),
+    ("constexpr int WN_THREADS = 256;\n", "float* g_lab = nullptr;\nconstexpr int WN_THREADS = 256;\n"),
 ]
 NOPF = [("      pfv = p.X[((long)(n2 * H + y) * W + x) * C];        // default cache policy: the line is to stay in L2", "      pfv = 1.f;")]
 VARIANTS["fullnopf"] = VARIANTS["full"] + NOPF
@@ -109,6 +109,9 @@ VARIANTS["scalar"] = [
      '  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3")          // t0 - t2'),
 ]
 VARIANT_FLAGS = {"scalar": ["-fno-slp-vectorize"]}
+for _d in (16, 32, 48, 96):                      # prefetch distance in the XCD's run of tiles
+    VARIANTS[f"fullpf{_d}"] = VARIANTS["full"]
+    VARIANT_FLAGS[f"fullpf{_d}"] = [f"-DWN_PF_DIST={_d}"]
 
 
 def build(name):
@@ -119,7 +122,7 @@ def build(name):
         src = src.replace(old, new)
     os.makedirs(LAB, exist_ok=True)
     cpp = os.path.join(LAB, f"conv_wino_{name}.hip")
-    if name in ("full", "fullnopf", "fullpfact"):
+    if name.startswith("full"):
         src += '\nextern "C" void acvae_lab_set(float* p) { g_lab = p; }\n'
     open(cpp, "w").write(src.replace('#include "../../include/acvae_hip.h"', f'#include "{ROOT}/include/acvae_hip.h"'))
     obj = os.path.join(LAB, f"conv_wino_{name}.o")
@@ -162,7 +165,7 @@ def time_one():
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); fns["dgrad"](); b.record(); torch.cuda.synchronize()
-            nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
+            nwg = N * (((H + 1) // 2 + (64 // W) - 1) // (64 // W)) * (Cin // 64)
             t = dx.reshape(-1)[:nwg * 32].reshape(nwg, 8, 4)[:, 0, :].double().cpu()
             t0 = float(t[:, 0].min())
             st, en, cu = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01, t[:, 2].long()          # microseconds
@@ -175,9 +178,9 @@ def time_one():
                   f"workgroup {sum(durs) / len(durs):.1f} us (max {max(durs):.1f}); gap between two on one CU {sum(gaps) / max(1, len(gaps)):.2f} us (max {max(gaps or [0]):.1f}); "
                   f"last end {float(en.max()):.1f} us; main loop {float(t[:, 3].floor().mean()) * 0.01:.1f} us real per workgroup [after {warm} warm-up launches]")
           continue
-        if os.environ.get("ACVAE_DEV_LIB", "").endswith(("_full.so", "_fullnopf.so", "_fullpfact.so")):
+        if os.environ.get("ACVAE_DEV_LIB", "").rsplit("_", 1)[-1].startswith("full"):
             import ctypes
-            nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
+            nwg = N * (((H + 1) // 2 + (64 // W) - 1) // (64 // W)) * (Cin // 64)
             labbuf = torch.zeros(nwg, 3, 4, device="cuda")
             raw = ctypes.CDLL(os.environ["ACVAE_DEV_LIB"])
             raw.acvae_lab_set.argtypes = [ctypes.c_void_p]; raw.acvae_lab_set(labbuf.data_ptr())
@@ -229,7 +232,7 @@ def time_one():
                 fns["dgrad"]()
             b.record(); torch.cuda.synchronize()
             print(f"   call {a.elapsed_time(b) * 50:.0f} us (mean of 20 back to back)", end="; ")
-            nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * (Cin // 64)
+            nwg = N * (((H + 1) // 2 + (64 // W) - 1) // (64 // W)) * (Cin // 64)
             t = dx.reshape(-1)[:nwg * 32].reshape(nwg, 8, 4).double()
             cyc, real = t[:, :, 0].mean(), t[:, :, 1].mean()
             print(f"{Cin}->{Cout}@{W} dgrad: main loop {float(cyc):.0f} shader cycles in {float(real) * 10:.0f} ns -> in-kernel clock "
@@ -239,7 +242,7 @@ def time_one():
             for k in ("fwd_act", "dgrad"):
                 fns[k](); torch.cuda.synchronize()
                 buf = (y if k == "fwd_act" else dx).reshape(-1)
-                nwg = N * (((H + 1) // 2 + (128 // W) - 1) // (128 // W)) * ((Cin if k == "dgrad" else Cout) // 64)
+                nwg = N * (((H + 1) // 2 + (64 // W) - 1) // (64 // W)) * ((Cin if k == "dgrad" else Cout) // 64)
                 t = buf[:nwg * 32].reshape(nwg, 8, 4).double()
                 m = t.mean(dim=(0,))
                 print(f"{Cin}->{Cout}@{W} {k}: WGs {nwg} chunks {int(t[0,0,3])}; per wave (prologue, main, epilogue) cycles/100MHz-ticks: "
