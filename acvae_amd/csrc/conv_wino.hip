@@ -42,15 +42,19 @@ constexpr int WN_TN = 64;         // output channels per workgroup
 constexpr int WN_SC = 66, WN_SR = 2 * WN_SC, WN_SQ = 276;
 constexpr int WN_BCHUNK = 16 * 2 * 64;   // float4 per weight chunk image: [position][k half][column]
 constexpr int WN_MAXC = 2048;            // input channels whose BatchNorm scale / shift fit the LDS copy of the ACT kernel
+#ifndef WN_PRIO_EDGE
+#define WN_PRIO_EDGE 3                   // wavefront priority in prologue and epilogue (main loop: 0)
+#endif
 #ifndef WN_PF_DIST
 #define WN_PF_DIST 64                    // prefetch distance in the XCD's run of tiles (2 workgroups on each of its 32 CUs)
 #endif
 
-// LDS: the two window buffers (one array, 2 x 17664 B); the epilogue's exchange (4 wavefronts x 8 KB) and the BatchNorm sums
-// (1 KB) reuse them behind the main loop.  With the ACT build's 16 KB of scale / shift: 51 KB per workgroup, two per CU.
+// LDS: one array - the two window buffers (2 x 17664 B), then (ACT build) the scale / shift copy; the epilogue's exchange
+// (6 sets x 8 KB) and the BatchNorm sums (1 KB) overlay it behind the main loop.  50-52 KB per workgroup, two per CU.
 constexpr int WN_RAWBUF = 4 * WN_SQ;        // float4 per stage buffer
-constexpr int WN_EX_F4 = 4 * 512;           // float4 of the exchange area: [wavefront 4][row 32][lane 64] floats
-static_assert(WN_EX_F4 + 64 <= 2 * WN_RAWBUF, "exchange + sums must fit the window buffers");
+constexpr int WN_EX_F4 = 6 * 512;           // float4 of the exchange area: [set 6][row 16][lane 64] pairs
+constexpr int WN_LDS_F4 = WN_EX_F4 + 64;    // float4 of a workgroup's array
+static_assert(2 * WN_RAWBUF <= WN_LDS_F4 && 2 * WN_RAWBUF + 2 * WN_MAXC / 4 >= WN_LDS_F4, "exchange + sums overlay the window buffers (+ scale / shift)");
 
 // Tile (row of the block, column) of MFMA row `row` (0..31, = lane & 31 of the A operand).  A ds_read_b128
 // is served in four groups of 16 lanes - NOT consecutive ones: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32
@@ -167,6 +171,14 @@ __device__ __forceinline__ void wino_htrans_ip(float4 (&t)[4], float4 (&v)[4]) {
   v[2] = make_float4(c0[0], c0[1], c1[0], c1[1]);
   v[3] = make_float4(e0[0], e0[1], e1[0], e1[1]);
 }
+// first use of an accumulator: C = 0 as the instruction's inline constant instead of 16 v_mov per accumulator in the prologue
+__device__ __forceinline__ void mfma4_first(f32x16& c, float4 a, float4 b) {
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, z, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+}
 __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
@@ -174,47 +186,55 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
 }
 
-// Epilogue of both forward kernels: At . A in registers, the two position halves of a tile meet through LDS (`ex`: 8 KB per
-// wavefront, partner = wave ^ 1), raw output + BatchNorm partial sums.
-// Round 4: the epilogue was ~1100 instructions per wavefront (a tile-coordinate computation, a 64-bit address and a bounds
-// branch for each of a lane's 16 tiles) = 2.7 us of a 22 us workgroup on the 64-channel layers.  The 16 tiles of a lane are
-// four groups (k = r >> 2) of four tiles whose coordinates differ by a WAVE-UNIFORM step (wino_tile: cell = T[2k + h] + (r & 3),
-// T a multiple of 4): so the lane computes four byte offsets into its clip, the per-tile steps live in SGPRs, and the stores are
-// buffer stores (32-bit lane offset + scalar offset) against a descriptor of the CLIP whose size makes the hardware drop rows
-// past the clip's end - no address arithmetic, no branch per tile.  The LDS exchange moves both pixels of a tile in one
-// 8-byte access.
-// STATS: the launch also returns the BatchNorm partial sums of its raw output (forward convolutions); the data gradient's
-// build leaves the 112 instructions of the sums out of its epilogue.
-template <int XH, bool STATS>
-__device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 (&acc)[8], float* ex_mine, const float* ex_partner,
-                                              float* red, int nh, int li, int h, int lane, int n, int ty0, int bm, int bn) {
-  const int tid = (XH + nh * 2) * 64 + lane;          // = threadIdx.x, from the values taken afresh behind the main loop
+// Epilogue of the three kernels.  A wavefront holds ONE vertical frequency XI of its 32 tiles x 64 output channels: per
+// column half nh and accumulator row r it applies the horizontal half of At . A (4 positions -> the tile's 2 output columns:
+// F = [m0 + m1 + m2, m1 - m2 - m3]) and the four wavefronts meet ONCE through LDS for the vertical half:
+//   output row 0 = (F0 + F1) + F2,  output row 1 = F1 - (F3 + F2)        (F_x: the pair of wavefront x)
+// Wavefront XI produces output row XI >> 1 of column half XI & 1, keeps its own pairs of that half in registers and reads the
+// two others; six of the eight (frequency, half) sets are ever read by another wavefront - 6 x 8 KB of LDS over the window
+// buffers (and, in the BatchNorm + ReLU build, its scale / shift copy), 16-32 writes and 32 reads of 8 bytes per lane, one
+// barrier.  (First version: two rounds, one per column half, inside the 35 KB of the window buffers: three more barriers and
+// 4.3-6.9 us per workgroup against 2.6-3.9; in-kernel timeline.)
+// Addressing (round 4): the 16 tiles of a lane are four groups (k = r >> 2) of four tiles whose coordinates differ by a
+// WAVE-UNIFORM step (wino_tile: cell = T[2k + h] + (r & 3), T a multiple of 4): so the lane computes one byte offset into its
+// clip per group, the per-tile steps live in SGPRs, and the stores are buffer stores (32-bit lane offset + scalar offset)
+// against a descriptor of the CLIP whose size makes the hardware drop rows past the clip's end - no address arithmetic, no
+// branch per tile.
+// STATS: the launch also returns the BatchNorm partial sums of its raw output (forward convolutions).
+template <int XI, bool STATS>
+__device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 (&acc)[8], float2* ex, float* red, int li, int h,
+                                              int lane, int n, int ty0, int bm, int bn) {
+  constexpr int ROW = XI >> 1, NH = XI & 1;             // output row of the tile / column half this wavefront stores
+  // exchange sets: 0: F0[1], 1: F1[0], 2: F1[1], 3: F2[0], 4: F2[1], 5: F3[0]
+  constexpr int SET_OTHER = XI == 0 ? 0 : XI == 1 ? 1 : XI == 2 ? 4 : 5;      // this wavefront's pairs of the half it does not store
+  constexpr int SET_OWN = XI == 1 ? 2 : XI == 2 ? 3 : -1;                      // ... of its own half (frequencies 1, 2: needed by the other row)
+  constexpr int SET_A = XI == 0 ? 1 : XI == 1 ? 0 : XI == 2 ? 1 : 2, SET_B = XI == 0 ? 3 : XI == 1 ? 4 : XI == 2 ? 5 : 4;
+  const int tid = XI * 64 + lane;                       // = threadIdx.x, from the values taken afresh behind the main loop
   const int H = p.H, W = p.W, Cout = p.Cout;
   float2 keep[16];
-  float2* exm = reinterpret_cast<float2*>(ex_mine);
-  const float2* exp_ = reinterpret_cast<const float2*>(ex_partner);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float hl[2][2];
 #pragma unroll
-    for (int xl = 0; xl < 2; ++xl) {
-      const float m0 = acc[xl * 4 + 0][r], m1 = acc[xl * 4 + 1][r], m2 = acc[xl * 4 + 2][r], m3 = acc[xl * 4 + 3][r];
-      hl[xl][0] = m0 + m1 + m2;
-      hl[xl][1] = m1 - m2 - m3;
+    for (int nh = 0; nh < 2; ++nh) {
+      const float m0 = acc[0 + nh][r], m1 = acc[2 + nh][r], m2 = acc[4 + nh][r], m3 = acc[6 + nh][r];
+      const float2 f = make_float2(m0 + m1 + m2, m1 - m2 - m3);
+      if (nh == NH) {
+        keep[r] = f;
+        if (SET_OWN >= 0) ex[(SET_OWN * 16 + r) * 64 + lane] = f;
+      } else {
+        ex[(SET_OTHER * 16 + r) * 64 + lane] = f;
+      }
     }
-    const float s0 = hl[0][0] + hl[1][0], s1 = hl[0][1] + hl[1][1];
-    keep[r] = make_float2(XH ? -s0 : s0, XH ? -s1 : s1);
-    exm[r * 64 + lane] = make_float2(hl[1][0], hl[1][1]);
   }
   __syncthreads();
-  const int cout = bn * WN_TN + nh * 32 + li;
-  // per group k: pixel (y, x) of the tile with r & 3 == 0 (y already the output row XH of the tile), byte offset into the clip
+  const int cout = bn * WN_TN + NH * 32 + li;
+  // per group k: pixel (y, x) of the tile with r & 3 == 0 (y already the output row of the tile), byte offset into the clip
   int yk[4], voff[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int tyl, tx;
     wino_tile(8 * k + 4 * h, p.tw_shift, tyl, tx);
-    yk[k] = 2 * (ty0 + tyl) + XH;
+    yk[k] = 2 * (ty0 + tyl) + ROW;
     voff[k] = ((yk[k] * W + 2 * tx) * Cout + cout) * 4;
   }
   // wave-uniform step of tile j = r & 3 inside a group: TW >= 4: two pixels to the right per tile; TW = 2 (wino_tile: the
@@ -233,8 +253,9 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int k = r >> 2, j = r & 3;
-    const float2 pr = exp_[r * 64 + lane];
-    const float o0 = keep[r].x + pr.x, o1 = keep[r].y + pr.y;
+    const float2 a = ex[(SET_A * 16 + r) * 64 + lane], b = ex[(SET_B * 16 + r) * 64 + lane];
+    // the order of round 3's two-wavefront exchange (bit-identical results): (F0 + F1) + F2 and F1 - (F3 + F2)
+    const float o0 = ROW ? a.x - (b.x + keep[r].x) : (keep[r].x + a.x) + b.x, o1 = ROW ? a.y - (b.y + keep[r].y) : (keep[r].y + a.y) + b.y;
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), yrs, voff[k], soff[j], 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), yrs, voff[k], soff[j] + pix, 0);
     if (STATS) {
@@ -248,14 +269,12 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
     s += __shfl_xor(s, 32, 64);
     qq += __shfl_xor(qq, 32, 64);
     if (h == 0) {
-      red[(XH * 2 + 0) * 64 + nh * 32 + li] = s;
-      red[(XH * 2 + 1) * 64 + nh * 32 + li] = qq;
+      red[(ROW * 2 + 0) * 64 + NH * 32 + li] = s;
+      red[(ROW * 2 + 1) * 64 + NH * 32 + li] = qq;
     }
     __syncthreads();
     if (tid < WN_TN) {
-      float ts = 0.f, tq = 0.f;
-#pragma unroll
-      for (int w = 0; w < 2; ++w) { ts += red[(w * 2 + 0) * 64 + tid]; tq += red[(w * 2 + 1) * 64 + tid]; }
+      const float ts = red[(0 * 2 + 0) * 64 + tid] + red[(1 * 2 + 0) * 64 + tid], tq = red[(0 * 2 + 1) * 64 + tid] + red[(1 * 2 + 1) * 64 + tid];
       float* out = p.partials + (long)bm * 2 * p.Cout + bn * WN_TN + tid;
       out[0] = ts;
       out[p.Cout] = tq;
@@ -263,14 +282,16 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
   }
 }
 
-// XH: position half of this wavefront (vertical frequencies {0,1} from window rows 0-2 / {3,2} from rows 1-3)
-template <int XH, bool ACT, bool STATS>
+// XI: vertical frequency of this wavefront.  Window rows (of the tile's four) and sign: 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3
+template <int XI, bool ACT, bool STATS>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* scsh) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same value as a scalar (for the code behind the main loop)
+  // Two workgroups share a CU: this wavefront's prologue / epilogue run beside a wavefront of the OTHER workgroup that is
+  // inside its main loop, and the SIMD's round-robin issue gives each of their ~600 vector instructions one slot per 64-cycle
+  // MFMA of the neighbour: 4-7 us of latency for ~1.5 us of work (in-kernel timeline).  WN_PRIO_EDGE raises the priority
+  // outside the main loop so that these short phases run through and the wavefront joins the MFMA stream again.
+  __builtin_amdgcn_s_setprio(WN_PRIO_EDGE);
+  const int tid = threadIdx.x, lane = tid & 63;
   const int li = lane & 31, h = lane >> 5;
-  // wavefront roles: XH = wave & 1, nh = column half
-  const int nh = wave >> 1;
   int bm, bn;
   wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);
   const int RW = wino_row_pitch(p.tw_shift), R = p.R;
@@ -283,9 +304,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   const int nitems = ((2 * R + 2) << p.w_shift) * 4;
   const int q = tid & 3;
   for (int i = tid; i < (2 * R + 2) * 8; i += WN_THREADS) {
-    const int ry = i >> 3, side = (i >> 2) & 1, qq = i & 3;
+    const int ry = i >> 3, side = (i >> 2) & 1, qi = i & 3;
     const int rx = side ? W + 1 : 0;
-    const int slot = qq * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1);
+    const int slot = qi * WN_SQ + (ry & 1) * WN_SR + (rx & 1) * WN_SC + (ry >> 1) * RW + (rx >> 1);
     raw0[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     raw1[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -317,8 +338,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   };
   // ACT: scale / shift of all C input channels sit in LDS (scsh: [C/4] scale quads, then [C/4] shift quads) - a
   // global load inside a filler slot would wait out its whole latency there.  Staged in the prologue BEHIND the first
-  // window loads and the first weight DMA, so that the three latencies run side by side (staged in front of them, every
-  // workgroup paid one more global round trip: 8000 workgroups of eight chunks on the 64-channel layer).
+  // window loads and the first weight loads, so that the three latencies run side by side.
   auto stage_scsh = [&]() {
     if (ACT) {
       for (int i = tid; i < (C >> 2); i += WN_THREADS) {
@@ -348,11 +368,8 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   };
   auto put_raw = [&](float4* raw) { put_raw_part(raw, 0); put_raw_part(raw, 2); };
   // weight chunk c: 32 KB image [position][k half][column] of float4 (4 k-steps).  The fragments go from L2 / L1 STRAIGHT into
-  // the MFMA operand registers: lane (h, li) of a wavefront (nh) needs exactly one float4 per position and chunk, at
-  // (pos * 128 + h * 64 + nh * 32 + li) - two 512-byte runs per wave instruction.  (The previous form moved the chunk
-  // into LDS by LDS-DMA and read the fragments back: per chunk and wavefront 4 DMA instructions at 100+ issue cycles each
-  // inside a phase full of LDS reads, 8 ds_read_b128 and a barrier per chunk - 5200-5450 cycles per chunk against 4096 of
-  // MFMA, of which ~470 went away in the lab build without the DMA; tools/lab_wino.py `full` / `nodma`.)
+  // the MFMA operand registers: lane (h, li) needs one float4 per position, column half and chunk, at
+  // (pos * 128 + h * 64 + nh * 32 + li) - two 512-byte runs per wave instruction.
   const int nchunk = C >> 3;
   const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.U + ((long)bn * nchunk) * (WN_BCHUNK * 4)), 0, 0x7fffffff, 0x00020000);
@@ -360,62 +377,44 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   int tyl_a, tx_a;
   wino_tile(li, p.tw_shift, tyl_a, tx_a);
   const int abase = tyl_a * RW + tx_a;
-  int rowoff[3];      // window rows XH, XH+1, XH+2 of the tile: plane (row parity) and row index
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const int i = XH + a;
-    rowoff[a] = (i & 1) * WN_SR + (i >> 1) * RW + abase;
-  }
-  constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;     // vertical frequencies of local positions 0..3 / 4..7
-  const int bvoff = (h * 64 + nh * 32 + li) * 16;
-  // group g (0..7) of chunk c: local position g -> image position xi0 * 4 + g (g < 4) or xi1 * 4 + g - 4
+  constexpr int RA = XI == 0 ? 0 : XI == 2 ? 2 : 1, RB = XI == 0 ? 2 : XI == 1 ? 2 : XI == 2 ? 1 : 3;    // t = row RA -/+ row RB
+  const int rowa = (RA & 1) * WN_SR + (RA >> 1) * RW + abase, rowb = (RB & 1) * WN_SR + (RB >> 1) * RW + abase;
+  const int bvoff = (h * 64 + li) * 16;
+  // group g (0..7) of chunk c: horizontal position g >> 1 (image position XI * 4 + (g >> 1)), column half g & 1
   auto load_b = [&](int c, int g) {
     typedef unsigned wn_v4u __attribute__((ext_vector_type(4)));
-    const int pos = g < 4 ? xi0 * 4 + g : xi1 * 4 + (g - 4);
-    const wn_v4u v = __builtin_amdgcn_raw_buffer_load_b128(urs, bvoff, c * (WN_BCHUNK * 16) + pos * 2048, 0);
+    const wn_v4u v = __builtin_amdgcn_raw_buffer_load_b128(urs, bvoff, c * (WN_BCHUNK * 16) + (XI * 4 + (g >> 1)) * 2048 + (g & 1) * 512, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   };
 
-  f32x16 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  f32x16 acc[8];             // [horizontal position nu][column half nh] = acc[2 nu + nh]; first written by chunk 0 (C = 0)
 
   // ---------------------------------------------------------------- main loop
-  // Per 8-channel chunk a wavefront issues 8 groups of 4 MFMAs (one accumulator each) and, pinned BETWEEN the groups by
-  // sched_barriers, the work that does not need the matrix pipe.  A chunk starts with its operands in registers: v0 (the
-  // horizontally transformed window of positions 0-3), t1 (the vertical transform for positions 4-7) - the window reads
-  // and transforms of the NEXT chunk are software-pipelined into the tail of this one - and the weight fragments in a ring
-  // of four float4 (slot g & 3 for group g): the slot a group has just used is reloaded with the fragment four groups ahead
-  // (>= 1500 cycles of flight for an L2 hit of 300-500).  Every filler slot sits behind a group of 4 dependent MFMAs (256
-  // cycles of pipe): the two wavefronts of a SIMD fall into alternating groups by themselves, one's fillers run under the
-  // other's MFMAs.  All vector-memory operations are plain loads now, so the waits are the compiler's own counted ones
-  // and ONE barrier per 16-channel stage remains (for the window buffers):
+  // Per 8-channel chunk a wavefront issues 8 groups of 4 MFMAs (one accumulator each; a transformed fragment serves the two
+  // column halves) and, pinned BETWEEN the groups by sched_barriers, the work that does not need the matrix pipe.  A chunk
+  // starts with its operands in registers: the transformed window of its frequency (va / vb by chunk parity; the window reads
+  // and the transform of the NEXT chunk - 8 ds_read_b128, 16 v_pk_add_f32 - are software-pipelined into this one) and the
+  // weight fragments in a ring of four float4 (slot g & 3 for group g): the slot a group has just used is reloaded with the
+  // fragment four groups ahead (>= 1500 cycles of flight for an L2 hit of 300-500).  Round 4: on this part an fp32 MFMA and
+  // any other vector instruction of the SIMD add up (a chunk measured 4096 + 2 x 256 cycles = the MFMAs plus the 32 packed adds
+  // of each of the SIMD's two wavefronts, whatever else was in the program), so the transform is the cost to cut: one vertical
+  // frequency per wavefront and both column halves halves the adds per MFMA (until round 4: two frequencies, one column half).
+  // ONE barrier per 16-channel stage (for the window buffers):
   //   raw window of stage s+1: loaded (global -> registers) in chunk (s-1, 0), written to LDS in chunk (s, 0), first read
   //   (prefetch for chunk (s+1, 0)) in chunk (s, 1); its buffer's last readers were the prefetch reads in chunk (s-1, 0);
   //   the barrier at the end of chunk (s, 0) separates both pairs.
   const int nstage = C >> 4;
-  const float4* const aq0 = raw0 + h * WN_SQ;        // + 2 * sub * WN_SQ + rowoff[a] + (j & 1) * WN_SC + (j >> 1)
+  const float4* const aq0 = raw0 + h * WN_SQ;        // + 2 * sub * WN_SQ + row + (j & 1) * WN_SC + (j >> 1)
   const float4* const aq1 = raw1 + h * WN_SQ;
-  float4 v0[4], t1[4], B[4];
-  // window reads + vertical transform of one chunk: rows XH, XH+2 -> t0 (in place), rows XH+1 and XH (XH+2) -> t1
-  auto read_rows02 = [&](const float4* rq, float4 (&d0)[4], float4 (&d2)[4]) {
+  float4 va[4], vb[4], B[4];
+  auto read_row = [&](const float4* rq, int row, float4 (&d)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d0[j] = rq[rowoff[0] + (j & 1) * WN_SC + (j >> 1)];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d2[j] = rq[rowoff[2] + (j & 1) * WN_SC + (j >> 1)];
+    for (int j = 0; j < 4; ++j) d[j] = rq[row + (j & 1) * WN_SC + (j >> 1)];
   };
-  auto read_row1 = [&](const float4* rq, float4 (&d1)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d1[j] = rq[rowoff[1] + (j & 1) * WN_SC + (j >> 1)];
-  };
-  // t1 = XH ? d1 - d0 : d1 + d2 (into d1);  t0 = d0 - d2 (into d0) -> v0 = horizontal transform of t0
-  auto vertical = [&](float4 (&d0)[4], float4 (&d1)[4], float4 (&d2)[4]) {
+  auto vertical = [&](float4 (&da)[4], float4 (&db)[4]) {     // into da
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (XH) pk_sub_ip(d1[j], d0[j]); else pk_add_ip(d1[j], d2[j]);
-      pk_sub_ip(d0[j], d2[j]);
+      if (XI == 1) pk_add_ip(da[j], db[j]); else pk_sub_ip(da[j], db[j]);
     }
   };
 
@@ -428,107 +427,111 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   issue_raw(nstage > 1 ? 1 : 0);
   __syncthreads();
   {
-    float4 d0[4], d1[4], d2[4];
-    read_rows02(aq0, d0, d2);
-    read_row1(aq0, d1);
-    vertical(d0, d1, d2);
-    wino_htrans_ip(d0, v0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t1[j] = d1[j];
+    float4 da[4], db[4];
+    read_row(aq0, rowa, da);
+    read_row(aq0, rowb, db);
+    vertical(da, db);
+    wino_htrans_ip(da, va);
   }
 #define WN_SB() __builtin_amdgcn_sched_barrier(0)
   // No run-time condition anywhere in a chunk: past the last stage the staging repeats the last stage (loads that hit L2,
-  // stores into a buffer nobody reads any more), past the last chunk the weight ring reloads the last chunk.  Two copies of
-  // the chunk (with / without) make the register allocator carry both sets of accumulators through the join (1 KB of
-  // spills per lane).
-  auto step = [&](int c, auto kk) {
+  // stores into a buffer nobody reads any more), past the last chunk the weight ring reloads the last chunk.
+  auto step = [&](int c, auto kk, auto first) {
     constexpr int K = decltype(kk)::value;            // c % 4
+    constexpr bool FIRST = decltype(first)::value;    // chunk 0: the accumulators start here
+    auto mm = [&](f32x16& a_, float4 x_, float4 y_) { if (FIRST) mfma4_first(a_, x_, y_); else mfma4(a_, x_, y_); };
     constexpr int sub = K & 1, sp = K >> 1;
+    float4 (&vc)[4] = sub ? vb : va;                   // this chunk's fragments / the next chunk's
+    float4 (&vn)[4] = sub ? va : vb;
     const int st = c >> 1;
     float4* const rnxt = sp ? raw0 : raw1;
     // the next chunk's window: the other half of this stage's buffer, or the first half of the next stage's
     const float4* const nq = sub ? (sp ? aq0 : aq1) : (sp ? aq1 : aq0) + 2 * WN_SQ;
     const int cn = c + 1 < nchunk ? c + 1 : c;          // last chunk: a harmless repeat instead of a branch
-    float4 d0[4], d1[4], d2[4], v1[4];
+    float4 da[4], db[4];
     const int st1 = st + 1 < nstage ? st + 1 : nstage - 1, st2 = st + 2 < nstage ? st + 2 : nstage - 1;
     if (sub == 0) read_scsh(st1);
     WN_SB();
-    mfma4(acc[0], v0[0], B[0]);
+    mm(acc[0], vc[0], B[0]);
     WN_SB();
     B[0] = load_b(c, 4);
     // first chunk of a stage: the staging of stage st + 1 (loaded during the previous stage), then the loads of stage st + 2
     if (sub == 0) put_raw_part(rnxt, 0);
     WN_SB();
-    mfma4(acc[1], v0[1], B[1]);
+    mm(acc[1], vc[0], B[1]);
     WN_SB();
     B[1] = load_b(c, 5);
     if (sub == 0) put_raw_part(rnxt, 2);
     WN_SB();
-    mfma4(acc[2], v0[2], B[2]);
+    mm(acc[2], vc[1], B[2]);
     WN_SB();
     B[2] = load_b(c, 6);
     if (sub == 0) issue_raw(st2);                     // stored in chunk (st + 1, 0)
     WN_SB();
-    mfma4(acc[3], v0[3], B[3]);
+    mm(acc[3], vc[1], B[3]);
     WN_SB();
     B[3] = load_b(c, 7);
-    wino_htrans_ip(t1, v1);
+    read_row(nq, rowa, da);
     WN_SB();
-    mfma4(acc[4], v1[0], B[0]);
+    mm(acc[4], vc[2], B[0]);
     WN_SB();
     B[0] = load_b(cn, 0);
-    read_rows02(nq, d0, d2);
+    read_row(nq, rowb, db);
     WN_SB();
-    mfma4(acc[5], v1[1], B[1]);
+    mm(acc[5], vc[2], B[1]);
     WN_SB();
     B[1] = load_b(cn, 1);
-    read_row1(nq, d1);
     WN_SB();
-    mfma4(acc[6], v1[2], B[2]);
+    mm(acc[6], vc[3], B[2]);
     WN_SB();
     B[2] = load_b(cn, 2);
-    vertical(d0, d1, d2);
+    vertical(da, db);
     WN_SB();
-    mfma4(acc[7], v1[3], B[3]);
+    mm(acc[7], vc[3], B[3]);
     WN_SB();
     B[3] = load_b(cn, 3);
-    wino_htrans_ip(d0, v0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t1[j] = d1[j];
+    wino_htrans_ip(da, vn);
     WN_SB();
     if (sub == 0) __syncthreads();
   };
 #undef WN_SB
   using std::integral_constant;
-  for (int c = 0; c < nchunk; c += 4) {
-    step(c, integral_constant<int, 0>());
-    step(c + 1, integral_constant<int, 1>());
+  using std::false_type;
+  __builtin_amdgcn_s_setprio(0);
+  // the first group of chunks apart (chunk 0's MFMAs take C = 0), then the loop; the number of chunks is even
+  step(0, integral_constant<int, 0>(), std::true_type());
+  step(1, integral_constant<int, 1>(), false_type());
+  if (2 < nchunk) {
+    step(2, integral_constant<int, 2>(), false_type());
+    step(3, integral_constant<int, 3>(), false_type());
+  }
+  for (int c = 4; c < nchunk; c += 4) {
+    step(c, integral_constant<int, 0>(), false_type());
+    step(c + 1, integral_constant<int, 1>(), false_type());
     if (c + 2 < nchunk) {
-      step(c + 2, integral_constant<int, 2>());
-      step(c + 3, integral_constant<int, 3>());
+      step(c + 2, integral_constant<int, 2>(), false_type());
+      step(c + 3, integral_constant<int, 3>(), false_type());
     }
   }
+  __builtin_amdgcn_s_setprio(WN_PRIO_EDGE);
   __syncthreads();          // the epilogue reuses the window buffers
-  // Lane and wavefront coordinates are taken afresh here (lane id from mbcnt, the wave index kept as a scalar): carried over
-  // from the top of the kernel they are live across the main loop, which has no register to spare (the BatchNorm + ReLU build
-  // spilled one of them).
+  // Lane coordinates are taken afresh here (lane id from mbcnt): carried over from the top of the kernel they are live across
+  // the main loop, which has no register to spare.
   const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int li_e = lane_e & 31, h_e = lane_e >> 5;
-  const int tid_e = wave_s * 64 + lane_e;
-  const int nh_e = wave_s >> 1;
+  const int tid_e = XI * 64 + lane_e;
 
   // ---------------------------------------------------------------- prefetch for the workgroup that follows on this XCD
   // A workgroup's prologue waits out one HBM round trip for the first stage of its window (2-3 us under load: the tensor was
-  // written by the previous kernel and is far larger than the caches) and, with one workgroup per CU, nothing runs under it.
+  // written by the previous kernel and is far larger than the caches).
   // The XCD works through its run of tiles in dispatch order, 32 CUs x 2 workgroups at a time: the workgroup that starts when
   // this one ends is most often tile t + WN_PF_DIST of the run (in-kernel timeline, tools/lab_wino.py full) - and whichever CU of
   // the XCD gets that tile, it reads through the same L2.  So, with its own loads done, every workgroup touches the first
   // 128-byte line of each window pixel of that tile (channels 0-31: stages 0 and 1; one dword load per pixel, the value is
   // discarded at the end of the epilogue): the line is on its way into the XCD's L2 while this epilogue runs.
-  // Only where the operand carries no activation: the BatchNorm + ReLU build of this kernel sits exactly at 256 registers and
-  // its main loop lost 2-6 % with the prefetch in the program (measured, same session: 5280 -> 5580 cycles per chunk on the
-  // 64-channel layer) - more than the shorter prologue gives back; the plain build gains 1-4 % per call on the 64 / 128-channel
-  // layers (prologue 2.7 -> 1.7 us; profiles/r04_wino_lab.txt).
+  // Only where the operand carries no activation: the BatchNorm + ReLU build lost 2-6 % in its main loop with the prefetch in
+  // the program - more than the shorter prologue gave back.  With two workgroups per CU (the one's prologue under the other's
+  // main loop) the gain is within the noise (profiles/r04_wino_lab.txt); kept, it costs nothing.
   float pfv = 0.f;
   if (!ACT) {
     const int nn_ = (int)gridDim.y;
@@ -542,9 +545,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   }
 
   // ---------------------------------------------------------------- epilogue
-  float* exb = reinterpret_cast<float*>(raw0);        // [wave][32][64 lanes] over both window buffers (raw1 follows raw0), then the sums
-  wino_epilogue<XH, STATS>(p, acc, exb + wave_s * 2048, exb + (wave_s ^ 1) * 2048, reinterpret_cast<float*>(raw0 + WN_EX_F4),
-                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);
+  float2* exb = reinterpret_cast<float2*>(raw0);        // [set][16][64 lanes] pairs over the workgroup's whole array, then the sums
+  wino_epilogue<XI, STATS>(p, acc, exb, reinterpret_cast<float*>(raw0 + WN_EX_F4),
+                           li_e, h_e, lane_e, n, ty0, bm, bn);
   if (!ACT) asm volatile("" :: "v"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved
 }
 
@@ -552,22 +555,25 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 // Three builds: the data gradient (neither), a block's first convolution (statistics), its second one (both).
 template <bool ACT, bool STATS>
 __device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw, float4* scsh) {
-  if ((threadIdx.x >> 6) & 1) conv_wino_body<1, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh);
-  else conv_wino_body<0, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh);
+  switch (threadIdx.x >> 6) {
+    case 0: conv_wino_body<0, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh); break;
+    case 1: conv_wino_body<1, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh); break;
+    case 2: conv_wino_body<2, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh); break;
+    default: conv_wino_body<3, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh); break;
+  }
 }
 // (256 threads, 2 wavefronts per SIMD): at most 256 registers per wavefront, so that two workgroups share a CU
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoParams p) {
-  __shared__ float4 raw[2 * WN_RAWBUF];
+  __shared__ float4 raw[WN_LDS_F4];
   conv_wino_entry<false, false>(p, raw, nullptr);
 }
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_stats_kernel(WinoParams p) {
-  __shared__ float4 raw[2 * WN_RAWBUF];
+  __shared__ float4 raw[WN_LDS_F4];
   conv_wino_entry<false, true>(p, raw, nullptr);
 }
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_act_kernel(WinoParams p) {
-  __shared__ float4 raw[2 * WN_RAWBUF];
-  __shared__ float4 scsh[2 * WN_MAXC / 4];
-  conv_wino_entry<true, true>(p, raw, scsh);
+  __shared__ float4 raw[2 * WN_RAWBUF + 2 * WN_MAXC / 4];
+  conv_wino_entry<true, true>(p, raw, raw + 2 * WN_RAWBUF);
 }
 
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:

@@ -12,7 +12,7 @@ CSRC = os.path.join(ROOT, "acvae_amd", "csrc")
 LAB = os.path.join(ROOT, "tools", "lab")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I" + CSRC]
 
-PRE_LOOP = "  using std::integral_constant;\n  for (int c = 0; c < nchunk; c += 4) {"
+PRE_LOOP = "  using std::integral_constant;\n  using std::false_type;\n  __builtin_amdgcn_s_setprio(0);"
 FAKE_D = ("#pragma unroll\n    for (int j = 0; j < 4; ++j) asm volatile(\"\" : \"=v\"(DST[j].x), \"=v\"(DST[j].y), \"=v\"(DST[j].z), "
           "\"=v\"(DST[j].w));")
 VARIANTS = {
@@ -34,20 +34,20 @@ VARIANTS["stamps"] = [
     ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
      "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_t0 = clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
     (PRE_LOOP, "  const long long lab_t1 = clock64();\n" + PRE_LOOP),
-    ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
-     "  const long long lab_t2 = clock64();\n  float* exb"),
-    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
-     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+    ("  // ---------------------------------------------------------------- epilogue\n  float2* exb",
+     "  const long long lab_t2 = clock64();\n  float2* exb"),
+    ("                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  const int wave = XI;\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    o[0] = (float)(lab_t1 - lab_t0); o[1] = (float)(lab_t2 - lab_t1); o[2] = (float)(clock64() - lab_t2); o[3] = (float)nchunk;\n  }\n}\n\n// ACT: the operand carries"),
 ]
 # in-kernel clock: s_memtime (shader cycles) against s_memrealtime (100 MHz) around the main loop -> [workgroup][wave][4] =
 # cycles, 100-MHz ticks, chunks, 0 (MI355X_MICROARCH.md, DVFS give-back (6))
 VARIANTS["clock"] = [
     (PRE_LOOP, "  const long long lab_c0 = clock64(), lab_r0 = wall_clock64();\n" + PRE_LOOP),
-    ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
-     "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n  float* exb"),
-    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
-     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+    ("  // ---------------------------------------------------------------- epilogue\n  float2* exb",
+     "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n  float2* exb"),
+    ("                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  const int wave = XI;\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    o[0] = (float)(lab_c1 - lab_c0); o[1] = (float)(lab_r1 - lab_r0); o[2] = (float)nchunk; o[3] = 0.f;\n  }\n}\n\n// ACT: the operand carries"),
 ]
 # workgroup timeline: [workgroup][wave][4] = start, end (100-MHz wall clock, low 24 bits as float), CU key (XCC id << 8 | HW_ID[15:8]), 0
@@ -55,8 +55,8 @@ VARIANTS["timeline"] = [
     ("      out[0] = o0;\n      out[p.Cout] = o1;\n", "      asm volatile(\"\" :: \"v\"(out), \"v\"(o0), \"v\"(o1));\n"),     # no output stores: the stamps go into Y
     ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
      "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
-    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
-     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
+    ("                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  const int wave = XI;\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
      "    o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = 0.f;\n  }\n}\n\n// ACT: the operand carries"),
 ]
@@ -66,10 +66,10 @@ VARIANTS["full"] = [
     ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
      "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
     (PRE_LOOP, "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n" + PRE_LOOP),
-    ("  // ---------------------------------------------------------------- epilogue\n  float* exb",
-     "  const long long lab_c2 = clock64(), lab_r2 = wall_clock64();\n  float* exb"),
-    ("                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
-     "                           nh_e, li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  if (lane == 0 && wave < 2) {\n    float* o = p.lab + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 3 + wave) * 4;\n"
+    ("  // ---------------------------------------------------------------- epilogue\n  float2* exb",
+     "  const long long lab_c2 = clock64(), lab_r2 = wall_clock64();\n  float2* exb"),
+    ("                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
+     "                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  const int wave = XI;\n  if (lane == 0 && wave < 2) {\n    float* o = p.lab + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 3 + wave) * 4;\n"
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
      "    if (wave == 0) { o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = (float)nchunk; }\n"
      "    else { o[0] = (float)(lab_r1 & 0xffffff); o[1] = (float)(lab_r2 & 0xffffff); o[2] = (float)(lab_c2 - lab_c1); o[3] = 0.f; }\n  }\n}\n\n// ACT: the operand carries"),
@@ -109,6 +109,8 @@ VARIANTS["scalar"] = [
      '  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3")          // t0 - t2'),
 ]
 VARIANT_FLAGS = {"scalar": ["-fno-slp-vectorize"]}
+VARIANTS["fullprio0"] = VARIANTS["full"]
+VARIANT_FLAGS["fullprio0"] = ["-DWN_PRIO_EDGE=0"]
 for _d in (16, 32, 48, 96):                      # prefetch distance in the XCD's run of tiles
     VARIANTS[f"fullpf{_d}"] = VARIANTS["full"]
     VARIANT_FLAGS[f"fullpf{_d}"] = [f"-DWN_PF_DIST={_d}"]
