@@ -43,8 +43,11 @@ struct WinoWeightsBatch {
   void add(const float* w, float* u, int cout, int cin, bool dg) { W[n] = w; U[n] = u; Cout[n] = cout; Cin[n] = cin; dgrad[n] = dg ? 1 : 0; ++n; }
 };
 int conv3x3_wino_weights_batch(WinoWeightsBatch& b, hipStream_t st);
+// red (data gradient only; partials = [conv_wino_partials_rows][2][Cout] then receives bn_bwd_reduce_kernel's sums): the launch's
+// output is the upstream gradient of the BatchNorm + ReLU that normalised red->Y (same shape as the output)
+struct WinoBnReduce { const float* Y; const float* scale; const float* shift; const float* mean; const float* invstd; };
 int conv3x3_wino(const float* X, const float* scale, const float* shift, const float* U, float* Y, float* partials, int N,
-                 int H, int W, int Cin, int Cout, hipStream_t st);
+                 int H, int W, int Cin, int Cout, hipStream_t st, const WinoBnReduce* red = nullptr);
 bool conv3x3_wino_wgrad_ok(int H, int W, int Cin, int Cout);
 long conv3x3_wino_wgrad_slab_floats(int N, int H, int W, int Cin, int Cout);     // 0 when the shape is not taken
 int conv3x3_wino_wgrad(const float* dY, const float* X, const float* scale, const float* shift, float* dW_oihw, float* slab,
@@ -99,9 +102,11 @@ int bn_relu_pool(const T* Y, const float* scale, const float* shift, T* P, int N
                  DropoutSpec drop, hipStream_t st, bool pool = true);
 int bn_bwd_blocks(int N, int H, int W, int C);
 template <class T>
+// ready_rows > 0 (plain upstream only): `partials` already holds that many rows of the reduction's sums (written by the data
+// gradient that produced dO, conv3x3_wino with a WinoBnReduce): the reduction pass is skipped
 int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, T* dY, double* dpart, int N, int H,
-           int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats = true);
+           int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats = true, int ready_rows = 0);
 template <class T>
 int relu_mask(const T* Y, const float* scale, const float* shift, uint8_t* out, int N, int H, int W, int C, hipStream_t st);
 template <class T>

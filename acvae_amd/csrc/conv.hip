@@ -1622,9 +1622,10 @@ int bn_bwd_blocks(int N, int H, int W, int C) { return cdiv((long)N * H * W, bnb
 template <class T>
 int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const float* shift, const float* mean,
            const float* invstd, float* partials, float* sum_g, float* sum_gy, T* dY, double* dpart, int N, int H,
-           int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats) {
+           int W, int C, DropoutSpec drop, hipStream_t st, bool batch_stats, int ready_rows) {
   const int Cc = C < 1024 ? C : 1024;
   if (C % 4 != 0 || 1024 % Cc != 0 || C % Cc != 0) return ACVAE_EUNSUPPORTED;
+  if (ready_rows > 0 && upstream != UP_PLAIN) return ACVAE_EINVAL;
   const dim3 rgrid(bn_bwd_blocks(N, H, W, C), C / Cc);
   const int nb = rgrid.x;
   const size_t shm = 256 * 8 * sizeof(float);
@@ -1651,9 +1652,10 @@ int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const floa
   } else if (upstream == UP_POOL) { BN_BWD_LAUNCH(UP_POOL); }
   else if (upstream == UP_DROP) { BN_BWD_LAUNCH(UP_DROP); }
   else {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<UP_PLAIN, T>), rgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials,
-                       N, H, W, C, bnb_pix(C), drop);
-    ACVAE_TRY(colsum2(partials, nb, 2 * C, dpart, sum_g, sum_gy, C, st));
+    if (ready_rows <= 0)
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<UP_PLAIN, T>), rgrid, dim3(256), shm, st, Y, dO, scale, shift, mean, invstd, partials,
+                         N, H, W, C, bnb_pix(C), drop);
+    ACVAE_TRY(colsum2(partials, ready_rows > 0 ? ready_rows : nb, 2 * C, dpart, sum_g, sum_gy, C, st));
     // grid stride a multiple of C/4 (256 is one for C <= 1024; an even grid makes it one for C = 2048)
     int g = ew_grid((total + 1) / 2);
     if ((C / 4) > 256 && (g & 1)) ++g;
@@ -1668,8 +1670,8 @@ int bn_bwd(const T* Y, const T* dO, int upstream, const float* scale, const floa
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }
-template int bn_bwd<float>(const float*, const float*, int, const float*, const float*, const float*, const float*, float*, float*, float*, float*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool);
-template int bn_bwd<bf16_t>(const bf16_t*, const bf16_t*, int, const float*, const float*, const float*, const float*, float*, float*, float*, bf16_t*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool);
+template int bn_bwd<float>(const float*, const float*, int, const float*, const float*, const float*, const float*, float*, float*, float*, float*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool, int);
+template int bn_bwd<bf16_t>(const bf16_t*, const bf16_t*, int, const float*, const float*, const float*, const float*, float*, float*, float*, bf16_t*, double*, int, int, int, int, DropoutSpec, hipStream_t, bool, int);
 
 template <class T>
 int relu_mask(const T* Y, const float* scale, const float* shift, uint8_t* out, int N, int H, int W, int C, hipStream_t st) {

@@ -85,6 +85,13 @@ struct WinoParams {
   const float* U;       // wino_weights_kernel image
   float* Y;             // [N][H][W][Cout]
   float* partials;      // [blocks][2][Cout] or nullptr
+  // data gradient feeding a BatchNorm + ReLU backward (WinoBnReduce): the tensor that BatchNorm normalised (same shape as Y),
+  // its scale / shift / mean / invstd
+  const float* rY;
+  const float* rscale;
+  const float* rshift;
+  const float* rmean;
+  const float* rinvstd;
   int N, H, W, C, Cout;
   int tw_shift;         // TW = W/2 = 1 << tw_shift
   int R;                // tile rows per workgroup = 32 / TW
@@ -200,8 +207,13 @@ __device__ __forceinline__ void mfma4(f32x16& c, float4 a, float4 b) {
 // clip per group, the per-tile steps live in SGPRs, and the stores are buffer stores (32-bit lane offset + scalar offset)
 // against a descriptor of the CLIP whose size makes the hardware drop rows past the clip's end - no address arithmetic, no
 // branch per tile.
-// STATS: the launch also returns the BatchNorm partial sums of its raw output (forward convolutions).
-template <int XI, bool STATS>
+// MODE 1 (forward convolutions): the launch also returns the BatchNorm partial sums of its raw output (sum, sum of squares).
+// MODE 2 (the data gradient of a block's second convolution): its output dA is the upstream gradient of the first
+// convolution's BatchNorm + ReLU, whose backward starts with the sums  sum g, sum g * yhat  (g = dA where the activation
+// was positive, yhat = (y - mean) * invstd) over the whole batch - bn_bwd_reduce_kernel, a pass over two tensors (0.40 ms per
+// step in four launches).  The epilogue has dA in registers: it reads y at the pixels it stores (32 loads per lane, issued in
+// front of the exchange) and returns the partial sums in the layout of bn_bwd_reduce_kernel ([blocks][2][Cout]).
+template <int XI, int MODE>
 __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 (&acc)[8], float2* ex, float* red, int li, int h,
                                               int lane, int n, int ty0, int bm, int bn) {
   constexpr int ROW = XI >> 1, NH = XI & 1;             // output row of the tile / column half this wavefront stores
@@ -209,24 +221,9 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
   constexpr int SET_OTHER = XI == 0 ? 0 : XI == 1 ? 1 : XI == 2 ? 4 : 5;      // this wavefront's pairs of the half it does not store
   constexpr int SET_OWN = XI == 1 ? 2 : XI == 2 ? 3 : -1;                      // ... of its own half (frequencies 1, 2: needed by the other row)
   constexpr int SET_A = XI == 0 ? 1 : XI == 1 ? 0 : XI == 2 ? 1 : 2, SET_B = XI == 0 ? 3 : XI == 1 ? 4 : XI == 2 ? 5 : 4;
+  constexpr bool STATS = MODE != 0;
   const int tid = XI * 64 + lane;                       // = threadIdx.x, from the values taken afresh behind the main loop
   const int H = p.H, W = p.W, Cout = p.Cout;
-  float2 keep[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-      const float m0 = acc[0 + nh][r], m1 = acc[2 + nh][r], m2 = acc[4 + nh][r], m3 = acc[6 + nh][r];
-      const float2 f = make_float2(m0 + m1 + m2, m1 - m2 - m3);
-      if (nh == NH) {
-        keep[r] = f;
-        if (SET_OWN >= 0) ex[(SET_OWN * 16 + r) * 64 + lane] = f;
-      } else {
-        ex[(SET_OTHER * 16 + r) * 64 + lane] = f;
-      }
-    }
-  }
-  __syncthreads();
   const int cout = bn * WN_TN + NH * 32 + li;
   // per group k: pixel (y, x) of the tile with r & 3 == 0 (y already the output row of the tile), byte offset into the clip
   int yk[4], voff[4];
@@ -247,6 +244,33 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
     soff[j] = (dyj[j] * W + dx) * Cout * 4;
   }
   const int pix = Cout * 4;                                  // bytes from a pixel to its right neighbour
+  float2 yv[MODE == 2 ? 16 : 1];
+  float rsc = 0.f, rsh = 0.f, rmu = 0.f, ris = 0.f;
+  if (MODE == 2) {
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rY) + (long)n * H * W * Cout, 0, H * W * Cout * 4, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      yv[r].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, voff[r >> 2], soff[r & 3], 0));
+      yv[r].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, voff[r >> 2], soff[r & 3] + pix, 0));
+    }
+    rsc = p.rscale[cout]; rsh = p.rshift[cout]; rmu = p.rmean[cout]; ris = p.rinvstd[cout];
+  }
+  float2 keep[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const float m0 = acc[0 + nh][r], m1 = acc[2 + nh][r], m2 = acc[4 + nh][r], m3 = acc[6 + nh][r];
+      const float2 f = make_float2(m0 + m1 + m2, m1 - m2 - m3);
+      if (nh == NH) {
+        keep[r] = f;
+        if (SET_OWN >= 0) ex[(SET_OWN * 16 + r) * 64 + lane] = f;
+      } else {
+        ex[(SET_OTHER * 16 + r) * 64 + lane] = f;
+      }
+    }
+  }
+  __syncthreads();
   // descriptor of clip n: stores whose offset lies past H * W * Cout * 4 bytes (rows >= H of a partial block) are dropped
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Y + (long)n * H * W * Cout, 0, H * W * Cout * 4, 0x00020000);
   float s = 0.f, qq = 0.f;
@@ -258,11 +282,18 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
     const float o0 = ROW ? a.x - (b.x + keep[r].x) : (keep[r].x + a.x) + b.x, o1 = ROW ? a.y - (b.y + keep[r].y) : (keep[r].y + a.y) + b.y;
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), yrs, voff[k], soff[j], 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), yrs, voff[k], soff[j] + pix, 0);
-    if (STATS) {
+    if (MODE == 1) {
       const bool ok = yk[k] + dyj[j] < H;
       const float a0 = ok ? o0 : 0.f, a1 = ok ? o1 : 0.f;
       s += a0 + a1;
       qq += a0 * a0 + a1 * a1;
+    }
+    if (MODE == 2) {
+      // bn_bwd_reduce_kernel's arithmetic on the two pixels (rows past the clip: y = 0 from the bounds-checked load, masked anyway)
+      const bool ok = yk[k] + dyj[j] < H;
+      const float g0 = (ok && yv[r].x * rsc + rsh > 0.f) ? o0 : 0.f, g1 = (ok && yv[r].y * rsc + rsh > 0.f) ? o1 : 0.f;
+      s += g0; s += g1;
+      qq += g0 * ((yv[r].x - rmu) * ris); qq += g1 * ((yv[r].y - rmu) * ris);
     }
   }
   if (STATS && p.partials) {
@@ -283,7 +314,7 @@ __device__ __forceinline__ void wino_epilogue(const WinoParams& p, const f32x16 
 }
 
 // XI: vertical frequency of this wavefront.  Window rows (of the tile's four) and sign: 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3
-template <int XI, bool ACT, bool STATS>
+template <int XI, bool ACT, int STATS>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0, float4* raw1, float4* scsh) {
   // Two workgroups share a CU: this wavefront's prologue / epilogue run beside a wavefront of the OTHER workgroup that is
   // inside its main loop, and the SIMD's round-robin issue gives each of their ~600 vector instructions one slot per 64-cycle
@@ -553,7 +584,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
 
 // ACT: the operand carries the previous layer's BatchNorm + ReLU (p.scale / p.shift); STATS: BatchNorm partial sums of the output.
 // Three builds: the data gradient (neither), a block's first convolution (statistics), its second one (both).
-template <bool ACT, bool STATS>
+template <bool ACT, int STATS>
 __device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw, float4* scsh) {
   switch (threadIdx.x >> 6) {
     case 0: conv_wino_body<0, ACT, STATS>(p, raw, raw + WN_RAWBUF, scsh); break;
@@ -565,15 +596,19 @@ __device__ __forceinline__ void conv_wino_entry(const WinoParams& p, float4* raw
 // (256 threads, 2 wavefronts per SIMD): at most 256 registers per wavefront, so that two workgroups share a CU
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoParams p) {
   __shared__ float4 raw[WN_LDS_F4];
-  conv_wino_entry<false, false>(p, raw, nullptr);
+  conv_wino_entry<false, 0>(p, raw, nullptr);
+}
+__global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_bnred_kernel(WinoParams p) {
+  __shared__ float4 raw[WN_LDS_F4];
+  conv_wino_entry<false, 2>(p, raw, nullptr);
 }
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_stats_kernel(WinoParams p) {
   __shared__ float4 raw[WN_LDS_F4];
-  conv_wino_entry<false, true>(p, raw, nullptr);
+  conv_wino_entry<false, 1>(p, raw, nullptr);
 }
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_act_kernel(WinoParams p) {
   __shared__ float4 raw[2 * WN_RAWBUF + 2 * WN_MAXC / 4];
-  conv_wino_entry<true, true>(p, raw, raw + 2 * WN_RAWBUF);
+  conv_wino_entry<true, 1>(p, raw, raw + 2 * WN_RAWBUF);
 }
 
 // U = G g G^T for every (input channel, output channel) pair, written as the LDS image of the weight chunks:
@@ -676,13 +711,16 @@ int conv3x3_wino_weights_batch(WinoWeightsBatch& b, hipStream_t st) {
 // Y[N][H][W][Cout] = conv3x3(act(X[N][H][W][Cin])), pad 1; act = relu(x * scale + shift) when scale != nullptr.
 // U: conv3x3_wino_weights image for (Cin -> Cout).  partials (nullable): [conv_wino_partials_rows][2][Cout].
 int conv3x3_wino(const float* X, const float* scale, const float* shift, const float* U, float* Y, float* partials, int N,
-                 int H, int W, int Cin, int Cout, hipStream_t st) {
+                 int H, int W, int Cin, int Cout, hipStream_t st, const WinoBnReduce* red) {
   if (!X || !U || !Y) return ACVAE_EINVAL;
+  if (red && (scale || !partials || !red->Y || !red->scale || !red->shift || !red->mean || !red->invstd)) return ACVAE_EINVAL;
   if (!conv3x3_wino_ok(H, W, Cin, Cout)) return ACVAE_EUNSUPPORTED;
   if ((long)N * H * W * Cin >= (1L << 32)) return ACVAE_EUNSUPPORTED;      // 32-bit element offsets into X
   if (!aligned16(X) || !aligned16(U) || !aligned16(Y) || (scale && (!aligned16(scale) || !aligned16(shift)))) return ACVAE_EALIGN;
   WinoParams p;
   p.X = X; p.scale = scale; p.shift = shift; p.U = U; p.Y = Y; p.partials = partials;
+  p.rY = red ? red->Y : nullptr; p.rscale = red ? red->scale : nullptr; p.rshift = red ? red->shift : nullptr;
+  p.rmean = red ? red->mean : nullptr; p.rinvstd = red ? red->invstd : nullptr;
   p.N = N; p.H = H; p.W = W; p.C = Cin; p.Cout = Cout;
   const int TW = W / 2;
   p.tw_shift = __builtin_ctz(TW);
@@ -695,7 +733,8 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   if ((long)N * p.bpc >= (1L << 20)) return ACVAE_EUNSUPPORTED;
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);
-  if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  if (red) hipLaunchKernelGGL(conv_wino_bnred_kernel, grid, dim3(WN_THREADS), 0, st, p);
+  else if (scale) hipLaunchKernelGGL(conv_wino_act_kernel, grid, dim3(WN_THREADS), 0, st, p);
   else if (partials) hipLaunchKernelGGL(conv_wino_stats_kernel, grid, dim3(WN_THREADS), 0, st, p);
   else hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(WN_THREADS), 0, st, p);
   prof_end(ACVAE_PROF_CONV_IGEMM, st);

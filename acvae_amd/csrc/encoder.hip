@@ -2,6 +2,7 @@
 // kernels of conv.hip / gemm.hip on one stream with no host synchronisation.  All memory is supplied by
 // the caller: `saved` keeps what the backward needs (raw conv outputs, pooled tensors, BN statistics,
 // repacked weights), `scratch` is reusable within a call.
+#include <algorithm>
 #include "common.h"
 #include "conv.h"
 #include "../../include/acvae_hip.h"
@@ -100,7 +101,9 @@ int make_layout(int arch, int N, int T, int F, EncLayout& L) {
                     : acvae::conv3x3_wgrad_slab_floats(N, h, w, kChan[b - 1], kChan[b]);
       if (sl > max_slab) max_slab = sl;
     }
-    const long bp = (long)acvae::bn_bwd_blocks(N, h, w, kChan[b]) * 2 * kChan[b];
+    long bp = (long)acvae::bn_bwd_blocks(N, h, w, kChan[b]) * 2 * kChan[b];
+    if (esz == 4 && wino_on() && acvae::conv3x3_wino_ok(h, w, kChan[b], kChan[b]))      // the data gradient's fused reduction: its rows
+      bp = std::max(bp, (long)acvae::conv_wino_partials_rows(N, h, w) * 2 * kChan[b]);
     if (bp > max_bnpart) max_bnpart = bp;
     if (L.pool[b]) { h /= 2; w /= 2; }
   }
@@ -155,13 +158,19 @@ int conv_fwd(const TA* X, const float* scale, const float* shift, const float* W
   return acvae::conv3x3_igemm(X, scale, shift, (const TA*)wbuf, Y, partials, N, H, W, Cin, Cout, st);
 }
 // dX = conv3x3(dY, flipped / transposed W) for the layer Cin -> Cout
+// red / redpart / red_rows: the Winograd launch also reduces the BatchNorm + ReLU backward that consumes dX (conv.h: WinoBnReduce);
+// *red_rows = rows of sums written to redpart, 0 where the path taken does not do it
 template <class TA>
 int conv_dgrad(const TA* dY, const float* W_oihw, TA* wbuf, TA* dX, int N, int H, int W, int Cin, int Cout, hipStream_t st,
-               bool ready = false) {
+               bool ready = false, const acvae::WinoBnReduce* red = nullptr, float* redpart = nullptr, int* red_rows = nullptr) {
+  if (red_rows) *red_rows = 0;
   if constexpr (sizeof(TA) == 4) {
     if (use_wino<TA>(H, W, Cout, Cin)) {
       if (!ready) ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, (float*)wbuf, Cout, Cin, true, st));
-      return acvae::conv3x3_wino(dY, nullptr, nullptr, (const float*)wbuf, dX, nullptr, N, H, W, Cout, Cin, st);
+      const bool fuse = red && redpart && red_rows;
+      if (fuse) *red_rows = acvae::conv_wino_partials_rows(N, H, W);
+      return acvae::conv3x3_wino(dY, nullptr, nullptr, (const float*)wbuf, dX, fuse ? redpart : nullptr, N, H, W, Cout, Cin, st,
+                                 fuse ? red : nullptr);
     }
   }
   if (!ready) ACVAE_TRY(acvae::repack_weights<TA>(W_oihw, nullptr, wbuf, Cout, Cin, st));
@@ -395,11 +404,15 @@ int encoder_bwd_t(const void* const* params, void* const* grads, const float* fe
     // the data gradient's Winograd images were built by the training forward (same parameters: the optimiser runs after us)
     // (Winograd images where that path runs, implicit-GEMM repacks elsewhere - the forward chose with the same predicate)
     const bool wd_ready = training != 0;
-    ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd_ready ? (TA*)(saved + L.wd2[b]) : wd, dyb, N, H, W, C, C, st, wd_ready));
+    // ... and the launch leaves the sums of bn1's backward reduction in bnpart (fp32 Winograd path)
+    int red_rows = 0;
+    acvae::WinoBnReduce red{(const float*)Y1, n1.scale, n1.shift, n1.mean, n1.invstd};
+    ACVAE_TRY(conv_dgrad<TA>((const TA*)dya, P(p_conv(b, 2)), wd_ready ? (TA*)(saved + L.wd2[b]) : wd, dyb, N, H, W, C, C, st, wd_ready,
+                             sizeof(TA) == 4 ? &red : nullptr, bnpart, &red_rows));
     // conv1 / bn1
     DropoutSpec none{0.f, nullptr, 0, 0};
     ACVAE_TRY(acvae::bn_bwd<TA>(Y1, dyb, UP_PLAIN, n1.scale, n1.shift, n1.mean, n1.invstd, bnpart, G(p_bn(b, 1, 1)),
-                            G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st, training != 0));
+                            G(p_bn(b, 1, 0)), dya, dpart, N, H, W, C, none, st, training != 0, red_rows));
     if (b > 1) {
       ACVAE_TRY(conv_wgrad<TA>((const TA*)dya, (const TA*)(saved + L.p[b - 1]), nullptr, nullptr, G(p_conv(b, 1)), slab, N, H,
                                W, Cin, C, st));

@@ -256,8 +256,9 @@ def main():
         wino = not bf16 and os.environ.get("ACVAE_CONV_WINO", "1") != "0"
         kernel = ("conv_igemm_bf16_kernel (conv3x3 implicit GEMM fwd+dgrad, v_mfma_f32_32x32x16_bf16, bf16 activations)"
                   if bf16 else
-                  "conv_wino_kernel + conv_wino_stats_kernel + conv_wino_act_kernel (conv3x3 data gradient / forward / forward with BatchNorm+ReLU "
-                  "operand as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 7 + 3 + 4 launches per step)" if wino else
+                  "conv_wino_kernel + conv_wino_bnred_kernel + conv_wino_stats_kernel + conv_wino_act_kernel (conv3x3 data gradient / data gradient "
+                  "with the next BatchNorm backward's sums / forward / forward with BatchNorm+ReLU operand as Winograd F(2x2,3x3) on "
+                  "v_mfma_f32_32x32x2_f32: 3 + 4 + 3 + 4 launches per step)" if wino else
                   "conv_igemm3_kernel (conv3x3 implicit GEMM fwd+dgrad with horizontal-tap reuse, fp32 MFMA)")
         which = ("BASELINE configs[2] per-GPU shape (bf16 forward / fp32 loss)" if bf16 else "BASELINE configs[1]")
         # `achieved` / `frac` = flops the kernel actually ISSUES to the matrix pipe over its measured time (<= 1 by

@@ -88,7 +88,7 @@ def test_hot_kernels_keep_everything_in_registers():
     ge.build()
     usage = b.resource_usage()
     hot = ("decode_persist_kernel", "decode_persist_bwd_kernel", "posterior_persist_fwd_kernel", "posterior_persist_bwd_kernel",
-           "conv_wino_kernel", "conv_wino_stats_kernel", "conv_wino_act_kernel", "conv_wino_wgrad_kernel_s1", "conv_wino_wgrad_kernel_s2",
+           "conv_wino_kernel", "conv_wino_bnred_kernel", "conv_wino_stats_kernel", "conv_wino_act_kernel", "conv_wino_wgrad_kernel_s1", "conv_wino_wgrad_kernel_s2",
            "conv_wino_wgrad_kernel_s3", "conv_wino_wgrad_kernel_s4")
     for k in hot:
         hits = {n: u for n, u in usage.items() if k + "E" in n or n.endswith(k)}

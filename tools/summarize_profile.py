@@ -36,7 +36,7 @@ def counter(sub, name):
                 continue
             k = r["Kernel_Name"]
             short = ("conv_wgrad" if ("conv_wgrad" in k or "conv_wino_wgrad" in k) else "conv_igemm" if ("conv_igemm" in k or "conv_wino_kernel" in k or "conv_wino_act_kernel" in k
-                                                                               or "conv_wino_stats_kernel" in k) else None)
+                                                                               or "conv_wino_stats_kernel" in k or "conv_wino_bnred_kernel" in k) else None)
             if short:
                 per[short].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
