@@ -722,12 +722,12 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   auto P = [&](int i) { return (const float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc, Hp = E;
-  // Only d_mem_in is on the step's critical path (the encoder backward waits for it).  With a second stream and
-  // independent chains, everything d_mem_in does not depend on - the parameter-gradient products, the embedding
-  // gradients, d_q_z - is queued on the second stream AFTER the call has released the first one, where it runs beside
-  // the encoder backward.  The caller then owns two obligations (include/acvae_hip.h): the second stream must be joined
-  // before the gradients / d_q_z are read on another stream, and saved / scratch / the incoming gradients must stay
-  // untouched until it has drained.
+  // d_mem_in and d_q_z are on the step's critical path (the encoder backward waits for d_mem_in and, through the posterior's
+  // backward, for d_q_z).  With a second stream and independent chains, everything else - the parameter-gradient products,
+  // the embedding gradients - is queued on the second stream AFTER the call has released the first one, where it runs beside
+  // the posterior's and the encoder's backward.  The caller then owns two obligations (include/acvae_hip.h): the second
+  // stream must be joined before the parameter gradients are read on another stream, and saved / scratch / the incoming
+  // gradients must stay untouched until it has drained.
   const bool defer = acvae_decode_bwd_defers(dis_flags_host, Tc, stream, aux_stream, flags) != 0;
   const bool has_ln = Eenc != E || params[TP_LN_W] != nullptr;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
@@ -831,8 +831,23 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   auto dec_memgrad = [&]() -> int {
     return gemm(dencproj, A, wt_datt + (long)H * A, A, nullptr, dmem, E, N * S, E, A, 1, st);
   };
-  // batched parameter gradients of the decoder, the embedding gradient and d_q_z
-  auto dec_params = [&](const Ctx& c, TnWs ws, double* dp) -> int {
+  // d z of the decoder's input gates, routed to the posterior sample (here) or to the prior sample (prior chain, below), per
+  // step.  The posterior's backward waits for d_q_z and the encoder's backward for the posterior's (its pooled audio
+  // embedding): in deferred mode this product stays on the FIRST stream (round 4: at the tail of the trailing work it held the
+  // encoder backward back by the whole 0.6 ms of parameter-gradient products in front of it).
+  auto dec_dz = [&](const Ctx& c) -> int {
+    ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, c));  // d z
+    if (!prior_feeds_decoder) {
+      ACVAE_TRY(acvae::copy_rows(d_q_z, E, dz_dec, E, R, E, c));
+    } else {
+      for (int t = 0; t < Tc; ++t)
+        ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
+                                   (long)Tc * E, N, E, c));
+    }
+    return ACVAE_OK;
+  };
+  // batched parameter gradients of the decoder, the embedding gradient and (with_dz) d_q_z
+  auto dec_params = [&](const Ctx& c, TnWs ws, double* dp, bool with_dz = true) -> int {
     ACVAE_TRY(gemm_tn(dgi, 3 * H, rnn_d, 3 * E, G(TP_DEC_WIH), 3 * E, 3 * H, 3 * E, R, ws, c));
     ACVAE_TRY(acvae::colsum2(dgi, R, 3 * H, dp, G(TP_DEC_BIH), nullptr, 0, c));
     ACVAE_TRY(gemm_tn(dgh, 3 * H, hprev_d, H, G(TP_DEC_WHH), H, 3 * H, H, R, ws, c));
@@ -846,17 +861,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, c));                    // d emb
     if (emb_keep)          // back through the word-embedding dropout
       ACVAE_TRY(acvae::dropout_rows(drnn, (long)Tc * E, E, emb_keep, E, (long)N * E, emb_drop_p < 1.f ? 1.f / (1.f - emb_drop_p) : 0.f, N, Tc, E, c));
-    ACVAE_TRY(gemm(dgi, 3 * H, wt_dih + (long)2 * E * 3 * H, 3 * H, nullptr, dz_dec, E, R, E, 3 * H, 0, c));  // d z
+    if (with_dz) ACVAE_TRY(dec_dz(c));
     ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, c));
     ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, c));
-    // route dz to the posterior sample (here) or to the prior sample (prior chain, below), per step
-    if (!prior_feeds_decoder) {
-      ACVAE_TRY(acvae::copy_rows(d_q_z, E, dz_dec, E, R, E, c));
-    } else {
-      for (int t = 0; t < Tc; ++t)
-        ACVAE_TRY(acvae::copy_rows(d_q_z + (long)t * E, (long)Tc * E, dis_flags_host[t] ? nullptr : dz_dec + (long)t * E,
-                                   (long)Tc * E, N, E, c));
-    }
     return ACVAE_OK;
   };
 
@@ -1003,10 +1010,11 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   } else {
     ACVAE_TRY(acvae::copy_rows(d_mem_in, E, dmem, E, N * S, E, st));
   }
-  if (defer) {                 // everything else: behind the first stream's work so far, on the second stream
+  if (defer) {                 // d_q_z on the first stream; everything else behind the first stream's work so far, on the second
+    ACVAE_TRY(dec_dz(st));
     ACVAE_TRY(Fork::edge(st.s, sp.s));
     ACVAE_TRY(heads_params(sp, tn_p, dpart_p));
-    ACVAE_TRY(dec_params(sp, tn_p, dpart_p));
+    ACVAE_TRY(dec_params(sp, tn_p, dpart_p, false));
     ACVAE_TRY(prior_params());
   }
   return ACVAE_OK;

@@ -147,7 +147,7 @@ class TrainStep:
             model._grad_ready_cb = self._on_grads_ready
             model.encoder._grad_ready_cb = self._on_grads_ready
         self._buf_work = None
-        self._decode_event = self._text_event = None
+        self._decode_event = self._decode_aux_event = self._text_event = None
         self._decode_deferred = self._projemb_seen = False
         self._proj_emb = isinstance(model.decoder.word_embeddings, torch.nn.Sequential)
         # The BatchNorm-buffer broadcast issued at the end of step() is joined wherever the buffers are read outside
@@ -231,9 +231,9 @@ class TrainStep:
             if not self._proj_emb:               # with projected embeddings their gradients are still to come ("projemb")
                 self.exchange.ready(0)
         elif tag == "decode_deferred":
-            # trailing-gradient mode: the decode backward's parameter gradients are still running on the SIDE stream;
-            # `event` (main stream) does not cover them, the stream "text" fires on does
-            self._decode_event = event
+            # trailing-gradient mode: the decode backward's parameter gradients are still running on the decode calls' SECOND
+            # stream: `event` = (event on the main stream, event behind the trailing work on the second stream)
+            self._decode_event, self._decode_aux_event = event
             self._decode_deferred = True
         elif tag == "projemb":
             # _ProjTableFn's backward: the last three decode-side gradients.  Autograd runs it after the decode backward
@@ -243,15 +243,16 @@ class TrainStep:
             # mode, nothing on this stream covers the side stream's work yet: leave the bucket to "text".
             self._projemb_seen = True
             if self._text_event is not None or not self._decode_deferred:
-                self.exchange.ready(0, after=(self._decode_event, self._text_event))
+                self.exchange.ready(0, after=(self._decode_event, self._decode_aux_event, self._text_event))
         elif tag == "text":
             if torch.cuda.is_available() and self.flat_g.is_cuda:
                 self._text_event = torch.cuda.Event()
                 self._text_event.record(torch.cuda.current_stream())
-            # decode-written gradients not announced yet (trailing-gradient mode): they were queued on this (side)
-            # stream or on the main stream behind `_decode_event`; with projected embeddings bucket 0 waits for "projemb"
+            # decode-written gradients not announced yet (trailing-gradient mode): they were queued on the decode calls' second
+            # stream (`_decode_aux_event`) or on the main stream behind `_decode_event`; with projected embeddings bucket 0
+            # waits for "projemb"
             if not self._proj_emb or self._projemb_seen:
-                self.exchange.ready(0, after=(self._decode_event,))
+                self.exchange.ready(0, after=(self._decode_event, self._decode_aux_event))
             self.exchange.ready(1)
         elif isinstance(tag, tuple):
             if tag[1] == self.model.encoder.N_BLOCKS:
@@ -308,7 +309,7 @@ class TrainStep:
             cur = torch.cuda.current_stream()
             cur.wait_event(ready)
             feats.record_stream(cur)
-        self._decode_event = self._text_event = None
+        self._decode_event = self._decode_aux_event = self._text_event = None
         self._decode_deferred = self._projemb_seen = False
         for p in self.order:
             p.grad = None                                             # optimizer.zero_grad(set_to_none=True)

@@ -99,12 +99,15 @@ class _DecodeFn(torch.autograd.Function):
             ev.record(torch.cuda.current_stream())
             if not defers:                       # every gradient this call writes is ordered on the current stream
                 model._grad_ready_cb("decode", ev)
-            else:
-                model._grad_ready_cb("decode_deferred", ev)
+            else:                                # ... or on the decode calls' second stream: a second event behind its trailing work
+                ev_aux = torch.cuda.Event()
+                ev_aux.record(model._side_stream(torch.cuda.current_stream()))
+                model._grad_ready_cb("decode_deferred", (ev, ev_aux))
         if defers:
-            # The parameter gradients and d_q_z are still being computed on the side stream (beside the encoder backward
-            # that starts now).  Their consumers: the posterior backward (same stream: ordered), the gradient exchange
-            # announced from there, and whoever reads .grad after backward() - joined here at the end of the pass.
+            # The parameter gradients are still being computed on the decode calls' second stream (beside the posterior's and
+            # the encoder's backward, which start now: d_mem and d_q_z are complete on the current stream).  Their consumers:
+            # the gradient exchange (the event above) and whoever reads .grad after backward() - joined here at the end of
+            # the pass.
             side, cur = model._side_stream(torch.cuda.current_stream()), torch.cuda.current_stream()
             for t in [ctx.saved, outputs, d_qz] + [u for u in ups if u is not None]:
                 t.record_stream(side)                      # freed by autograd while the side stream still reads them
@@ -325,9 +328,19 @@ class Hybrid_VAEModel(CaptionModel):
         _lib.check_persist_status(dev)
 
     def _side_stream(self, main):
+        """Second stream of the decode calls (prior chain forward, trailing parameter gradients backward)."""
         if getattr(self, "_side", None) is None or self._side.device != main.device:
-            self._side = torch.cuda.Stream(device=main.device)
+            self._side = torch.cuda.Stream(device=main.device, priority=int(os.environ.get("ACVAE_SIDE_PRIO", "0")))
         return self._side
+
+    def _post_stream(self, main):
+        """The posterior's own stream (forward beside the encoder, backward beside the decode calls' trailing parameter
+        gradients: on the SAME stream its backward - which the encoder's backward waits for - sat behind 0.6 ms of them)."""
+        if os.environ.get("ACVAE_POST_STREAM", "1") == "0":       # A/B: the posterior on the decode calls' second stream, as until round 4
+            return self._side_stream(main)
+        if getattr(self, "_side_q", None) is None or self._side_q.device != main.device:
+            self._side_q = torch.cuda.Stream(device=main.device, priority=int(os.environ.get("ACVAE_POST_PRIO", "0")))
+        return self._side_q
 
     def _aux_stream(self):
         """Second HIP stream handle for the decode calls (prior chain beside the decoder chain), or None."""
@@ -359,7 +372,7 @@ class Hybrid_VAEModel(CaptionModel):
             # HIP stream beside the MFMA-bound encoder; autograd replays its backward on that stream too, where it
             # overlaps with the encoder backward.
             main = torch.cuda.current_stream()
-            side = self._side_stream(main) if self.use_side_stream else main
+            side = self._post_stream(main) if self.use_side_stream else main
             eps_q = None if self.noise is None else self.noise.get("eps_q")
             if eps_q is None:                                      # same generator order as the reference: the
                 lens1 = np.asarray(cap_lens) - 1                   # posterior's randn precedes the per-step draws

@@ -404,12 +404,12 @@ int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, con
                              const uint8_t* emb_keep, float emb_drop_p, int flags);
 /* Backward for upstream gradients of logits / outputs / p_means / p_logs / p_z / p_means_utt (each may be
  * NULL).  Writes every decoder / pnet / mean_log_out / ln gradient, d_mem_in [N,S,Eenc] and d_q_z [N,Tc,E].
- * Stream contract: d_mem_in is ordered on `stream` when the call returns.  With ACVAE_FLAG_DEFER_PARAM_GRADS, when
+ * Stream contract: d_mem_in and d_q_z are ordered on `stream` when the call returns.  With ACVAE_FLAG_DEFER_PARAM_GRADS, when
  * acvae_decode_bwd_defers says 1 for the same flags / streams (a second stream is given and no step fed the prior's z to the
- * decoder), everything d_mem_in does not depend on - the parameter gradients and d_q_z - is queued on `aux_stream` behind
- * the call, so that it runs beside whatever `stream` does next (the encoder backward): the caller joins aux_stream before
- * those results are read on another stream, and keeps saved / scratch / outputs / the upstream gradients untouched until
- * aux_stream has drained.  Without the flag (0) everything is ordered on `stream` on return.  Hybrid_VAEModel, which joins
+ * decoder), everything else - the parameter gradients - is queued on `aux_stream` behind
+ * the call, so that it runs beside whatever `stream` does next (the posterior's and the encoder's backward): the caller joins
+ * aux_stream before those gradients are read on another stream, and keeps saved / scratch / outputs / the upstream gradients
+ * untouched until aux_stream has drained.  Without the flag (0) everything is ordered on `stream` on return.  Hybrid_VAEModel, which joins
  * the second stream at the end of the backward pass, passes it unless ACVAE_DECODE_DEFER=0 (-0.07 ms per step on the
  * reference configuration). */
 int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream, int flags);
