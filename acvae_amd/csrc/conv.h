@@ -86,6 +86,7 @@ int bn_finalize(const float* partials, int P, int C, double count, const float* 
 long colsum_scratch_doubles(int width);
 // zero the tickets at the head of a dpart scratch: once per composite call, in front of its first column sum / bn_finalize
 int colsum_tickets_reset(double* dpart, hipStream_t st);
+long colsum_ticket_words();             // ... the same tickets as a region for a ZeroBatch (rnn.h)
 // deterministic column sums of x[P][width] (ld == width): out[i] = sum_p x[p][i]; entries >= split (if > 0) go to out2
 int colsum2(const float* x, int P, int width, double* dpart, float* out, float* out2, int split, hipStream_t st);
 int conv1_first_blocks(int N, int T);
@@ -125,6 +126,11 @@ int acvae_gemm_nt_dual(const float* A1, int64_t lda1, const float* B1, int64_t l
 int acvae_gemm_nt_pair(const float* A0, int64_t lda0, const float* B0, int64_t ldb0, int K0, const float* bias0, float* C0,
                        int64_t ldc0, int N0, int acc0, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, int K1,
                        const float* bias1, float* C1, int64_t ldc1, int N1, int acc1, int M, hipStream_t st);
+// gemm_tn with its slab sum in the same launch (gemm.hip); ws = [TN_TICKETS words, zeroed once per composite call | slabs]
+constexpr int TN_TICKETS = 256;
+int acvae_gemm_tn_fused(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                        int accumulate, float* ws, int64_t ws_bytes, hipStream_t st);
 long acvae_skinny_ws_floats();
+long acvae_skinny_ticket_words();       // words at the head of a skinny workspace that a composite call zeroes once
 int acvae_skinny_ws_reset(float* ws, hipStream_t st);
 #include "transpose_batch.h"

@@ -1547,6 +1547,7 @@ int colsum2(const float* partials, int P, int width, double* dpart, float* out, 
 }
 long colsum_scratch_doubles(int width) { return CS_TICKETS / 2 + (long)CS_R * width; }
 // the tickets at the head of a dpart scratch start at zero: once per composite call, in front of its first column sum
+long colsum_ticket_words() { return CS_TICKETS; }
 int colsum_tickets_reset(double* dpart, hipStream_t st) {
   return hipMemsetAsync(dpart, 0, CS_TICKETS * sizeof(unsigned), st) == hipSuccess ? ACVAE_OK : (int)hipGetLastError();
 }

@@ -62,6 +62,9 @@ struct PbParams {
 
 namespace acvae {
 bool decode_persist_bwd_ok(int N, int Tc, int S, int E, int H, int A);
+// internal flag beside the public ACVAE_FLAG_* of a launch: the caller has zeroed p.cnt in this stream (with its other tickets,
+// one launch: rnn.h ZeroBatch) - the launcher skips its own memset
+#define ACVAE_FLAG_INT_CNT_ZEROED (1 << 16)
 long decode_persist_bwd_counter_words(int Tc);
 int decode_persist_bwd_rc_splits(int S);     // attention workgroups per clip (64 frames each)
 int decode_persist_bwd(PbParams p, hipStream_t st, int flags);

@@ -1364,7 +1364,8 @@ bool persist_fits(K kernel, int kid, int grid, size_t shm) {
 }
 // memset of the counters, the launch and its tail, chained behind the device's previous persistent launch
 template <class K, class P>
-int persist_launch(K kernel, int kid, const P& p, int grid, size_t shm, long counter_words, const PoisonList& poison, hipStream_t st) {
+int persist_launch(K kernel, int kid, const P& p, int grid, size_t shm, long counter_words, const PoisonList& poison, hipStream_t st,
+                   bool zeroed = false) {
   int dev = 0;
   ACVAE_TRY(persist_device(dev));
   PersistSlot& sl = g_slot[dev];
@@ -1374,7 +1375,7 @@ int persist_launch(K kernel, int kid, const P& p, int grid, size_t shm, long cou
   } else if (hipStreamWaitEvent(st, sl.done, 0) != hipSuccess) {
     return (int)hipGetLastError();
   }
-  if (hipMemsetAsync(p.cnt, 0, (size_t)counter_words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
+  if (!zeroed && hipMemsetAsync(p.cnt, 0, (size_t)counter_words * sizeof(unsigned), st) != hipSuccess) return (int)hipGetLastError();
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(PD_THREADS), shm, st, p);
   hipLaunchKernelGGL(persist_tail_kernel, dim3(1), dim3(1024), 0, st, p.abort_word, sl.status.load(), kid, poison);
   ACVAE_LAUNCH_CHECK();
@@ -1450,7 +1451,7 @@ int decode_persist_fwd(PdParams p, hipStream_t st, int flags) {
   PoisonList poison{};
   poison_add(poison, p.outputs, R * p.H); poison_add(poison, p.p_means, R * p.E); poison_add(poison, p.p_logs, R * p.E);
   poison_add(poison, p.p_z, R * p.E); poison_add(poison, p.attn_w, R * p.S);
-  return persist_launch(decode_persist_kernel, PK_DECODE_FWD, p, grid, shm, words, poison, st);
+  return persist_launch(decode_persist_kernel, PK_DECODE_FWD, p, grid, shm, words, poison, st, (flags & ACVAE_FLAG_INT_CNT_ZEROED) != 0);
 }
 
 // ---- decode backward
@@ -1494,7 +1495,8 @@ int decode_persist_bwd(PbParams p, hipStream_t st, int flags) {
   poison_add(poison, p.dgi, R * 3 * p.H); poison_add(poison, p.dgh, R * 3 * p.H); poison_add(poison, p.dgates, R * 4 * p.E);
   poison_add(poison, p.dml_all, R * 2 * p.E); poison_add(poison, p.dctx, R * p.E); poison_add(poison, p.dqd, R * p.A);
   poison_add(poison, p.dencproj, (long)p.N * p.S * p.A);
-  ACVAE_TRY(persist_launch(decode_persist_bwd_kernel, PK_DECODE_BWD, p, grid, decode_bwd_shm(p.S, p.A), words, poison, st));
+  ACVAE_TRY(persist_launch(decode_persist_bwd_kernel, PK_DECODE_BWD, p, grid, decode_bwd_shm(p.S, p.A), words, poison, st,
+                           (flags & ACVAE_FLAG_INT_CNT_ZEROED) != 0));
   // (dctx poisoned = NaN in dmem: attn_dmem_kernel forms it from dctx behind the tail)
   hipLaunchKernelGGL(attn_dmem_kernel, dim3(p.N * p.S), dim3(256), 0, st, p.attn_w, p.dctx, p.dmem, p.Tc, p.S, p.E);
   ACVAE_LAUNCH_CHECK();
@@ -1518,7 +1520,7 @@ int posterior_persist_fwd(PqParams p, hipStream_t st, int flags) {
   PoisonList poison{};
   poison_add(poison, p.hid, (long)p.N * p.Tc * 2 * p.Hq);
   return persist_launch(posterior_persist_fwd_kernel, PK_POST_FWD, p, grid, sizeof(PqSmem), posterior_persist_counter_words(p.Tc),
-                        poison, st);
+                        poison, st, (flags & ACVAE_FLAG_INT_CNT_ZEROED) != 0);
 }
 int posterior_persist_bwd(PqbParams p, hipStream_t st, int flags) {
   if (!posterior_persist_ok(p.N, p.Tc, p.Hq)) return ACVAE_EUNSUPPORTED;
@@ -1531,6 +1533,6 @@ int posterior_persist_bwd(PqbParams p, hipStream_t st, int flags) {
     poison_add(poison, p.dgh[dir], (long)p.N * p.Tc * 3 * p.Hq);
   }
   return persist_launch(posterior_persist_bwd_kernel, PK_POST_BWD, p, grid, sizeof(PqSmem), posterior_persist_counter_words(p.Tc),
-                        poison, st);
+                        poison, st, (flags & ACVAE_FLAG_INT_CNT_ZEROED) != 0);
 }
 }  // namespace acvae

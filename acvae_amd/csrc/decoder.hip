@@ -47,8 +47,12 @@ inline int gemm2(const float* A1, long lda1, const float* B1, long ldb1, int K1,
 struct TnWs { float* p; long bytes; };
 inline int gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K, TnWs ws,
                    hipStream_t st) {
-  return acvae_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, 0, ws.p, ws.bytes, st);
+  return acvae_gemm_tn_fused(A, lda, B, ldb, C, ldc, M, N, K, 0, ws.p, ws.bytes, st);     // ws: tickets (zeroed at the call's entry) | slabs
 }
+// the regions every composite call zeroes in front of its first kernel, in ONE launch (rnn.h)
+inline void zb_skinny(acvae::ZeroBatch& zb, float* skws) { zb.add(skws, acvae_skinny_ticket_words()); }
+inline void zb_colsum(acvae::ZeroBatch& zb, double* dpart) { zb.add(dpart, acvae::colsum_ticket_words()); }
+inline void zb_tn(acvae::ZeroBatch& zb, TnWs ws) { zb.add(ws.p, TN_TICKETS); }
 inline int transp(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, hipStream_t st) {
   return acvae_transpose(in, ld_in, out, ld_out, rows, cols, st);
 }
@@ -85,7 +89,7 @@ struct Fork {
   int begin() const { return on() ? edge(main_s, aux) : ACVAE_OK; }
   int join() const { return on() ? edge(aux, main_s) : ACVAE_OK; }
 };
-inline long tn_ws_floats(int M, int N, int K) { return acvae_gemm_tn_workspace_bytes(M, N, K) / 4 + 64; }
+inline long tn_ws_floats(int M, int N, int K) { return acvae_gemm_tn_workspace_bytes(M, N, K) / 4 + 64 + TN_TICKETS; }
 
 // text-parameter table (state-dict order after the encoder; see include/acvae_hip.h)
 enum {
@@ -259,7 +263,17 @@ extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* cap
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
   Ctx st{(hipStream_t)stream, sc + L.skws};
-  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
+  const bool persist_q = !(flags & ACVAE_FLAG_NO_PERSIST) && acvae::posterior_persist_ok(N, Tc, Hq);
+  {
+    acvae::ZeroBatch zb;
+    zb_skinny(zb, st.skws);
+    if (persist_q) {
+      zb.add(sc + L.pq_cnt, acvae::posterior_persist_counter_words(Tc));
+      zb.add(sc + L.pq_hbuf, (long)4 * N * Hq);
+      flags |= ACVAE_FLAG_INT_CNT_ZEROED;
+    }
+    ACVAE_TRY(acvae::zero_batch(zb, st.s));
+  }
   auto P = [&](int i) { return (const float*)params[i]; };
   const int R = N * Tc;
   int64_t* words = (int64_t*)(sv + L.words);
@@ -267,7 +281,7 @@ extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* cap
   float* hid = sv + L.hidden;
   ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));            // x[:, :-1] restricted to Tc steps
   ACVAE_TRY(acvae::embed_gather(words, 1, P(TP_Q_EMB), V, X, E, R, E, st));
-  if (!(flags & ACVAE_FLAG_NO_PERSIST) && acvae::posterior_persist_ok(N, Tc, Hq)) {
+  if (persist_q) {
     // both directions, all steps: one launch (decode_persist.hip); the hoisted input projections first
     PqParams pq;
     for (int dir = 0; dir < 2; ++dir) {
@@ -280,8 +294,7 @@ extern "C" int acvae_posterior_fwd(const void* const* params, const int64_t* cap
     }
     pq.lens1 = lens1; pq.hid = hid; pq.hbuf = sc + L.pq_hbuf; pq.cnt = (unsigned*)(sc + L.pq_cnt);
     pq.N = N; pq.Tc = Tc; pq.Hq = Hq;
-    ACVAE_TRY(zero(pq.hbuf, (long)4 * N * Hq, st));
-    ACVAE_TRY(acvae::posterior_persist_fwd(pq, st.s, flags));
+    ACVAE_TRY(acvae::posterior_persist_fwd(pq, st.s, flags));          // hbuf and the counters: zeroed at the entry
   } else
   for (int dir = 0; dir < 2; ++dir) {
     const int o = dir * 4;
@@ -319,13 +332,18 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   float* sv = (float*)saved_v;
   float* sc = (float*)scratch_v;
   Ctx st{(hipStream_t)stream, sc + L.skws};
-  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc;
   TnWs tn{sc + L.tn, L.tn_floats * 4};
   double* dpart = (double*)(sc + L.dpart);
-  ACVAE_TRY(acvae::colsum_tickets_reset(dpart, st.s));
+  const bool persist = !(flags & ACVAE_FLAG_NO_PERSIST) && acvae::posterior_persist_ok(N, Tc, Hq);
+  {
+    acvae::ZeroBatch zb;
+    zb_skinny(zb, st.skws); zb_colsum(zb, dpart); zb_tn(zb, tn);
+    if (persist) { zb.add(sc + L.pq_cnt, acvae::posterior_persist_counter_words(Tc)); flags |= ACVAE_FLAG_INT_CNT_ZEROED; }
+    ACVAE_TRY(acvae::zero_batch(zb, st.s));
+  }
   const int64_t* words = (const int64_t*)(sv + L.words);
   float* X = sv + L.x;
   float* hid = sv + L.hidden;
@@ -341,7 +359,6 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   ACVAE_TRY(gemm_tn(dml, 2 * E, hid, 2 * Hq, G(TP_Q_TML_W), 2 * Hq, 2 * E, 2 * Hq, R, tn, st));
   ACVAE_TRY(acvae::colsum2(dml, R, 2 * E, dpart, G(TP_Q_TML_B), nullptr, 0, st));
   float* dx = sc + L.dx;
-  const bool persist = !(flags & ACVAE_FLAG_NO_PERSIST) && acvae::posterior_persist_ok(N, Tc, Hq);
   if (persist) {                 // BPTT of both directions in one launch; the parameter products below are unchanged
     PqbParams pb;
     for (int dir = 0; dir < 2; ++dir) {
@@ -457,16 +474,17 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
   Ctx st{(hipStream_t)stream, sc + L.skws};
   const Fork fork{st.s, (aux_stream && teacher) ? (hipStream_t)aux_stream : st.s};
   Ctx sp{fork.aux, sc + L.skws_p};
-  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
-  ACVAE_TRY(acvae_skinny_ws_reset(sp.skws, st.s));
   // the step-by-step paths may use the split-over-frames attention: its arrival counters start at zero (ordered in front of
   // the fork); the persistent launch has its own attention
   const bool persist_fwd = teacher && !prior_feeds_decoder && !(flags & ACVAE_FLAG_NO_PERSIST) && H == E &&
                            acvae::decode_persist_ok(N, Tc, S, E, H, A);
   const bool attws_ready = !persist_fwd && L.attfws_bytes > 0;
-  if (attws_ready) {
-    ACVAE_TRY(zero(sc + L.attfws_d, 256, st.s));
-    ACVAE_TRY(zero(sc + L.attfws_p, 256, st.s));
+  {   // every ticket / counter of the call in one launch, in front of the fork
+    acvae::ZeroBatch zb;
+    zb_skinny(zb, st.skws); zb_skinny(zb, sp.skws);
+    if (attws_ready) { zb.add(sc + L.attfws_d, 256); zb.add(sc + L.attfws_p, 256); }
+    if (persist_fwd) { zb.add(sc + L.pd_cnt, acvae::decode_persist_counter_words(Tc)); flags |= ACVAE_FLAG_INT_CNT_ZEROED; }
+    ACVAE_TRY(acvae::zero_batch(zb, st.s));
   }
 
   int64_t* words = (int64_t*)(sv + L.words);
@@ -717,8 +735,6 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   Ctx st{(hipStream_t)stream, sc + L.skws};
   const Fork fork{st.s, aux_stream ? (hipStream_t)aux_stream : st.s};
   Ctx sp{fork.aux, sc + L.skws_p};
-  ACVAE_TRY(acvae_skinny_ws_reset(st.skws, st.s));
-  ACVAE_TRY(acvae_skinny_ws_reset(sp.skws, st.s));
   auto P = [&](int i) { return (const float*)params[i]; };
   auto G = [&](int i) { return (float*)grads[i]; };
   const int R = N * Tc, Hp = E;
@@ -734,8 +750,18 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   TnWs tn_p{sc + L.tn_p, L.tn_p_floats * 4};
   double* dpart = (double*)(sc + L.dpart);
   double* dpart_p = (double*)(sc + L.dpart_p);
-  ACVAE_TRY(acvae::colsum_tickets_reset(dpart, st.s));        // in front of the fork: both chains' column sums start from zeroed tickets
-  ACVAE_TRY(acvae::colsum_tickets_reset(dpart_p, st.s));
+  const bool persist_bwd = !prior_feeds_decoder && !(flags & ACVAE_FLAG_NO_PERSIST) && acvae::decode_persist_bwd_ok(N, Tc, S, E, H, A);
+  {   // in front of the fork: both chains' tickets (skinny split-K, column sums, gemm_tn tiles), the persistent launch's arrival
+      // counters and the prior attention's memory gradient - one launch instead of eight memsets
+    acvae::ZeroBatch zb;
+    zb_skinny(zb, st.skws); zb_skinny(zb, sp.skws); zb_colsum(zb, dpart); zb_colsum(zb, dpart_p); zb_tn(zb, tn); zb_tn(zb, tn_p);
+    if (persist_bwd) {
+      zb.add(sc + L.pd_cnt_b, acvae::decode_persist_bwd_counter_words(Tc));
+      zb.add(sc + L.dmem_p, (long)N * S * E);
+      flags |= ACVAE_FLAG_INT_CNT_ZEROED;
+    }
+    ACVAE_TRY(acvae::zero_batch(zb, st.s));
+  }
   const int64_t* words = (const int64_t*)(sv + L.words);
   float* mem = sv + L.mem;
   float* rnn_d = sv + L.rnn_d;
@@ -958,13 +984,12 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     for (int t = Tc - 1; t >= 0; --t) ACVAE_TRY(prior_bptt(t));
     ACVAE_TRY(prior_memgrad());
     ACVAE_TRY(prior_params());
-  } else if (!(flags & ACVAE_FLAG_NO_PERSIST) && acvae::decode_persist_bwd_ok(N, Tc, S, E, H, A)) {
+  } else if (persist_bwd) {
     // independent chains: the Tc steps of both BPTT chains as ONE persistent launch on the first stream
     // (decode_persist.hip); everything batched behind it runs as before, the prior's share on the second stream.  Of
     // prior_begin() only the zeroing of the prior attention's memory gradient is needed (and its memsets of dhp / dc / dlz
     // on the second stream would race with the launch, which uses dhp as a hand-off buffer).
-    ACVAE_TRY(zero(dmem_p, (long)N * S * E, sp));
-    PbParams pb{};
+    PbParams pb{};                                   // (dmem_p: zeroed at the entry)
     pb.wt_dhh = wt_dhh; pb.wt_datt = wt_datt; pb.wt_dih = wt_dih; pb.wt_phh = wt_phh; pb.wt_pih = wt_pih; pb.wt_pml = wt_pml;
     pb.att_v = P(TP_DEC_ATT_V);
     pb.encproj = sv + L.encproj_d; pb.mem = mem; pb.qd = qd; pb.attn_w = attn_w; pb.gru_save = gru_save; pb.hprev_d = hprev_d;

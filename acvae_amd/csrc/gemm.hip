@@ -6,6 +6,7 @@
 #include "mfma_tile.h"
 #include "transpose_batch.h"
 #include "../../include/acvae_hip.h"
+#include "conv.h"
 
 namespace {
 using namespace mfma;
@@ -46,6 +47,56 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, long slab_str
     const int m = (int)(i / N), n = (int)(i % N);
     float acc = 0.f;
     for (int z = 0; z < nsplit; ++z) acc += slab[z * slab_stride + i];
+    float* p = C + (long)m * ldc + n;
+    *p = accumulate ? *p + acc : acc;
+  }
+}
+
+// gemm_tn with the slab sum inside (the composite calls' form: 12 launches of slab_reduce_kernel per step): every K-slice
+// writes its partial tile to its slab and takes a ticket of the TILE; the block that draws the last one sums the tile's slices
+// IN SLICE ORDER - the arithmetic of slab_reduce_kernel, bit for bit - into C.  Hand-off without fences: the partial tile is
+// stored write-through (sc1), drained (vmcnt(0)) in front of the barrier and the ticket, and read back with sc1 loads.  (With
+// __threadfence() around the ticket - a write-back and an invalidate of the XCD's whole L2 per workgroup - the Winograd weight
+// gradient running beside these products on the first stream lost 18 %: 0.55 -> 0.65 ms per launch, +0.8 ms per step.)
+// Tickets: one word per output tile, zeroed once per composite call, reset by the reducer.
+template <int WM, int WN, bool VEC4>
+__global__ __launch_bounds__(256, 2) void gemm_tn_fused_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                               long ldb, float* __restrict__ slab, float* __restrict__ C, long ldc,
+                                                               int M, int N, int K, int k_per, int accumulate, long slab_stride,
+                                                               unsigned* __restrict__ tickets) {
+  __shared__ TnSmem<WM, WN> sm;
+  __shared__ int s_last;
+  PlainKMajorLoader<VEC4> al{A, lda, M, K}, bl{B, ldb, N, K};
+  const int kb = blockIdx.z * k_per;
+  const int ke = min(K, kb + k_per);
+  tn_block<WM, WN, true>(al, bl, M, N, kb, ke, blockIdx.x, blockIdx.y, slab + (long)blockIdx.z * slab_stride, (long)N, 0, sm);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* tk = tickets + blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.z - 1 ? 1 : 0;
+    if (s_last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  constexpr int TM = WM * 64, TN = WN * 64;
+  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const int nsplit = gridDim.z;
+  for (int i = threadIdx.x; i < TM * TN; i += 256) {
+    const int m = m0 + i / TN, n = n0 + i % TN;
+    if (m >= M || n >= N) continue;
+    const long e = (long)m * N + n;
+    float acc = 0.f;
+    for (int z0 = 0; z0 < nsplit; z0 += 8) {          // eight loads in flight; the additions stay in slice order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = z0 + u < nsplit ? __hip_atomic_load(slab + (z0 + u) * slab_stride + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (z0 + u < nsplit) acc += v[u];
+    }
     float* p = C + (long)m * ldc + n;
     *p = accumulate ? *p + acc : acc;
   }
@@ -202,6 +253,7 @@ int acvae_transpose_batch(TransposeBatch& b, hipStream_t st) {
 
 // Internal C++ entry (also used by the composite encoder/decoder drivers).
 long acvae_skinny_ws_floats() { return SK_MAX_TILES + (long)SK_MAX_TILES * 1024; }
+long acvae_skinny_ticket_words() { return SK_MAX_TILES; }
 int acvae_skinny_ws_reset(float* ws, hipStream_t st) {   // zero the ticket counters (first SK_MAX_TILES words)
   return hipMemsetAsync(ws, 0, SK_MAX_TILES * sizeof(unsigned), st) == hipSuccess ? ACVAE_OK : (int)hipGetLastError();
 }
@@ -365,6 +417,33 @@ extern "C" int acvae_gemm_tn(const float* A, int64_t lda, const float* B, int64_
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
                        dim3(256), 0, st, slab_ws, slab_stride, s, C, ldc, M, N, accumulate);
   }
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+
+// ws = [TN_TICKETS words of tickets (zeroed once per composite call) | slabs]
+int acvae_gemm_tn_fused(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                        int accumulate, float* ws, int64_t ws_bytes, hipStream_t st) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ACVAE_EINVAL;
+  int s = tn_splits(M, N, K);
+  const bool narrow = (M <= 64);
+  dim3 grid(cdiv(M, narrow ? 64 : 128), cdiv(N, narrow ? 256 : 128), 1);
+  if (s > 1 && (!ws || ws_bytes < (int64_t)TN_TICKETS * 4 + (int64_t)s * M * N * (int64_t)sizeof(float) ||
+                (long)grid.x * grid.y > TN_TICKETS))
+    return acvae_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, accumulate, nullptr, 0, st);     // one slice per tile, no workspace
+  int k_per = cdiv(cdiv(K, s), BKT) * BKT;
+  s = cdiv(K, k_per);
+  if (s <= 1) return acvae_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, accumulate, nullptr, 0, st);
+  grid.z = s;
+  const bool vec = aligned16(A) && aligned16(B) && (lda & 3) == 0 && (ldb & 3) == 0 && (M & 3) == 0 && (N & 3) == 0;
+  unsigned* tickets = reinterpret_cast<unsigned*>(ws);
+  float* slab = ws + TN_TICKETS;
+#define LAUNCH_TNF(WM_, WN_, V_)                                                                                        \
+  hipLaunchKernelGGL((gemm_tn_fused_kernel<WM_, WN_, V_>), grid, dim3(256), 0, st, A, lda, B, ldb, slab, C, ldc, M, N, K, k_per, \
+                     accumulate, (long)M * N, tickets)
+  if (narrow) { if (vec) LAUNCH_TNF(1, 4, true); else LAUNCH_TNF(1, 4, false); }
+  else        { if (vec) LAUNCH_TNF(2, 2, true); else LAUNCH_TNF(2, 2, false); }
+#undef LAUNCH_TNF
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

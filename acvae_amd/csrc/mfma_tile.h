@@ -304,7 +304,9 @@ struct PlainKMajorLoader {
   }
 };
 
-template <int WM, int WN, class ALoader, class BLoader>
+// WT: the tile is stored write-through (relaxed agent-scope atomic stores: `sc1`) - the form for a partial tile that another
+// workgroup will read in the same launch (gemm.hip: gemm_tn_fused_kernel)
+template <int WM, int WN, bool WT = false, class ALoader, class BLoader>
 __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, int k_begin, int k_end,
                                          int block_m, int block_n, float* C, long ldc, int accumulate,
                                          TnSmem<WM, WN>& sm) {
@@ -385,7 +387,8 @@ __device__ __forceinline__ void tn_block(ALoader al, BLoader bl, int M, int N, i
           float* p = C + (long)m * ldc + n;
           float v = acc[em][en][r];
           if (accumulate) v += *p;
-          *p = v;
+          if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *p = v;
         }
       }
     }

@@ -41,4 +41,12 @@ struct CopyRowsBatch {
   }
 };
 int copy_rows_batch(const CopyRowsBatch& b, hipStream_t st);
+// up to 10 regions of 32-bit words zeroed in ONE launch: the tickets / arrival counters / accumulators a composite call starts
+// from (each was a 5-us hipMemsetAsync in front of the call's first kernel; words % 1 == 0, 4-byte aligned)
+struct ZeroBatch {
+  static constexpr int MAXJ = 10;
+  void* p[MAXJ]; long words[MAXJ]; int n = 0;
+  void add(void* ptr, long w) { if (ptr && w > 0) { p[n] = ptr; words[n] = w; ++n; } }
+};
+int zero_batch(const ZeroBatch& b, hipStream_t st);
 }  // namespace acvae

@@ -290,10 +290,25 @@ __global__ void copy_rows_batch_kernel(acvae::CopyRowsBatch b) {
   }
 }
 
+__global__ void zero_batch_kernel(acvae::ZeroBatch b) {
+  const int j = blockIdx.y;
+  unsigned* p = static_cast<unsigned*>(b.p[j]);
+  const long n = b.words[j];
+  for (long i = blockIdx.x * (long)TH + threadIdx.x; i < n; i += (long)gridDim.x * TH) p[i] = 0u;
+}
+
 }  // namespace
 
 namespace acvae {
 #define LAUNCH(k, g, ...) hipLaunchKernelGGL(k, dim3(g), dim3(TH), 0, st, __VA_ARGS__)
+int zero_batch(const ZeroBatch& b, hipStream_t st) {
+  if (b.n <= 0) return ACVAE_OK;
+  if (b.n > ZeroBatch::MAXJ) return ACVAE_EINVAL;
+  long most = 1;
+  for (int j = 0; j < b.n; ++j) if (b.words[j] > most) most = b.words[j];
+  hipLaunchKernelGGL(zero_batch_kernel, dim3(grid1(most), b.n), dim3(TH), 0, st, b);
+  ACVAE_LAUNCH_CHECK(); return ACVAE_OK;
+}
 int copy_rows_batch(const CopyRowsBatch& b, hipStream_t st) {
   if (b.n <= 0) return ACVAE_OK;
   long most = 1;
