@@ -102,16 +102,36 @@ struct WinoParams {
   int w_shift;          // W = 1 << w_shift
   unsigned bpc_magic;   // x / bpc = umulhi(x, bpc_magic) for x < 2^20, bpc >= 2
   int nn_shift;         // log2(Cout / 64) when that is a power of two, else -1 (generic division)
+  int bn_group;         // order of an XCD's run of tiles: 0 = column block fastest; G = 1, 2, 4: groups of G column blocks, inside a
+                        // group the row block runs through all its values with the G column blocks fastest (see wino_tile_of)
 };
-// (row block, column block) of this workgroup: mfma_tile.h xcd_tile with the launcher's constants instead of divisions
-__device__ __forceinline__ void wino_xcd_tile(const WinoParams& p, int nm, int nn, int& bm, int& bn) {
+// (row block, column block) of position t in the launch's tile order.  bn_outer = 0: the column block runs fastest - the
+// workgroups an XCD runs side by side share their input window (one read from HBM, nn - 1 from its L2) and use ALL nn weight
+// images at once: right while those fit the 4 MB L2 (nn x 4096 x C bytes).  Where they do not (256 -> 256 channels and wider:
+// 4 - 17 MB) every workgroup fetched its 1 - 2 MB image from the Infinity Cache again - 2048 workgroups x 2 MB per launch on
+// the 512-channel layers, FETCH_SIZE 3.0x the algorithmic reads (profiles/r04_e_traffic_conv_igemm.json).  bn_group = G: an XCD
+// works through ALL row blocks with only G column blocks (as many images as fit 2 MB of its L2), then the next G: the input
+// is read nn / G times instead - 771 -> 495 MB per launch on the 512-channel layers (G = 1).
+__device__ __forceinline__ void wino_tile_of(const WinoParams& p, int t, int nm, int nn, int& bm, int& bn) {
+  if (p.bn_group) {
+    const int G = p.bn_group, per = nm * G;              // positions of a group of G column blocks
+    int grp = (int)__fdividef((float)t, (float)per);     // t < 2^23: exact up to +-1, corrected below
+    int rem = t - grp * per;
+    if (rem < 0) { --grp; rem += per; } else if (rem >= per) { ++grp; rem -= per; }
+    bm = rem >> (G >> 1);                                // G is 1, 2 or 4: log2 G = G >> 1
+    bn = grp * G + (rem & (G - 1));
+  } else if (p.nn_shift >= 0) { bn = t & (nn - 1); bm = t >> p.nn_shift; }
+  else { bn = t % nn; bm = t / nn; }
+}
+// position of this workgroup: mfma_tile.h xcd_tile with the launcher's constants instead of divisions
+__device__ __forceinline__ int wino_xcd_tile(const WinoParams& p, int nm, int nn, int& bm, int& bn) {
   const int total = nm * nn;
   const int b = blockIdx.x + blockIdx.y * nm;
   const int q = total >> 3, r = total & 7;
   const int xcd = b & 7, idx = b >> 3;
-  const int t = xcd * q + (xcd < r ? xcd : r) + idx;   // XCD x owns q (+1 if x < r) consecutive tiles, N fastest inside the run
-  if (p.nn_shift >= 0) { bn = t & (nn - 1); bm = t >> p.nn_shift; }
-  else { bn = t % nn; bm = t / nn; }
+  const int t = xcd * q + (xcd < r ? xcd : r) + idx;   // XCD x owns q (+1 if x < r) consecutive positions
+  wino_tile_of(p, t, nm, nn, bm, bn);
+  return t;
 }
 
 // The transform adds as v_pk_add_f32: two values per VALU issue slot.  In-kernel counters and the A/B below say the SIMD's issue
@@ -324,7 +344,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   const int tid = threadIdx.x, lane = tid & 63;
   const int li = lane & 31, h = lane >> 5;
   int bm, bn;
-  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);
+  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);
   const int RW = wino_row_pitch(p.tw_shift), R = p.R;
   const int n = p.bpc == 1 ? bm : (int)__umulhi((unsigned)bm, p.bpc_magic), ty0 = (bm - n * p.bpc) * R;   // (2^32 / 1 does not fit the constant)
   const int H = p.H, W = p.W, C = p.C;
@@ -566,8 +586,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p, float4* raw0
   float pfv = 0.f;
   if (!ACT) {
     const int nn_ = (int)gridDim.y;
-    const int t2 = bm * nn_ + bn + WN_PF_DIST * ((int)gridDim.x * nn_ >= 8 * WN_PF_DIST ? 1 : 0);
-    const int bm2 = p.nn_shift >= 0 ? t2 >> p.nn_shift : t2 / nn_;
+    const int t2 = tpos + WN_PF_DIST * ((int)gridDim.x * nn_ >= 8 * WN_PF_DIST ? 1 : 0);
+    int bm2 = bm, bn2 = bn;
+    if (t2 < (int)gridDim.x * nn_) wino_tile_of(p, t2, (int)gridDim.x, nn_, bm2, bn2);
     const int n2 = p.bpc == 1 ? bm2 : (int)__umulhi((unsigned)bm2, p.bpc_magic), ty2 = (bm2 - n2 * p.bpc) * R;
     const int ry = tid_e >> p.w_shift, x = tid_e & (W - 1);
     const int y = 2 * ty2 - 1 + ry;
@@ -730,6 +751,11 @@ int conv3x3_wino(const float* X, const float* scale, const float* shift, const f
   p.bpc_magic = (unsigned)((0x100000000ULL + (unsigned)p.bpc - 1) / (unsigned)p.bpc);   // ceil(2^32 / bpc): exact for x * bpc < 2^32
   const int nn = Cout / WN_TN;
   p.nn_shift = (nn & (nn - 1)) == 0 ? __builtin_ctz(nn) : -1;
+  {   // column blocks whose weight images (4096 x Cin bytes each) share 2 MB of an XCD's L2; all of them: the plain order
+    int G = 1;
+    while (G < 4 && (long)(2 * G) * 4096 * Cin <= (2L << 20)) G *= 2;
+    p.bn_group = (G < nn && nn % G == 0 && (long)nn * 4096 * Cin > (2L << 20) && (long)N * p.bpc * nn < (1L << 23)) ? G : 0;
+  }
   if ((long)N * p.bpc >= (1L << 20)) return ACVAE_EUNSUPPORTED;
   const dim3 grid(N * p.bpc, Cout / WN_TN);
   prof_begin(ACVAE_PROF_CONV_IGEMM, st);

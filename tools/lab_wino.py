@@ -31,8 +31,8 @@ VARIANTS = {
 }
 # phase stamps (s_memtime): [workgroup][wave][4] = prologue, main loop, epilogue, chunks; written over the start of Y after the epilogue
 VARIANTS["stamps"] = [
-    ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
-     "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_t0 = clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    ("  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_t0 = clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
     (PRE_LOOP, "  const long long lab_t1 = clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float2* exb",
      "  const long long lab_t2 = clock64();\n  float2* exb"),
@@ -53,8 +53,8 @@ VARIANTS["clock"] = [
 # workgroup timeline: [workgroup][wave][4] = start, end (100-MHz wall clock, low 24 bits as float), CU key (XCC id << 8 | HW_ID[15:8]), 0
 VARIANTS["timeline"] = [
     ("      out[0] = o0;\n      out[p.Cout] = o1;\n", "      asm volatile(\"\" :: \"v\"(out), \"v\"(o0), \"v\"(o1));\n"),     # no output stores: the stamps go into Y
-    ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
-     "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    ("  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
     ("                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
      "                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  const int wave = XI;\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
@@ -63,8 +63,8 @@ VARIANTS["timeline"] = [
 # timeline + phases in one launch (output stores kept): wave 0 = start, end, CU key, chunks; wave 1 = main loop start, end (100-MHz
 # ticks, low 24 bits), main-loop shader cycles, 0
 VARIANTS["full"] = [
-    ("  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
-     "  wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
+    ("  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
+     "  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
     (PRE_LOOP, "  const long long lab_c1 = clock64(), lab_r1 = wall_clock64();\n" + PRE_LOOP),
     ("  // ---------------------------------------------------------------- epilogue\n  float2* exb",
      "  const long long lab_c2 = clock64(), lab_r2 = wall_clock64();\n  float2* exb"),

@@ -56,15 +56,20 @@ for k in ("conv_igemm", "conv_wgrad"):
               "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
 wino = not bf16 and os.environ.get("ACVAE_CONV_WINO", "1") != "0"
 res["kernel"] = ("conv_igemm_bf16_kernel<128|64> (bf16 storage, v_mfma_f32_32x32x16_bf16)" if bf16 else
-                 "conv_wino_kernel / _stats_kernel / _act_kernel (conv3x3 as Winograd F(2x2,3x3): data gradient / forward / forward with BatchNorm + ReLU "
-                 "on the operand; all 14 launches of a step averaged)" if wino else
+                 "conv_wino_kernel / _bnred_kernel / _stats_kernel / _act_kernel (conv3x3 as Winograd F(2x2,3x3): data gradient / data gradient + the next "
+                 "BatchNorm backward's sums / forward / forward with BatchNorm + ReLU on the operand; all 14 launches of a step averaged)" if wino else
                  "conv_igemm3_kernel<128|64> (conv3x3 implicit GEMM with horizontal-tap reuse, forward + data gradient)")
 res["hbm_bytes_per_launch"] = res["conv_igemm"]["hbm_bytes_per_launch"]
 # one read of the conv input + one write of its output + the weights, over the 14 launches of a step at B=32, T=1000
 # (7 forward convolutions + 7 data gradients, every layer but the Cin = 1 one): 5.346 GB fp32, 2.673 GB bf16
-res["algorithmic_bytes_per_launch"] = (2.672934912e9 if bf16 else 5.345869824e9) / 14
+# Round 4 (fp32 Winograd): four of the data gradients also reduce the BatchNorm backward that consumes them
+# (conv_wino_bnred_kernel) and read the normalised tensor for it - 0.983 GB per step that bn_bwd_reduce_kernel no longer reads
+conv_bytes = 2.672934912e9 if bf16 else 5.345869824e9
+fused_reads = 0.98304e9 if wino else 0.0
+res["algorithmic_bytes_per_launch"] = (conv_bytes + fused_reads) / 14
+res["algorithmic_reads_per_launch"] = (conv_bytes / 2 + fused_reads) / 14
 res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
-res["fetch_over_algorithmic_reads"] = res["conv_igemm"]["fetch_bytes_per_launch"] / (res["algorithmic_bytes_per_launch"] / 2)
+res["fetch_over_algorithmic_reads"] = res["conv_igemm"]["fetch_bytes_per_launch"] / res["algorithmic_reads_per_launch"]
 json.dump(res, open(os.path.join(dst, f"{tag}_traffic_conv_igemm.json"), "w"), indent=1)
 if not bf16:
     json.dump(res, open(os.path.join(dst, "traffic_conv_igemm.json"), "w"), indent=1)
