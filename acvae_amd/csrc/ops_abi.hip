@@ -143,6 +143,26 @@ extern "C" int acvae_conv3x3_dgrad_wino(const float* dY, const float* W_oihw, fl
   return acvae::conv3x3_wino(dY, nullptr, nullptr, ws + L.wp, dX, nullptr, N, H, W, Cout, Cin, st);
 }
 
+// the data gradient that also reduces the BatchNorm + ReLU backward its output feeds (conv_wino_bnred_kernel): sum_g = sum of the
+// masked gradient (= d beta), sum_gy = sum of masked gradient x normalised activation (= d gamma), as acvae_bn_relu_bwd's first pass
+extern "C" int acvae_conv3x3_dgrad_bnred_wino(const float* dY, const float* W_oihw, float* dX, const float* Yprev, const float* bn_prev,
+                                              float* sum_g, float* sum_gy, void* ws_v, int64_t ws_bytes, int N, int H, int W, int Cin,
+                                              int Cout, void* stream) {
+  if (!conv_dims_ok(N, H, W, Cin, Cout) || !dY || !W_oihw || !dX || !Yprev || !bn_prev || !sum_g || !sum_gy || !ws_v) return ACVAE_EINVAL;
+  if (!acvae::conv3x3_wino_ok(H, W, Cout, Cin)) return ACVAE_EUNSUPPORTED;
+  const ConvWs L = conv_ws(N, H, W, Cin, Cout);
+  const ConvWs Lr = conv_ws(N, H, W, Cout, Cin);          // the partial sums have Cin columns (the data gradient's outputs)
+  if (ws_bytes < L.total * 4 || ws_bytes < Lr.total * 4) return ACVAE_EWORKSPACE;
+  if (!aligned16(ws_v)) return ACVAE_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)ws_v;
+  ACVAE_TRY(acvae::colsum_tickets_reset((double*)(ws + Lr.dpart), st));
+  ACVAE_TRY(acvae::conv3x3_wino_weights(W_oihw, ws + L.wp, Cout, Cin, true, st));
+  const acvae::WinoBnReduce red{Yprev, bn_prev, bn_prev + Cin, bn_prev + 2 * Cin, bn_prev + 3 * Cin};     // scale | shift | mean | invstd
+  ACVAE_TRY(acvae::conv3x3_wino(dY, nullptr, nullptr, ws + L.wp, dX, ws + Lr.partials, N, H, W, Cout, Cin, st, &red));
+  return acvae::colsum2(ws + Lr.partials, acvae::conv_wino_partials_rows(N, H, W), 2 * Cin, (double*)(ws + Lr.dpart), sum_g, sum_gy, Cin, st);
+}
+
 extern "C" int acvae_conv3x3_wgrad_wino(const float* dY, const float* X, const float* in_scale, const float* in_shift,
                                         float* dW_oihw, void* ws_v, int64_t ws_bytes, int N, int H, int W, int Cin, int Cout,
                                         void* stream) {

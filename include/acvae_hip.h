@@ -279,6 +279,14 @@ int acvae_conv3x3_fwd_wino(const float* X, const float* W_oihw, const float* in_
                            int H, int W, int Cin, int Cout, void* stream);
 int acvae_conv3x3_dgrad_wino(const float* dY, const float* W_oihw, float* dX, void* ws, int64_t ws_bytes, int N, int H,
                              int W, int Cin, int Cout, void* stream);
+/* The data gradient of a convolution whose INPUT was relu(batchnorm(Yprev)) - the second convolution of a ConvBlock
+ * (models/encoder.py:631-641) - with the first pass of that BatchNorm + ReLU's backward inside: besides dX it returns
+ * sum_g[Cin] = sum over pixels of g and sum_gy[Cin] = sum of g * (Yprev - mean) * invstd, g = dX where Yprev * scale + shift > 0.
+ * bn_prev = [4][Cin]: scale | shift | mean | invstd (the bn_out of the layer that made Yprev).  The workspace must cover
+ * acvae_conv3x3_workspace_bytes for (Cin, Cout) and for (Cout, Cin). */
+int acvae_conv3x3_dgrad_bnred_wino(const float* dY, const float* W_oihw, float* dX, const float* Yprev, const float* bn_prev,
+                                   float* sum_g, float* sum_gy, void* ws, int64_t ws_bytes, int N, int H, int W, int Cin,
+                                   int Cout, void* stream);
 /* weight gradient in the same form (Cin % 64 == 0, Cout % 64 == 0): 16 GEMMs over the tiles, split over workgroups into
  * fp32 slabs that are summed in fixed order (in double) and folded through G^T . G. */
 int acvae_conv3x3_wgrad_wino(const float* dY, const float* X, const float* in_scale, const float* in_shift, float* dW_oihw,

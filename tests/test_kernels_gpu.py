@@ -156,6 +156,40 @@ def run_conv_wino(N, H, W, Cin, Cout, act, seed=0):
 WINO_SHAPES = [(3, 7, 4), (2, 33, 8), (2, 9, 16)]      # odd H (half-empty last tile row), several / partial row blocks
 
 
+def test_conv3x3_winograd_dgrad_with_bn_backward_sums():
+    """conv_wino_bnred_kernel: the data gradient whose epilogue also reduces the BatchNorm + ReLU backward that consumes it -
+    dX every element against fp64 as for the plain data gradient, the two sums against fp64 sums over the fp64 dX."""
+    for (N, H, W, Cin, Cout) in [(2, 11, 64, 64, 64), (3, 9, 32, 128, 128), (2, 37, 16, 256, 256), (3, 21, 4, 512, 512),
+                                 (2, 33, 8, 64, 128), (5, 40, 64, 64, 64)]:
+        x, w, dy, _, _, _, dx_ref, _ = conv_case(N, H, W, Cin, Cout, False, seed=31 + Cin)
+        g = torch.Generator().manual_seed(7 + Cout)
+        yprev = torch.randn(N, H, W, Cin, generator=g) * 1.3 + 0.2
+        gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        mean, var = yprev.double().mean(dim=(0, 1, 2)), yprev.double().var(dim=(0, 1, 2), unbiased=False)
+        invstd = 1 / torch.sqrt(var + 1e-5)
+        scale = gamma.double() * invstd
+        shift = beta.double() - mean * scale
+        bn = torch.stack([scale, shift, mean, invstd]).float().cuda().contiguous()
+        wsb = max(_lib.call("acvae_conv3x3_workspace_bytes", N, H, W, Cin, Cout), _lib.call("acvae_conv3x3_workspace_bytes", N, H, W, Cout, Cin))
+        ws = ws_buf(wsb)
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        sg, sgy = torch.full((Cin,), float("nan"), device="cuda"), torch.full((Cin,), float("nan"), device="cuda")
+        _lib.call("acvae_conv3x3_dgrad_bnred_wino", nhwc(dy).cuda(), w.cuda().contiguous(), dx, yprev.cuda(), bn, sg, sgy, ws, wsb,
+                  N, H, W, Cin, Cout, S())
+        assert_every_element(dx, nhwc(dx_ref), 9 * Cout, f"wino dgrad+bnred {Cin}->{Cout} {N}x{H}x{W}")
+        # reference sums from the fp64 data gradient under the KERNEL's ReLU decisions (fp32 y * scale + shift, as bn_bwd_reduce_kernel)
+        yd = yprev.double()
+        mask = (yprev * bn[0].cpu() + bn[1].cpu()) > 0
+        gg = nhwc(dx_ref) * mask
+        ref_g = gg.sum(dim=(0, 1, 2))
+        ref_gy = (gg * ((yd - bn[2].cpu().double()) * bn[3].cpu().double())).sum(dim=(0, 1, 2))
+        cnt = N * H * W
+        tol_g = 4e-6 * float(nhwc(dx_ref).abs().max()) * cnt ** 0.5 * 9 + 1e-6
+        assert float((sg.cpu().double() - ref_g).abs().max()) <= tol_g, (float((sg.cpu().double() - ref_g).abs().max()), tol_g)
+        assert float((sgy.cpu().double() - ref_gy).abs().max()) <= 3 * tol_g, (float((sgy.cpu().double() - ref_gy).abs().max()), tol_g)
+        assert float(ref_g.abs().max()) > 100 * tol_g      # the bound means something
+
+
 @pytest.mark.parametrize("Cin,Cout", LAYERS)
 def test_conv3x3_winograd_every_layer_shape_vs_fp64(Cin, Cout):
     shapes = WINO_SHAPES if Cin <= 512 else WINO_SHAPES[:1]
