@@ -89,6 +89,16 @@ int colsum_tickets_reset(double* dpart, hipStream_t st);
 long colsum_ticket_words();             // ... the same tickets as a region for a ZeroBatch (rnn.h)
 // deterministic column sums of x[P][width] (ld == width): out[i] = sum_p x[p][i]; entries >= split (if > 0) go to out2
 int colsum2(const float* x, int P, int width, double* dpart, float* out, float* out2, int split, hipStream_t st);
+// several column sums in ONE launch (the bias gradients of a group of linear layers: up to six 6-14 us launches in a row on the
+// text side); job j: out[i] (and out_b[i], if given: the two LSTM biases share a gradient) = sum_p x[p][i].  Each job keeps the
+// row groups and the order of additions of its own colsum2 launch (bit-identical); they share the tickets and the scratch of
+// one dpart: falls back to separate launches when those do not hold them all.
+struct ColsumBatch {
+  static constexpr int MAXJ = 6;
+  const float* x[MAXJ]; int P[MAXJ], width[MAXJ], R[MAXJ], blk0[MAXJ + 1]; long d0[MAXJ]; float* out[MAXJ]; float* out_b[MAXJ]; int n = 0;
+  void add(const float* xs, int p, int w, float* o, float* ob = nullptr) { x[n] = xs; P[n] = p; width[n] = w; out[n] = o; out_b[n] = ob; ++n; }
+};
+int colsum_batch(ColsumBatch& b, double* dpart, long dpart_doubles, hipStream_t st);
 int conv1_first_blocks(int N, int T);
 template <class TY>
 int conv1_first_fwd(const float* x, const float* scale0, const float* shift0, const float* W1, TY* Y,

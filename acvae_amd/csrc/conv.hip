@@ -740,6 +740,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
   }
 }
 
+// colsum_kernel<false> for several matrices at once (conv.h: ColsumBatch): block x -> (job, column block), block y -> row group
+// of the job (blocks past the job's groups leave at once); tickets are indexed by the launch's block x, group sums lie one job
+// behind the other.
+__global__ __launch_bounds__(256) void colsum_batch_kernel(acvae::ColsumBatch b, double* __restrict__ dpart) {
+  __shared__ double red[4][64];
+  __shared__ int s_last;
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;
+  const int R = b.R[j];
+  if ((int)blockIdx.y >= R) return;
+  const float* __restrict__ partials = b.x[j];
+  const int P = b.P[j], width = b.width[j];
+  unsigned* tickets = reinterpret_cast<unsigned*>(dpart);
+  double* dsum = dpart + CS_TICKETS / 2 + b.d0[j];
+  const int il = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = ((int)blockIdx.x - b.blk0[j]) * 64 + il;
+  double a = 0.0;
+  if (i < width)
+    for (int p = blockIdx.y + g * R; p < P; p += 4 * R) a += (double)partials[(long)p * width + i];
+  red[g][il] = a;
+  __syncthreads();
+  if (g == 0 && i < width) cs_store(dsum + (long)blockIdx.y * width + i, red[0][il] + red[1][il] + red[2][il] + red[3][il]);
+  if (!cs_last_arriver(tickets + blockIdx.x, (unsigned)R, &s_last)) return;
+  if (g != 0 || i >= width) return;
+  double t = 0.0;
+  for (int r0 = 0; r0 < R; r0 += 8) {          // eight loads in flight; the additions stay in group order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = r0 + u < R ? cs_load(dsum + (long)(r0 + u) * width + i) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r0 + u < R) t += v[u];
+  }
+  b.out[j][i] = (float)t;
+  if (b.out_b[j]) b.out_b[j][i] = (float)t;
+}
+
 // evaluation mode: scale / shift from the running statistics (no batch statistics, nothing to reduce)
 __global__ __launch_bounds__(64) void bn_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -1542,6 +1579,30 @@ int colsum2(const float* partials, int P, int width, double* dpart, float* out, 
   const int R = cs_groups(P);
   hipLaunchKernelGGL(colsum_kernel<false>, dim3(cdiv(width, 64), R), dim3(256), 0, st, partials, P, width, dpart, out, out2, split,
                      BnFinalizeArgs{});
+  ACVAE_LAUNCH_CHECK();
+  return ACVAE_OK;
+}
+int colsum_batch(ColsumBatch& b, double* dpart, long dpart_doubles, hipStream_t st) {
+  if (b.n <= 0) return ACVAE_OK;
+  if (b.n > ColsumBatch::MAXJ) return ACVAE_EINVAL;
+  long d = 0;
+  int blocks = 0, maxr = 1;
+  for (int j = 0; j < b.n; ++j) {
+    b.R[j] = cs_groups(b.P[j]);
+    b.blk0[j] = blocks; b.d0[j] = d;
+    blocks += cdiv(b.width[j], 64);
+    d += (long)b.R[j] * b.width[j];
+    if (b.R[j] > maxr) maxr = b.R[j];
+  }
+  b.blk0[b.n] = blocks;
+  if (b.n == 1 || blocks > CS_TICKETS || CS_TICKETS / 2 + d > dpart_doubles) {         // one launch each, as before
+    for (int j = 0; j < b.n; ++j) {
+      ACVAE_TRY(colsum2(b.x[j], b.P[j], b.width[j], dpart, b.out[j], nullptr, 0, st));
+      if (b.out_b[j]) ACVAE_TRY(colsum2(b.x[j], b.P[j], b.width[j], dpart, b.out_b[j], nullptr, 0, st));
+    }
+    return ACVAE_OK;
+  }
+  hipLaunchKernelGGL(colsum_batch_kernel, dim3(blocks, maxr), dim3(256), 0, st, b, dpart);
   ACVAE_LAUNCH_CHECK();
   return ACVAE_OK;
 }

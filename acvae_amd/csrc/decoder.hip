@@ -105,9 +105,9 @@ struct PostLayout {
   // saved
   long words, x, hidden, save_f, save_r, hprev_f, hprev_r, argmax, saved_total;
   // scratch
-  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, wt2, pq_hbuf, pq_cnt, tn, dpart, skws,
+  long gi_f, gi_r, gh, hf, ml, dml, dhid, dgi_f, dgi_r, dgh_f, dgh_r, dh_a, dh_b, dx, wt, wt2, wt_ih0, wt_ih1, wt_ml, pq_hbuf, pq_cnt, tn, dpart, skws,
        scratch_total;
-  long tn_floats;
+  long tn_floats, dpart_doubles;
 };
 int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
   if (N <= 0 || Tc <= 0 || E <= 0 || Hq <= 0 || V <= 0) return ACVAE_EINVAL;
@@ -132,6 +132,8 @@ int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
   if ((long)3 * Hq * E > wt) wt = (long)3 * Hq * E;
   L.wt = c.take(wt);
   L.wt2 = c.take((long)3 * Hq * Hq);                        // persistent BPTT: both directions' transposed weight_hh at once
+  // the backward's other transposed weights (round 4: all five transposes of the call in one launch in front of it)
+  L.wt_ih0 = c.take((long)3 * Hq * E); L.wt_ih1 = c.take((long)3 * Hq * E); L.wt_ml = c.take((long)2 * E * 2 * Hq);
   L.pq_hbuf = c.take((long)4 * N * Hq);                     // persistent forward: h in flight, [direction][parity][N][Hq]
   L.pq_cnt = c.take(acvae::posterior_persist_counter_words(Tc));
   long tn = tn_ws_floats(2 * E, 2 * Hq, (int)R);
@@ -139,7 +141,8 @@ int post_layout(int N, int Tc, int E, int Hq, int V, PostLayout& L) {
   t2 = tn_ws_floats(3 * Hq, Hq, (int)R); if (t2 > tn) tn = t2;
   L.tn_floats = tn;
   L.tn = c.take(tn);
-  L.dpart = c.take(2 * acvae::colsum_scratch_doubles(2 * E > 3 * Hq ? 2 * E : 3 * Hq));
+  L.dpart_doubles = 4 * acvae::colsum_scratch_doubles(2 * E > 3 * Hq ? 2 * E : 3 * Hq);      // room for the batched column sums
+  L.dpart = c.take(2 * L.dpart_doubles);
   L.skws = c.take(acvae_skinny_ws_floats());
   L.scratch_total = c.off;
   return ACVAE_OK;
@@ -162,7 +165,7 @@ struct DecLayout {
   // bwd scratch private to the prior chain (it may run on the second stream)
   long dencproj_p, dvpart_p, dmem_p, drnn_p, tn_p, dpart_p, attws_p;
   long attws_bytes;
-  long tn_floats, tn_p_floats;
+  long tn_floats, tn_p_floats, dpart_doubles;
 };
 int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLayout& L) {
   if (N <= 0 || Tc <= 0 || S <= 0 || E <= 0 || H <= 0 || A <= 0 || V <= 1 || Eenc <= 0) return ACVAE_EINVAL;
@@ -215,7 +218,8 @@ int dec_layout(int N, int Tc, int S, int E, int H, int A, int V, int Eenc, DecLa
   L.tn = b.take(tn);
   {
     int w = V; if (4 * Hp > w) w = 4 * Hp; if (3 * H > w) w = 3 * H; if (2 * E > w) w = 2 * E; if (A > w) w = A;
-    L.dpart = b.take(2 * acvae::colsum_scratch_doubles(w));
+    L.dpart_doubles = acvae::colsum_scratch_doubles(w);
+    L.dpart = b.take(2 * L.dpart_doubles);
   }
   L.attws_bytes = acvae_attn_bwd_workspace_bytes(N, Tc, S, A > E ? A : E);
   L.attws = b.take(L.attws_bytes / 4 + 64);
@@ -350,21 +354,30 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
   float* dml = sc + L.dml;
   float* dhid = sc + L.dhid;
   float* wt = sc + L.wt;
+  float* wt_ml = sc + L.wt_ml;
+  float* wt_ih[2] = {sc + L.wt_ih0, sc + L.wt_ih1};
+  {   // the transposed weights of the dX = dY . W products: one launch (they depend on the parameters only)
+    TransposeBatch tb;
+    tb.add(P(TP_Q_TML_W), 2 * Hq, wt_ml, 2 * E, 2 * E, 2 * Hq);                             // [2Hq][2E]
+    for (int dir = 0; dir < 2; ++dir) {
+      tb.add(P(TP_Q_WIH + dir * 4), E, wt_ih[dir], 3 * Hq, 3 * Hq, E);                      // [E][3Hq]
+      if (persist) tb.add(P(TP_Q_WHH + dir * 4), Hq, dir ? sc + L.wt2 : wt, 3 * Hq, 3 * Hq, Hq);   // [Hq][3Hq]
+    }
+    ACVAE_TRY(acvae_transpose_batch(tb, st.s));
+  }
   ACVAE_TRY(acvae_reparam_bwd(d_q_z, E, d_q_means, d_q_logs, E, q_logs, E, eps_q, E, dml, 2 * E, R, E, st));
-  ACVAE_TRY(transp(P(TP_Q_TML_W), 2 * Hq, wt, 2 * E, 2 * E, 2 * Hq, st));                 // [2Hq][2E]
-  ACVAE_TRY(gemm(dml, 2 * E, wt, 2 * E, nullptr, dhid, 2 * Hq, R, 2 * Hq, 2 * E, 0, st));
+  ACVAE_TRY(gemm(dml, 2 * E, wt_ml, 2 * E, nullptr, dhid, 2 * Hq, R, 2 * Hq, 2 * E, 0, st));
   if (d_q_means_utt)
     ACVAE_TRY(acvae::pool_bwd(d_q_means_utt, lens1, (const int*)(sv + L.argmax), dhid, (long)Tc * 2 * Hq, 2 * Hq, 1, N,
                               Tc, 2 * Hq, st));
   ACVAE_TRY(gemm_tn(dml, 2 * E, hid, 2 * Hq, G(TP_Q_TML_W), 2 * Hq, 2 * E, 2 * Hq, R, tn, st));
-  ACVAE_TRY(acvae::colsum2(dml, R, 2 * E, dpart, G(TP_Q_TML_B), nullptr, 0, st));
+  acvae::ColsumBatch cb;                     // the five bias gradients of the call: one launch at its end
+  cb.add(dml, R, 2 * E, G(TP_Q_TML_B));
   float* dx = sc + L.dx;
   if (persist) {                 // BPTT of both directions in one launch; the parameter products below are unchanged
     PqbParams pb;
     for (int dir = 0; dir < 2; ++dir) {
-      float* wtd = dir ? sc + L.wt2 : wt;
-      ACVAE_TRY(transp(P(TP_Q_WHH + dir * 4), Hq, wtd, 3 * Hq, 3 * Hq, Hq, st));                   // [Hq][3Hq]
-      pb.wt[dir] = wtd;
+      pb.wt[dir] = dir ? sc + L.wt2 : wt;                    // transposed weight_hh, made at the entry
       pb.save[dir] = sv + (dir ? L.save_r : L.save_f);
       pb.hprev[dir] = sv + (dir ? L.hprev_r : L.hprev_f);
       pb.dgi[dir] = sc + (dir ? L.dgi_r : L.dgi_f);
@@ -396,12 +409,12 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
       }
     }
     ACVAE_TRY(gemm_tn(dgi, 3 * Hq, X, E, G(TP_Q_WIH + o), E, 3 * Hq, E, R, tn, st));
-    ACVAE_TRY(acvae::colsum2(dgi, R, 3 * Hq, dpart, G(TP_Q_BIH + o), nullptr, 0, st));
+    cb.add(dgi, R, 3 * Hq, G(TP_Q_BIH + o));
     ACVAE_TRY(gemm_tn(dgh, 3 * Hq, hprev, Hq, G(TP_Q_WHH + o), Hq, 3 * Hq, Hq, R, tn, st));
-    ACVAE_TRY(acvae::colsum2(dgh, R, 3 * Hq, dpart, G(TP_Q_BHH + o), nullptr, 0, st));
-    ACVAE_TRY(transp(P(TP_Q_WIH + o), E, wt, 3 * Hq, 3 * Hq, E, st));                     // [E][3Hq]
-    ACVAE_TRY(gemm(dgi, 3 * Hq, wt, 3 * Hq, nullptr, dx, E, R, E, 3 * Hq, dir, st));
+    cb.add(dgh, R, 3 * Hq, G(TP_Q_BHH + o));
+    ACVAE_TRY(gemm(dgi, 3 * Hq, wt_ih[dir], 3 * Hq, nullptr, dx, E, R, E, 3 * Hq, dir, st));
   }
+  ACVAE_TRY(acvae::colsum_batch(cb, dpart, L.dpart_doubles, st));
   ACVAE_TRY(zero(G(TP_Q_EMB), (long)V * E, st));
   ACVAE_TRY(acvae::embed_scatter(words, dx, E, G(TP_Q_EMB), V, R, E, st));
   return ACVAE_OK;
@@ -787,21 +800,22 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   if (d_logits) ACVAE_TRY(gemm(d_logits, V, wt_cls, V, nullptr, d_out, H, R, H, V, 1, st));
   // parameter gradients of the two heads (c: the stream / workspaces they are queued with)
   auto heads_params = [&](const Ctx& c, TnWs ws, double* dp) -> int {
+    acvae::ColsumBatch cb;
     if (d_p_means_utt) {
       ACVAE_TRY(gemm_tn(d_p_means_utt, 2 * E, sv + L.pool_hid, H, G(TP_MLO_W), H, 2 * E, H, N, ws, c));
-      ACVAE_TRY(acvae::colsum2(d_p_means_utt, N, 2 * E, dp, G(TP_MLO_B), nullptr, 0, c));
+      cb.add(d_p_means_utt, N, 2 * E, G(TP_MLO_B));
     } else {
       ACVAE_TRY(zero(G(TP_MLO_W), (long)2 * E * H, c));
       ACVAE_TRY(zero(G(TP_MLO_B), 2 * E, c));
     }
     if (d_logits) {
       ACVAE_TRY(gemm_tn(d_logits, V, outputs, H, G(TP_DEC_CLS_W), H, V, H, R, ws, c));
-      ACVAE_TRY(acvae::colsum2(d_logits, R, V, dp, G(TP_DEC_CLS_B), nullptr, 0, c));
+      cb.add(d_logits, R, V, G(TP_DEC_CLS_B));
     } else {
       ACVAE_TRY(zero(G(TP_DEC_CLS_W), (long)V * H, c));
       ACVAE_TRY(zero(G(TP_DEC_CLS_B), V, c));
     }
-    return ACVAE_OK;
+    return acvae::colsum_batch(cb, dp, L.dpart_doubles, c);
   };
   // They feed nothing downstream.  With a second stream they go there, in front of the prior's BPTT: the two serial
   // chains leave most of the GPU idle, so the 75 us of these products cost the first stream nothing.
@@ -875,14 +889,16 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   // batched parameter gradients of the decoder, the embedding gradient and (with_dz) d_q_z
   auto dec_params = [&](const Ctx& c, TnWs ws, double* dp, bool with_dz = true) -> int {
     ACVAE_TRY(gemm_tn(dgi, 3 * H, rnn_d, 3 * E, G(TP_DEC_WIH), 3 * E, 3 * H, 3 * E, R, ws, c));
-    ACVAE_TRY(acvae::colsum2(dgi, R, 3 * H, dp, G(TP_DEC_BIH), nullptr, 0, c));
     ACVAE_TRY(gemm_tn(dgh, 3 * H, hprev_d, H, G(TP_DEC_WHH), H, 3 * H, H, R, ws, c));
-    ACVAE_TRY(acvae::colsum2(dgh, R, 3 * H, dp, G(TP_DEC_BHH), nullptr, 0, c));
+    {   // the four bias-shaped gradients of the decoder in one launch
+      acvae::ColsumBatch cb;
+      cb.add(dgi, R, 3 * H, G(TP_DEC_BIH)); cb.add(dgh, R, 3 * H, G(TP_DEC_BHH));
+      cb.add(dencproj, N * S, A, G(TP_DEC_ATT_B)); cb.add(dvpart, dv_rows, A, G(TP_DEC_ATT_V));
+      ACVAE_TRY(acvae::colsum_batch(cb, dp, L.dpart_doubles, c));
+    }
     // attention parameters: W = [query half | memory half]
     ACVAE_TRY(gemm_tn(dqd, A, hprev_d, H, G(TP_DEC_ATT_W), E + H, A, H, R, ws, c));
     ACVAE_TRY(gemm_tn(dencproj, A, mem, E, G(TP_DEC_ATT_W) + H, E + H, A, E, N * S, ws, c));
-    ACVAE_TRY(acvae::colsum2(dencproj, N * S, A, dp, G(TP_DEC_ATT_B), nullptr, 0, c));
-    ACVAE_TRY(acvae::colsum2(dvpart, dv_rows, A, dp, G(TP_DEC_ATT_V), nullptr, 0, c));
     // d(rnn_input) for the embedding and z columns
     ACVAE_TRY(gemm(dgi, 3 * H, wt_dih, 3 * H, nullptr, drnn, E, R, E, 3 * H, 0, c));                    // d emb
     if (emb_keep)          // back through the word-embedding dropout
@@ -960,17 +976,18 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   // batched parameter gradients of the prior and its embedding gradient
   auto prior_params = [&]() -> int {
     ACVAE_TRY(gemm_tn(dml_all, 2 * E, hp_all, Hp, G(TP_P_ML_W), Hp, 2 * E, Hp, R, tn_p, sp));
-    ACVAE_TRY(acvae::colsum2(dml_all, R, 2 * E, dpart_p, G(TP_P_ML_B), nullptr, 0, sp));
     ACVAE_TRY(gemm_tn(dgates, 4 * Hp, rnn_p, 3 * E, G(TP_P_WIH), 3 * E, 4 * Hp, 3 * E, R, tn_p, sp));
-    ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BIH), nullptr, 0, sp));
-    ACVAE_TRY(acvae::colsum2(dgates, R, 4 * Hp, dpart_p, G(TP_P_BHH), nullptr, 0, sp));
     ACVAE_TRY(gemm_tn(dgates, 4 * Hp, hpprev, Hp, G(TP_P_WHH), Hp, 4 * Hp, Hp, R, tn_p, sp));
+    {   // the prior's bias-shaped gradients in one launch (the LSTM's two biases share theirs)
+      acvae::ColsumBatch cb;
+      cb.add(dml_all, R, 2 * E, G(TP_P_ML_B)); cb.add(dgates, R, 4 * Hp, G(TP_P_BIH), G(TP_P_BHH));
+      cb.add(dencproj_p, N * S, E, G(TP_P_ATT_B)); cb.add(dvpart_p, N, E, G(TP_P_ATT_V));
+      ACVAE_TRY(acvae::colsum_batch(cb, dpart_p, L.dpart_doubles, sp));
+    }
     // d emb_p = drnn[:, 0:E] + dqp . W_att[:, :E]
     ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn_p, 3 * E, R, E, E, 1, sp));
     ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn_p, sp));
     ACVAE_TRY(gemm_tn(dencproj_p, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn_p, sp));
-    ACVAE_TRY(acvae::colsum2(dencproj_p, N * S, E, dpart_p, G(TP_P_ATT_B), nullptr, 0, sp));
-    ACVAE_TRY(acvae::colsum2(dvpart_p, N, E, dpart_p, G(TP_P_ATT_V), nullptr, 0, sp));
     ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, sp));
     return acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp);
   };

@@ -19,8 +19,10 @@
  *           chains a device's persistent launches behind each other, the device's CU count, which kernels had their
  *           dynamic-LDS limit raised there, and the status pointer registered with acvae_persist_status_register.
  *     There are no process-global behaviour switches: what used to be acvae_set_decode_persist / _decode_defer /
- *     _attn_split are per-call `flags` (ACVAE_FLAG_*).  The only environment variables the library reads are the A/B
- *     switches of the encoder driver (ACVAE_CONV_WINO, ... listed in DESIGN.md), each read once.
+ *     _attn_split are per-call `flags` (ACVAE_FLAG_*).  The only environment variables the library reads are six A/B /
+ *     tuning switches, each read ONCE per process into a static constant (never written afterwards): ACVAE_CONV_WINO
+ *     (encoder.hip: 0 = implicit-GEMM convolutions), ACVAE_SKINNY_PAIR, ACVAE_HEADS_AUX (decoder.hip: launch pairing / which
+ *     stream the heads' gradients use), ACVAE_SKINNY_SPLITK (gemm.hip), ACVAE_BF16_BDMA, ACVAE_WGB_SLABCOST (conv_bf16.hip).
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises.
  *   - return 0 on success, a negative ACVAE_E* code for bad arguments, or a positive hipError_t.
  *   - fp32 everywhere ("dtype f32"), token ids / lengths int64 (as torch.long).
