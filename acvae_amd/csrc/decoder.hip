@@ -346,6 +346,7 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
     acvae::ZeroBatch zb;
     zb_skinny(zb, st.skws); zb_colsum(zb, dpart); zb_tn(zb, tn);
     if (persist) { zb.add(sc + L.pq_cnt, acvae::posterior_persist_counter_words(Tc)); flags |= ACVAE_FLAG_INT_CNT_ZEROED; }
+    zb.add(G(TP_Q_EMB), (long)V * E);          // the embedding-table gradient starts from zero (embed_scatter adds rows)
     ACVAE_TRY(acvae::zero_batch(zb, st.s));
   }
   const int64_t* words = (const int64_t*)(sv + L.words);
@@ -415,7 +416,6 @@ extern "C" int acvae_posterior_bwd(const void* const* params, void* const* grads
     ACVAE_TRY(gemm(dgi, 3 * Hq, wt_ih[dir], 3 * Hq, nullptr, dx, E, R, E, 3 * Hq, dir, st));
   }
   ACVAE_TRY(acvae::colsum_batch(cb, dpart, L.dpart_doubles, st));
-  ACVAE_TRY(zero(G(TP_Q_EMB), (long)V * E, st));
   ACVAE_TRY(acvae::embed_scatter(words, dx, E, G(TP_Q_EMB), V, R, E, st));
   return ACVAE_OK;
 }
@@ -773,6 +773,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
       zb.add(sc + L.dmem_p, (long)N * S * E);
       flags |= ACVAE_FLAG_INT_CNT_ZEROED;
     }
+    // the two embedding-table gradients start from zero (embed_scatter adds rows): here instead of two 10 MB memsets in the
+    // trailing part beside the encoder backward
+    zb.add(G(TP_DEC_EMB), (long)V * E); zb.add(G(TP_P_EMB), (long)V * E);
     ACVAE_TRY(acvae::zero_batch(zb, st.s));
   }
   const int64_t* words = (const int64_t*)(sv + L.words);
@@ -820,7 +823,9 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   // They feed nothing downstream.  With a second stream they go there, in front of the prior's BPTT: the two serial
   // chains leave most of the GPU idle, so the 75 us of these products cost the first stream nothing.
   static const bool heads_aux = !(getenv("ACVAE_HEADS_AUX") && atoi(getenv("ACVAE_HEADS_AUX")) == 0);
-  const bool heads_on_aux = heads_aux && fork.on() && !defer;
+  // (also in trailing-gradient mode, round 4: their 0.1 ms then run beside the persistent BPTT launch, which leaves most of the GPU
+  // idle, instead of beside the encoder backward's first weight gradient)
+  const bool heads_on_aux = heads_aux && fork.on();
   if (heads_on_aux) {
     ACVAE_TRY(heads_params(sp, tn_p, dpart_p));   // aux is behind fork.begin(): the upstream gradients are in place
   } else if (!defer) {
@@ -904,8 +909,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     if (emb_keep)          // back through the word-embedding dropout
       ACVAE_TRY(acvae::dropout_rows(drnn, (long)Tc * E, E, emb_keep, E, (long)N * E, emb_drop_p < 1.f ? 1.f / (1.f - emb_drop_p) : 0.f, N, Tc, E, c));
     if (with_dz) ACVAE_TRY(dec_dz(c));
-    ACVAE_TRY(zero(G(TP_DEC_EMB), (long)V * E, c));
-    ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, c));
+    ACVAE_TRY(acvae::embed_scatter(words_c, drnn, E, G(TP_DEC_EMB), V, R, E, c));        // (table zeroed at the call's entry)
     return ACVAE_OK;
   };
 
@@ -988,8 +992,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(gemm(dqp, E, wt_patt, E, nullptr, drnn_p, 3 * E, R, E, E, 1, sp));
     ACVAE_TRY(gemm_tn(dqp, E, rnn_p, 3 * E, G(TP_P_ATT_W), 2 * E, E, E, R, tn_p, sp));
     ACVAE_TRY(gemm_tn(dencproj_p, E, mem, E, G(TP_P_ATT_W) + E, 2 * E, E, E, N * S, tn_p, sp));
-    ACVAE_TRY(zero(G(TP_P_EMB), (long)V * E, sp));
-    return acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp);
+    return acvae::embed_scatter(words_c, drnn_p, 3 * E, G(TP_P_EMB), V, R, E, sp);       // (table zeroed at the call's entry)
   };
   if (prior_feeds_decoder) {   // the prior BPTT needs the decoder's dz: back to back
     ACVAE_TRY(dec_begin());
@@ -1055,7 +1058,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
   if (defer) {                 // d_q_z on the first stream; everything else behind the first stream's work so far, on the second
     ACVAE_TRY(dec_dz(st));
     ACVAE_TRY(Fork::edge(st.s, sp.s));
-    ACVAE_TRY(heads_params(sp, tn_p, dpart_p));
+    if (!heads_on_aux) ACVAE_TRY(heads_params(sp, tn_p, dpart_p));
     ACVAE_TRY(dec_params(sp, tn_p, dpart_p, false));
     ACVAE_TRY(prior_params());
   }
