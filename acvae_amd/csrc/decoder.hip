@@ -501,7 +501,9 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
   }
 
   int64_t* words = (int64_t*)(sv + L.words);
-  float* mem = sv + L.mem;
+  // without the ln projection the attention memory IS the caller's tensor (it stays valid through the backward, which gets it
+  // again): no copy into `saved` (round 4: one launch less in front of the persistent launch)
+  const float* mem = has_ln ? sv + L.mem : mem_in;
   float* encproj_d = sv + L.encproj_d;
   float* encproj_p = sv + L.encproj_p;
   float* qd = sv + L.qd;
@@ -518,14 +520,16 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
   const long ld3E = (long)Tc * 3 * E;
 
   // encoder memory (optional ln projection, vae_model.py:743-744) and the hoisted attention halves
-  if (has_ln) {
-    ACVAE_TRY(gemm(mem_in, Eenc, P(TP_LN_W), Eenc, P(TP_LN_B), mem, E, N * S, E, Eenc, 0, st));
-  } else {
-    ACVAE_TRY(acvae::copy_rows(mem, E, mem_in, E, N * S, E, st));
-  }
-  ACVAE_TRY(gemm(mem, E, P(TP_DEC_ATT_W) + H, E + H, P(TP_DEC_ATT_B), encproj_d, A, N * S, A, E, 0, st));
-  ACVAE_TRY(gemm(mem, E, P(TP_P_ATT_W) + E, 2 * E, P(TP_P_ATT_B), encproj_p, E, N * S, E, E, 0, st));
-  ACVAE_TRY(acvae::copy_rows(zeros, H > Hp ? H : Hp, nullptr, 0, N, H > Hp ? H : Hp, st));
+  if (has_ln) ACVAE_TRY(gemm(mem_in, Eenc, P(TP_LN_W), Eenc, P(TP_LN_B), sv + L.mem, E, N * S, E, Eenc, 0, st));
+  // the prior attention's half goes with the prior chain (second stream in the teacher-forced paths: the chain in front of the
+  // persistent launch was 9 launches on the first stream and 5 behind them on the second; now 6 and 6 side by side)
+  auto encproj_prior = [&](const Ctx& c) -> int {
+    return gemm(mem, E, P(TP_P_ATT_W) + E, 2 * E, P(TP_P_ATT_B), encproj_p, E, N * S, E, E, 0, c);
+  };
+  auto encproj_dec = [&]() -> int {
+    ACVAE_TRY(gemm(mem, E, P(TP_DEC_ATT_W) + H, E + H, P(TP_DEC_ATT_B), encproj_d, A, N * S, A, E, 0, st));
+    return acvae::copy_rows(zeros, H > Hp ? H : Hp, nullptr, 0, N, H > Hp ? H : Hp, st);
+  };
 
   // ---- per-range helpers; (t0,cnt) is either (0,Tc) [rows contiguous] or (t,1) [row stride Tc*C]
   auto rows_of = [&](int cnt) { return cnt == Tc ? R : N; };
@@ -648,6 +652,8 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
   if (teacher) {
     ACVAE_TRY(acvae::gather_words(caps, ld_caps, 1, words, N, Tc, st));
     ACVAE_TRY(fork.begin());
+    ACVAE_TRY(encproj_prior(sp));
+    ACVAE_TRY(encproj_dec());
     ACVAE_TRY(prior_pre(0, Tc));
     if (prior_feeds_decoder) {            // dec_pre reads p_z: the chains run back to back
       for (int t = 0; t < Tc; ++t) ACVAE_TRY(prior_step(t));
@@ -683,6 +689,8 @@ extern "C" int acvae_decode_fwd_sampled(const void* const* params, const float* 
     ACVAE_TRY(classify(0, Tc));
     ACVAE_TRY(fork.join());
   } else {
+    ACVAE_TRY(encproj_dec());
+    ACVAE_TRY(encproj_prior(st));
     for (int t = 0; t < Tc; ++t) {
       ACVAE_TRY(acvae::select_word(caps, ld_caps, seqs, Tc, words, Tc, t, train && ss_flags_host[t], start_idx, N, st));
       ACVAE_TRY(prior_pre(t, 1));
@@ -779,7 +787,7 @@ extern "C" int acvae_decode_bwd(const void* const* params, void* const* grads, c
     ACVAE_TRY(acvae::zero_batch(zb, st.s));
   }
   const int64_t* words = (const int64_t*)(sv + L.words);
-  float* mem = sv + L.mem;
+  const float* mem = has_ln ? sv + L.mem : mem_in;          // as in the forward
   float* rnn_d = sv + L.rnn_d;
   float* rnn_p = sv + L.rnn_p;
 
