@@ -6,7 +6,7 @@
 //   Y = At [ sum_ci (G g G^T) .* (Bt d B) ] A      d: 4x4 input window, g: 3x3 filter, Y: 2x2 outputs
 //
 // One workgroup = 32 output tiles (R tile rows x TW tile columns of ONE clip, TW = W/2, R = 32/TW) x 64 output channels
-// x all 16 transform positions: 16 GEMMs [32 tiles x Cin] x [Cin x 64] on FOUR wavefronts of 128 accumulators (248-252
+// x all 16 transform positions: 16 GEMMs [32 tiles x Cin] x [Cin x 64] on FOUR wavefronts of 128 accumulators (218-230
 // registers each), so that TWO workgroups share a CU (one wavefront of each per SIMD).  Until round 4 one workgroup of eight
 // wavefronts (64 tiles) had the CU to itself, and its prologue (first window from HBM: 1.4-2.6 us), its epilogue (2.0-2.4 us)
 // and the dispatch gap behind it (0.5 us) ran with the matrix pipes idle - 19 % of a 64-channel workgroup, 3 % of a
@@ -15,15 +15,17 @@
 //   * the activation window (2R+2 pixel rows x W+2 columns, 16 channels per stage) is staged ONCE, with the previous
 //     layer's BatchNorm+ReLU and the zero padding applied on the way, into four (row parity, column parity) planes, so
 //     that the 16 tiles a 16-lane LDS read group serves are 16 consecutive 16-byte slots;
-//   * every wavefront builds the Bt d B fragments of its 8 positions in registers from 12 ds_read_b128 (64 adds, issued as
-//     32 v_pk_add_f32, per 32 MFMAs) - the vertical half of the transform splits cleanly over the two position halves: rows 0-2 / 1-3;
+//   * every wavefront owns ONE vertical frequency of all 32 tiles and both 32-column halves: it builds the Bt d B fragments of
+//     its 4 positions in registers from 8 ds_read_b128 (two window rows) and 16 v_pk_add_f32 per 32 MFMAs - a fragment feeds two
+//     MFMA groups (until round 4: two frequencies, one column half: 12 reads and 32 packed adds per 32 MFMAs);
 //   * G g G^T is precomputed per step (wino_weights_kernel, all layers in one launch) into a 32 KB-per-8-channel-chunk image
 //     whose fragments go from L2 STRAIGHT into the MFMA operand registers (raw_buffer_load_b128 into a ring of four
 //     float4 per lane, reloaded four position groups ahead): they never pass through LDS (round 3; the LDS-DMA path
 //     cost ~470 cycles per chunk);
-//   * the epilogue applies At . A in registers, the two position halves of a tile meet through LDS once per tile, and
-//     the BatchNorm batch statistics of the raw output are reduced exactly like conv.hip's epilogue does.
-// The same kernel is the data gradient (X = dY, filter flipped and transposed by wino_weights_kernel, no activation).
+//   * the epilogue applies At . A in registers, the four frequencies of a tile meet through LDS once per tile, and the
+//     BatchNorm batch statistics of the raw output are reduced exactly like conv.hip's epilogue does.
+// The same kernel is the data gradient (X = dY, filter flipped and transposed by wino_weights_kernel, no activation); the data
+// gradient of a block's second convolution also reduces the BatchNorm + ReLU backward that consumes it (conv_wino_bnred_kernel).
 #include "mfma_tile.h"
 #include "../../include/acvae_hip.h"
 #include "conv.h"
