@@ -72,6 +72,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const bf16_t* __restrict__ 
   constexpr int NTN = BN / 64;       // 32-column MFMA tiles per wave along N
   constexpr int BR = BN / 32;        // weight-panel 16-byte slots per thread
   int bm, bn;
+  __builtin_amdgcn_s_setprio(3);      // prologue / epilogue beside the other workgroup's main loop (conv_wino.hip, round 4): -0.3 % of the bf16 step
   mfma::xcd_tile(gridDim.x, gridDim.y, bm, bn);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -180,6 +181,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const bf16_t* __restrict__ 
   put_b(0);
   dma_wait();
   __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
   for (int s = 0; s < NS; ++s) {
     const int grp = s / 3, dxi = s - grp * 3;
     const bool more = s + 1 < NS;
@@ -219,6 +221,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const bf16_t* __restrict__ 
   }
 
   // ---- epilogue: round to bf16, statistics of the rounded values, two channels per dword
+  __builtin_amdgcn_s_setprio(3);
   float* red = reinterpret_cast<float*>(&sm.a[0][0]);     // LDS is free (barrier above)
 #pragma unroll
   for (int j = 0; j < NTN; ++j) {
