@@ -809,12 +809,12 @@ struct WinoWgradParams {
 // SS = log2(tiles per stage row) as a template parameter: every window offset of the eight tile pairs of a stage is then an
 // immediate of its ds_read (the issue slots are what the kernel runs out of; the per-pair address arithmetic was a quarter
 // of its non-MFMA instructions).
-template <int XH, int SS>
+template <int XI, int SS>
 __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float* xw0, float* xw1, float* dy0, float* dy1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same value as a scalar (for the code behind the main loop)
-  const int ah = (wave >> 1) & 1, bh = wave >> 2;       // ci half, co half of this wavefront; XH = wave & 1
+  const int ah = wave >> 2;                              // ci half of this wavefront; XI = wave & 3: its vertical frequency
   const int z = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
   const int H = p.H, W = p.W;
   constexpr int STW = 1 << SS, WC = 2 * STW + 2;
@@ -901,10 +901,15 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   // tile of pair j for this lane half: t = 2j + kh -> tile row (2j) >> SS, tile column ((2j) & (STW-1)) + kh: kh only shifts the
   // window by two pixel columns and flips the channel swizzle (window columns 0,1 carry the tile's own column parity = kh,
   // columns 2,3 the other one)
-  const int ci = ah * 32 + li, co = bh * 32 + li;
+  // Round 4: a wavefront owns ONE vertical frequency of its 32 input channels and BOTH halves of the 64 output channels (until
+  // then: two frequencies, one half).  Its window transform then needs two rows instead of three and is no longer repeated by
+  // the wavefront of the other half: 8 packed adds per 8 MFMAs instead of 11 (the SIMD's issue time is what the kernel runs out of).
+  const int ci = ah * 32 + li;
   const int xo01 = kh * 128 + (ci ^ (32 * kh)), xo23 = kh * 128 + (ci ^ (32 * (1 - kh)));
   constexpr int rowstride = WC * 64;
-  const int bbase = kh * 256 + (co ^ (32 * kh));
+  const int bbase0 = kh * 256 + (li ^ (32 * kh)), bbase1 = kh * 256 + ((32 + li) ^ (32 * kh));
+  // window rows of the tile's four that frequency XI combines (signs folded as before): 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r3 - r1
+  constexpr int RA = XI == 0 ? 0 : 1, RB = XI == 0 ? 2 : XI == 3 ? 3 : 2;
 
   f32x16 acc[8];
 #pragma unroll
@@ -914,76 +919,78 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
 
   // Two register sets: the 16 LDS reads of tile pair j + 1 are issued before the 8 MFMAs of pair j (sched_barriers keep
   // them there; left alone the compiler reads each value just in front of the MFMA that takes it).
-  struct Frag { float d[3][4]; float y[4]; };
+  struct Frag { float d[2][4]; float y[2][4]; };
   auto load = [&](auto jj, const float* xw, const float* dys, Frag& f) {
     constexpr int j = decltype(jj)::value;
-    constexpr int OFF = ((2 * ((2 * j) >> SS) + XH) * WC + 2 * ((2 * j) & (STW - 1))) * 64;
+    constexpr int OFF = ((2 * ((2 * j) >> SS)) * WC + 2 * ((2 * j) & (STW - 1))) * 64;
     const float* x01 = xw + xo01 + OFF;
     const float* x23 = xw + xo23 + OFF;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      f.d[a][0] = x01[a * rowstride + 0 * 64];
-      f.d[a][1] = x01[a * rowstride + 1 * 64];
-      f.d[a][2] = x23[a * rowstride + 2 * 64];
-      f.d[a][3] = x23[a * rowstride + 3 * 64];
+    for (int a = 0; a < 2; ++a) {
+      constexpr int ROW[2] = {RA, RB};
+      f.d[a][0] = x01[ROW[a] * rowstride + 0 * 64];
+      f.d[a][1] = x01[ROW[a] * rowstride + 1 * 64];
+      f.d[a][2] = x23[ROW[a] * rowstride + 2 * 64];
+      f.d[a][3] = x23[ROW[a] * rowstride + 3 * 64];
     }
-    const float* yb = dys + bbase + j * 512;
-    f.y[0] = yb[0]; f.y[1] = yb[64]; f.y[2] = yb[128]; f.y[3] = yb[192];
+    const float* ya = dys + bbase0 + j * 512;
+    const float* yb = dys + bbase1 + j * 512;
+    f.y[0][0] = ya[0]; f.y[0][1] = ya[64]; f.y[0][2] = ya[128]; f.y[0][3] = ya[192];
+    f.y[1][0] = yb[0]; f.y[1][1] = yb[64]; f.y[1][2] = yb[128]; f.y[1][3] = yb[192];
   };
-  // Both operand transforms of a tile pair as ONE block of 11 v_pk_add_f32 (the scalar form needs 22 adds; issue slots are
-  // what the kernel runs out of).  Register pairs: P(a,0) = window row a, columns 0,1; P(a,1) = columns 2,3; Y0 / Y1 = gradient
-  // rows.  op_sel / op_sel_hi pick the dword of a pair per lane, neg_lo / neg_hi its sign:
-  //   t0 = XH ? r2 - r0 : r0 - r2,  t1 = XH ? r1 - r0 : r1 + r2        (both columns pairs: 4 instructions)
-  //   r1 = XH ? Y0 - Y1 : Y0 + Y1,  r0 = XH ? Y1 : Y0
-  //   A operands (a0,a1) = (t[0] - t[2], t[1] + t[2]),  (a2,a3) = (t[2] - t[1], t[3] - t[1])     for t0 and t1
-  //   B operands (b1,b2) = (r[0] + r[1], r[0] - r[1]),  b0 = r[0], b3 = r[1]                     for r0 and r1
+  // Both operand transforms of a tile pair as ONE block of v_pk_add_f32 (8 for the frequencies 1 and 2, 6 for 0 and 3; the scalar
+  // form needs twice as many adds; issue slots are what the kernel runs out of).  Register pairs: TL / TH = the vertical
+  // combination of the window, columns 0,1 / 2,3 (overwrites row RA's registers); per output-channel half h: Y0 / Y1 = the
+  // gradient rows, R = their vertical combination.  op_sel / op_sel_hi pick the dword of a pair per lane, neg_lo / neg_hi its sign:
+  //   A operands (a0,a1) = (t[0] - t[2], t[1] + t[2]),  (a2,a3) = (t[2] - t[1], t[3] - t[1])
+  //   B operands (b1,b2) = (r[0] + r[1], r[0] - r[1]),  b0 = r[0], b3 = r[1]
   // The block ends in the wait between a VALU write and an MFMA read of the register that the compiler's hazard recogniser
   // would insert if it could see inside.
+#define WG_A01(D, TL, TH) "v_pk_add_f32 " D ", " TL ", " TH " op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]\n\t"
+#define WG_A23(D, TL, TH) "v_pk_add_f32 " D ", " TH ", " TL " op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define WG_B12(D, R) "v_pk_add_f32 " D ", " R ", " R " op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+#define WG_SUB(D, A, B) "v_pk_add_f32 " D ", " A ", " B " neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define WG_ADD(D, A, B) "v_pk_add_f32 " D ", " A ", " B "\n\t"
   auto mm = [&](const Frag& f) {
-    f32x2 a01, a23, a45, a67, b12, b56, r1;
-    // the vertical differences overwrite the registers of window rows 0 / 1 (in-out operands): 16 register pairs in the block
-    f32x2 t0l = {f.d[0][0], f.d[0][1]}, t0h = {f.d[0][2], f.d[0][3]}, t1l = {f.d[1][0], f.d[1][1]}, t1h = {f.d[1][2], f.d[1][3]};
-    const f32x2 p20 = {f.d[2][0], f.d[2][1]}, p21 = {f.d[2][2], f.d[2][3]};
-    const f32x2 y0 = {f.y[0], f.y[1]}, y1 = {f.y[2], f.y[3]};
-    const f32x2 r0 = XH ? y1 : y0;
-#define WG_HORIZ(R0)                                                                                         \
-        "v_pk_add_f32 %0, %7, %8 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]\n\t"            /* a01 from t0 */ \
-        "v_pk_add_f32 %1, %8, %7 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* a23 */        \
-        "v_pk_add_f32 %2, %9, %10 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]\n\t"           /* a45 from t1 */ \
-        "v_pk_add_f32 %3, %10, %9 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t" /* a67 */       \
-        "v_pk_add_f32 %4, " R0 ", " R0 " op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\t" /* b12 from r0 */ \
-        "v_pk_add_f32 %5, %6, %6 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\t"   /* b56 from r1 */ \
-        "s_nop 1"
-    if (XH)
-      asm("v_pk_add_f32 %9, %9, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"        // t1l = row1 - row0   (before row0 is overwritten)
-          "v_pk_add_f32 %10, %10, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"      // t1h
-          "v_pk_add_f32 %7, %11, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0l = row2 - row0
-          "v_pk_add_f32 %8, %12, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0h
-          "v_pk_add_f32 %6, %13, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"      // r1 = y0 - y1
-          WG_HORIZ("%14")
-          : "=&v"(a01), "=&v"(a23), "=&v"(a45), "=&v"(a67), "=&v"(b12), "=&v"(b56), "=&v"(r1), "+v"(t0l), "+v"(t0h), "+v"(t1l),
-            "+v"(t1h)
-          : "v"(p20), "v"(p21), "v"(y0), "v"(y1));
-    else
-      asm("v_pk_add_f32 %7, %7, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0l = row0 - row2
-          "v_pk_add_f32 %8, %8, %12 neg_lo:[0,1] neg_hi:[0,1]\n\t"       // t0h
-          "v_pk_add_f32 %9, %9, %11\n\t"                                 // t1l = row1 + row2
-          "v_pk_add_f32 %10, %10, %12\n\t"                               // t1h
-          "v_pk_add_f32 %6, %13, %14\n\t"                                // r1 = y0 + y1
-          WG_HORIZ("%13")
-          : "=&v"(a01), "=&v"(a23), "=&v"(a45), "=&v"(a67), "=&v"(b12), "=&v"(b56), "=&v"(r1), "+v"(t0l), "+v"(t0h), "+v"(t1l),
-            "+v"(t1h)
-          : "v"(p20), "v"(p21), "v"(y0), "v"(y1));
-#undef WG_HORIZ
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[0], r0[0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[1], b12[0], acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[0], b12[1], acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[1], r0[1], acc[3], 0, 0, 0);
-    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a45[0], r1[0], acc[4], 0, 0, 0);
-    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a45[1], b56[0], acc[5], 0, 0, 0);
-    acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a67[0], b56[1], acc[6], 0, 0, 0);
-    acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a67[1], r1[1], acc[7], 0, 0, 0);
+    f32x2 a01, a23, b12a, b12b, ra, rb;
+    f32x2 tl = {f.d[0][0], f.d[0][1]}, th = {f.d[0][2], f.d[0][3]};           // row RA; overwritten by the vertical combination
+    const f32x2 ul = {f.d[1][0], f.d[1][1]}, uh = {f.d[1][2], f.d[1][3]};     // row RB
+    const f32x2 y0a = {f.y[0][0], f.y[0][1]}, y1a = {f.y[0][2], f.y[0][3]}, y0b = {f.y[1][0], f.y[1][1]}, y1b = {f.y[1][2], f.y[1][3]};
+    if constexpr (XI == 0) {                 // t = r0 - r2, r = Y0
+      asm(WG_SUB("%4", "%4", "%6") WG_SUB("%5", "%5", "%7")
+          WG_A01("%0", "%4", "%5") WG_A23("%1", "%4", "%5") WG_B12("%2", "%8") WG_B12("%3", "%9") "s_nop 1"
+          : "=&v"(a01), "=&v"(a23), "=&v"(b12a), "=&v"(b12b), "+v"(tl), "+v"(th) : "v"(ul), "v"(uh), "v"(y0a), "v"(y0b));
+      ra = y0a; rb = y0b;
+    } else if constexpr (XI == 3) {          // t = r3 - r1, r = Y1
+      asm(WG_SUB("%4", "%6", "%4") WG_SUB("%5", "%7", "%5")
+          WG_A01("%0", "%4", "%5") WG_A23("%1", "%4", "%5") WG_B12("%2", "%8") WG_B12("%3", "%9") "s_nop 1"
+          : "=&v"(a01), "=&v"(a23), "=&v"(b12a), "=&v"(b12b), "+v"(tl), "+v"(th) : "v"(ul), "v"(uh), "v"(y1a), "v"(y1b));
+      ra = y1a; rb = y1b;
+    } else if constexpr (XI == 1) {          // t = r1 + r2, r = Y0 + Y1
+      asm(WG_ADD("%6", "%6", "%8") WG_ADD("%7", "%7", "%9") WG_ADD("%4", "%10", "%11") WG_ADD("%5", "%12", "%13")
+          WG_A01("%0", "%6", "%7") WG_A23("%1", "%6", "%7") WG_B12("%2", "%4") WG_B12("%3", "%5") "s_nop 1"
+          : "=&v"(a01), "=&v"(a23), "=&v"(b12a), "=&v"(b12b), "=&v"(ra), "=&v"(rb), "+v"(tl), "+v"(th)
+          : "v"(ul), "v"(uh), "v"(y0a), "v"(y1a), "v"(y0b), "v"(y1b));
+    } else {                                 // t = r2 - r1, r = Y0 - Y1
+      asm(WG_SUB("%6", "%8", "%6") WG_SUB("%7", "%9", "%7") WG_SUB("%4", "%10", "%11") WG_SUB("%5", "%12", "%13")
+          WG_A01("%0", "%6", "%7") WG_A23("%1", "%6", "%7") WG_B12("%2", "%4") WG_B12("%3", "%5") "s_nop 1"
+          : "=&v"(a01), "=&v"(a23), "=&v"(b12a), "=&v"(b12b), "=&v"(ra), "=&v"(rb), "+v"(tl), "+v"(th)
+          : "v"(ul), "v"(uh), "v"(y0a), "v"(y1a), "v"(y0b), "v"(y1b));
+    }
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[0], ra[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[0], rb[0], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[1], b12a[0], acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[1], b12b[0], acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[0], b12a[1], acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[0], b12b[1], acc[5], 0, 0, 0);
+    acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[1], ra[1], acc[6], 0, 0, 0);
+    acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23[1], rb[1], acc[7], 0, 0, 0);
   };
+#undef WG_A01
+#undef WG_A23
+#undef WG_B12
+#undef WG_SUB
+#undef WG_ADD
   // One stage = 8 tile pairs = 8 blocks of 8 MFMAs per wavefront.  Everything that does not need the matrix pipe sits
   // BETWEEN the blocks (sched_barriers pin it there), where the other wavefront of the SIMD covers it with its own MFMAs:
   // the next stage's gradient DMA behind block 0, its window loads behind block 1, the staging of that window (BatchNorm +
@@ -1039,14 +1046,13 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
   // ---------------------------------------------------------------- slab: [z][position][ci][co]
   // Lane and wave coordinates are taken afresh here (lane id from mbcnt, wave index as a scalar): carried over from the top of
   // the kernel they would be live across the main loop, which has no register to spare (hipcc spilled `lane & 32`).
-  constexpr int xi0 = XH ? 3 : 0, xi1 = XH ? 2 : 1;
   const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int li_e = lane_e & 31, kh_e = lane_e >> 5;
-  const int ah_e = (wave_s >> 1) & 1, bh_e = wave_s >> 2;
+  const int ah_e = wave_s >> 2;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int pos = ((q >> 2) ? xi1 : xi0) * 4 + (q & 3);
-    float* out = p.slab + (((long)z * 16 + pos) * p.Cin + cib * 64 + ah_e * 32) * p.Cout + cob * 64 + bh_e * 32 + li_e;
+    const int pos = XI * 4 + (q >> 1);                 // acc[2 nu + h]: horizontal position nu, output-channel half h
+    float* out = p.slab + (((long)z * 16 + pos) * p.Cin + cib * 64 + ah_e * 32) * p.Cout + cob * 64 + (q & 1) * 32 + li_e;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * kh_e;
@@ -1057,8 +1063,12 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
 
 template <int SS>
 __device__ __forceinline__ void wino_wgrad_entry(const WinoWgradParams& p, float* xw0, float* xw1, float* dy0, float* dy1) {
-  if ((threadIdx.x >> 6) & 1) wino_wgrad_body<1, SS>(p, xw0, xw1, dy0, dy1);
-  else wino_wgrad_body<0, SS>(p, xw0, xw1, dy0, dy1);
+  switch ((threadIdx.x >> 6) & 3) {
+    case 0: wino_wgrad_body<0, SS>(p, xw0, xw1, dy0, dy1); break;
+    case 1: wino_wgrad_body<1, SS>(p, xw0, xw1, dy0, dy1); break;
+    case 2: wino_wgrad_body<2, SS>(p, xw0, xw1, dy0, dy1); break;
+    default: wino_wgrad_body<3, SS>(p, xw0, xw1, dy0, dy1); break;
+  }
 }
 #define WINO_WGRAD_KERNEL(SS)                                                                                    \
   __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel_s##SS(WinoWgradParams p) {                     \
