@@ -782,9 +782,9 @@ using namespace mfma;
 // contiguous range of 16-tile stages; the K split over workgroups goes through fp32 slabs [z][16][Cin][Cout] that
 // wino_wgrad_reduce_kernel sums in fixed order (in double) and folds through G^T . G into dW[co][ci][3][3].
 //   * both operands are transforms of raw data and are built in registers: per pair of tiles (one MFMA k-step: lanes
-//     0-31 take the even tile, 32-63 the odd one) a lane reads its channel of 12 window pixels and 4 gradient pixels
-//     (ds_read_b32, channel-contiguous over lanes) and spends 22 adds for 8 MFMAs; all signs of A and Bt are folded into
-//     the order of subtractions;
+//     0-31 take the even tile, 32-63 the odd one) a lane reads its input channel at the 8 window pixels of ITS vertical
+//     frequency and the 2 x 4 gradient pixels of both output-channel halves (ds_read_b32, channel-contiguous over lanes) and
+//     spends 12-16 adds (6-8 v_pk_add_f32) for 8 MFMAs; all signs of A and Bt are folded into the order of subtractions;
 //   * LDS holds the raw window [pixel][64 ci] and the gradients [tile][2x2][64 co]; the channel index is XOR-ed with 32
 //     for odd tile columns / odd tiles so that the two lane halves of a read never meet in a bank.
 constexpr int WG_XW_PIX = 136;                 // window pixels per stage: 4 x 34 (W >= 32) .. 10 x 10 (W = 8)
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradParams& p, float*
 
 template <int SS>
 __device__ __forceinline__ void wino_wgrad_entry(const WinoWgradParams& p, float* xw0, float* xw1, float* dy0, float* dy1) {
-  switch ((threadIdx.x >> 6) & 3) {
+  switch ((threadIdx.x >> 6) & 3) {      // (pairing a light frequency - 0 / 3: 6 packed adds - with a heavy one per SIMD: no difference)
     case 0: wino_wgrad_body<0, SS>(p, xw0, xw1, dy0, dy1); break;
     case 1: wino_wgrad_body<1, SS>(p, xw0, xw1, dy0, dy1); break;
     case 2: wino_wgrad_body<2, SS>(p, xw0, xw1, dy0, dy1); break;
