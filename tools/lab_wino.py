@@ -17,17 +17,13 @@ FAKE_D = ("#pragma unroll\n    for (int j = 0; j < 4; ++j) asm volatile(\"\" : \
           "\"=v\"(DST[j].w));")
 VARIANTS = {
     "base": [],
-    "new": [],
-    "pair": [],
-    "prioA": [(PRE_LOOP, "  if (wave < 4) __builtin_amdgcn_s_setprio(1);\n" + PRE_LOOP)],
-    "prioB": [(PRE_LOOP, "  if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n" + PRE_LOOP)],
     "nob": [(f"    B[{i}] = load_b({c}, {g});\n", "") for (i, c, g) in
             [(0, "c", 4), (1, "c", 5), (2, "c", 6), (3, "c", 7), (0, "cn", 0), (1, "cn", 1), (2, "cn", 2), (3, "cn", 3)]],
     "noraw": [("    if (sub == 0) put_raw_part(rnxt, 0);\n", ""), ("    if (sub == 0) put_raw_part(rnxt, 2);\n", ""),
               ("    if (sub == 0) issue_raw(st2);", "    (void)st2; (void)rnxt;"), ("    if (sub == 0) read_scsh(st1);\n", "    (void)st1;\n")],
     "nobar": [("    if (sub == 0) __syncthreads();\n  };", "  };")],
-    "nod": [("    read_rows02(nq, d0, d2);\n", "    (void)nq;\n" + FAKE_D.replace("DST", "d0") + "\n" + FAKE_D.replace("DST", "d2") + "\n"),
-            ("    read_row1(nq, d1);\n", FAKE_D.replace("DST", "d1") + "\n")],
+    "nod": [("    read_row(nq, rowa, da);\n", "    (void)nq;\n" + FAKE_D.replace("DST", "da") + "\n"),
+            ("    read_row(nq, rowb, db);\n", FAKE_D.replace("DST", "db") + "\n")],
 }
 # phase stamps (s_memtime): [workgroup][wave][4] = prologue, main loop, epilogue, chunks; written over the start of Y after the epilogue
 VARIANTS["stamps"] = [
@@ -49,16 +45,6 @@ VARIANTS["clock"] = [
     ("                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
      "                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  const int wave = XI;\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
      "    o[0] = (float)(lab_c1 - lab_c0); o[1] = (float)(lab_r1 - lab_r0); o[2] = (float)nchunk; o[3] = 0.f;\n  }\n}\n\n// ACT: the operand carries"),
-]
-# workgroup timeline: [workgroup][wave][4] = start, end (100-MHz wall clock, low 24 bits as float), CU key (XCC id << 8 | HW_ID[15:8]), 0
-VARIANTS["timeline"] = [
-    ("      out[0] = o0;\n      out[p.Cout] = o1;\n", "      asm volatile(\"\" :: \"v\"(out), \"v\"(o0), \"v\"(o1));\n"),     # no output stores: the stamps go into Y
-    ("  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;",
-     "  const int tpos = wino_xcd_tile(p, gridDim.x, gridDim.y, bm, bn);\n  const long long lab_r0 = wall_clock64();\n  const int RW = wino_row_pitch(p.tw_shift), R = p.R;"),
-    ("                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  if (!ACT) asm volatile(\"\" :: \"v\"(pfv));      // the prefetched value is dropped here: the load stays in the program, its register reserved\n}\n\n// ACT: the operand carries",
-     "                           li_e, h_e, lane_e, n, ty0, bm, bn);\n  asm volatile(\"\" :: \"v\"(pfv));\n  __syncthreads();\n  const int wave = XI;\n  if (lane == 0) {\n    float* o = p.Y + ((long)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + wave) * 4;\n"
-     "    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
-     "    o[0] = (float)(lab_r0 & 0xffffff); o[1] = (float)(wall_clock64() & 0xffffff); o[2] = (float)(((xcc & 15) << 8) | ((hw >> 8) & 255)); o[3] = 0.f;\n  }\n}\n\n// ACT: the operand carries"),
 ]
 # timeline + phases in one launch (output stores kept): wave 0 = start, end, CU key, chunks; wave 1 = main loop start, end (100-MHz
 # ticks, low 24 bits), main-loop shader cycles, 0
@@ -86,13 +72,10 @@ VARIANTS["full"] += [
 ]
 NOPF = [("      pfv = p.X[((long)(n2 * H + y) * W + x) * C];        // default cache policy: the line is to stay in L2", "      pfv = 1.f;")]
 VARIANTS["fullnopf"] = VARIANTS["full"] + NOPF
-VARIANTS["fullpfact"] = VARIANTS["full"] + [("  if (!ACT) {\n    const int nn_ = (int)gridDim.y;", "  {\n    const int nn_ = (int)gridDim.y;")]
 VARIANTS["mfmaonly"] = VARIANTS["nob"] + VARIANTS["noraw"] + VARIANTS["nod"]
 # no transforms either: what the bare MFMA stream (plus barrier and loop control) takes
-NOTRANS = [("    wino_htrans_ip(t1, v1);\n", "#pragma unroll\n    for (int j = 0; j < 4; ++j) v1[j] = t1[j];\n"),
-           ("    vertical(d0, d1, d2);\n", ""),
-           ("    wino_htrans_ip(d0, v0);\n#pragma unroll\n    for (int j = 0; j < 4; ++j) t1[j] = d1[j];\n    WN_SB();\n    if (sub == 0)",
-            "#pragma unroll\n    for (int j = 0; j < 4; ++j) { v0[j] = d0[j]; t1[j] = d1[j]; }\n    WN_SB();\n    if (sub == 0)")]
+NOTRANS = [("    vertical(da, db);\n", ""),
+           ("    wino_htrans_ip(da, vn);\n", "#pragma unroll\n    for (int j = 0; j < 4; ++j) vn[j] = da[j];\n")]
 VARIANTS["puremfma"] = VARIANTS["mfmaonly"] + NOTRANS
 VARIANTS["notrans"] = NOTRANS
 # scalar v_add_f32 / v_sub_f32 instead of the packed forms (twice the instructions)
@@ -107,6 +90,25 @@ VARIANTS["scalar"] = [
      '    v[2] = make_float4(T2.x - T1.x, T2.y - T1.y, T2.z - T1.z, T2.w - T1.w); v[3] = make_float4(T1.x - T3.x, T1.y - T3.y, T1.z - T3.z, T1.w - T3.w);\n'
      '    (void)a0; (void)a1; (void)c0; (void)c1; (void)e0; (void)e1; (void)n0; (void)n1; return; }\n'
      '  asm(WN_PK_SUB("%0", "%0", "%2") WN_PK_SUB("%1", "%1", "%3")          // t0 - t2'),
+]
+# no epilogue at all (the accumulators are kept alive, nothing is exchanged or stored): what the epilogue costs a launch
+VARIANTS["noepi"] = [
+    ("  wino_epilogue<XI, STATS>(p, acc, exb, reinterpret_cast<float*>(raw0 + WN_EX_F4),\n                           li_e, h_e, lane_e, n, ty0, bm, bn);",
+     "#pragma unroll\n  for (int i_ = 0; i_ < 8; ++i_)\n#pragma unroll\n    for (int r_ = 0; r_ < 16; ++r_) asm volatile(\"\" :: \"v\"(acc[i_][r_]));\n"
+     "  (void)exb; (void)li_e; (void)h_e; (void)n; (void)ty0;"),
+]
+VARIANTS["noepi_puremfma"] = VARIANTS["noepi"] + VARIANTS["puremfma"]
+# epilogue without its global stores (exchange and arithmetic kept)
+VARIANTS["nostore"] = [
+    ("    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), yrs, voff[k], soff[j], 0);\n    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), yrs, voff[k], soff[j] + pix, 0);\n",
+     "    asm volatile(\"\" :: \"v\"(o0), \"v\"(o1), \"v\"(voff[k]), \"s\"(soff[j]));\n    (void)yrs; (void)pix;\n"),
+]
+# ... and without the LDS exchange either (each wavefront combines its own pairs three times): arithmetic + stores only
+VARIANTS["noexch"] = [
+    ("        if (SET_OWN >= 0) ex[(SET_OWN * 16 + r) * 64 + lane] = f;\n", ""),
+    ("        ex[(SET_OTHER * 16 + r) * 64 + lane] = f;\n", "        asm volatile(\"\" :: \"v\"(f.x), \"v\"(f.y));\n"),
+    ("  __syncthreads();\n  // descriptor of clip n", "  // descriptor of clip n"),
+    ("    const float2 a = ex[(SET_A * 16 + r) * 64 + lane], b = ex[(SET_B * 16 + r) * 64 + lane];", "    const float2 a = keep[(r + 1) & 15], b = keep[(r + 2) & 15]; (void)ex;"),
 ]
 VARIANT_FLAGS = {"scalar": ["-fno-slp-vectorize"]}
 VARIANTS["fullprio0"] = VARIANTS["full"]
