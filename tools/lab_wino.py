@@ -110,6 +110,11 @@ VARIANTS["noexch"] = [
     ("  __syncthreads();\n  // descriptor of clip n", "  // descriptor of clip n"),
     ("    const float2 a = ex[(SET_A * 16 + r) * 64 + lane], b = ex[(SET_B * 16 + r) * 64 + lane];", "    const float2 a = keep[(r + 1) & 15], b = keep[(r + 2) & 15]; (void)ex;"),
 ]
+# prologue ablations: no zero-fill of padding slots / no first-stage wait
+VARIANTS["nozero"] = [
+    ("  for (int i = tid; i < (2 * R + 2) * 8; i += WN_THREADS) {", "  for (int i = tid; i < 0; i += WN_THREADS) {"),
+    ("    if (lv && !ok) {\n      raw0[slot] = make_float4(0.f, 0.f, 0.f, 0.f);\n      raw1[slot] = make_float4(0.f, 0.f, 0.f, 0.f);\n    }\n", "    (void)slot;\n"),
+]
 VARIANT_FLAGS = {"scalar": ["-fno-slp-vectorize"]}
 VARIANTS["fullprio0"] = VARIANTS["full"]
 VARIANT_FLAGS["fullprio0"] = ["-DWN_PRIO_EDGE=0"]
