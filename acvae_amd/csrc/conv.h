@@ -96,7 +96,10 @@ int colsum2(const float* x, int P, int width, double* dpart, float* out, float* 
 struct ColsumBatch {
   static constexpr int MAXJ = 6;
   const float* x[MAXJ]; int P[MAXJ], width[MAXJ], R[MAXJ], blk0[MAXJ + 1]; long d0[MAXJ]; float* out[MAXJ]; float* out_b[MAXJ]; int n = 0;
-  void add(const float* xs, int p, int w, float* o, float* ob = nullptr) { x[n] = xs; P[n] = p; width[n] = w; out[n] = o; out_b[n] = ob; ++n; }
+  void add(const float* xs, int p, int w, float* o, float* ob = nullptr) {       // n > MAXJ: too many jobs (colsum_batch refuses)
+    if (n < MAXJ) { x[n] = xs; P[n] = p; width[n] = w; out[n] = o; out_b[n] = ob; }
+    ++n;
+  }
 };
 int colsum_batch(ColsumBatch& b, double* dpart, long dpart_doubles, hipStream_t st);
 int conv1_first_blocks(int N, int T);

@@ -45,8 +45,8 @@ int copy_rows_batch(const CopyRowsBatch& b, hipStream_t st);
 // from (each was a 5-us hipMemsetAsync in front of the call's first kernel; words % 1 == 0, 4-byte aligned)
 struct ZeroBatch {
   static constexpr int MAXJ = 10;
-  void* p[MAXJ]; long words[MAXJ]; int n = 0;
-  void add(void* ptr, long w) { if (ptr && w > 0) { p[n] = ptr; words[n] = w; ++n; } }
+  void* p[MAXJ]; long words[MAXJ]; int n = 0;        // n > MAXJ: more regions were added than fit (zero_batch refuses)
+  void add(void* ptr, long w) { if (ptr && w > 0) { if (n < MAXJ) { p[n] = ptr; words[n] = w; } ++n; } }
 };
 int zero_batch(const ZeroBatch& b, hipStream_t st);
 }  // namespace acvae
