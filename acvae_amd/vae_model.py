@@ -109,7 +109,8 @@ class _DecodeFn(torch.autograd.Function):
             # the gradient exchange (the event above) and whoever reads .grad after backward() - joined here at the end of
             # the pass.
             side, cur = model._side_stream(torch.cuda.current_stream()), torch.cuda.current_stream()
-            for t in [ctx.saved, outputs, d_qz] + [u for u in ups if u is not None]:
+            # (mem too: without an ln projection the trailing products read the encoder memory itself, not a copy in `saved`)
+            for t in [ctx.saved, outputs, d_qz, mem] + [u for u in ups if u is not None]:
                 t.record_stream(side)                      # freed by autograd while the side stream still reads them
             if any(p is not None and p.is_leaf and p.grad is not None for p in params):   # (a projected embedding table is not a leaf)
                 cur.wait_stream(side)                      # autograd will accumulate into .grad on this stream right away

@@ -418,8 +418,8 @@ int acvae_decode_fwd_sampled(const void* const* params, const float* mem_in, con
  * acvae_decode_bwd_defers says 1 for the same flags / streams (a second stream is given and no step fed the prior's z to the
  * decoder), everything else - the parameter gradients - is queued on `aux_stream` behind
  * the call, so that it runs beside whatever `stream` does next (the posterior's and the encoder's backward): the caller joins
- * aux_stream before those gradients are read on another stream, and keeps saved / scratch / outputs / the upstream gradients
- * untouched until aux_stream has drained.  Without the flag (0) everything is ordered on `stream` on return.  Hybrid_VAEModel, which joins
+ * aux_stream before those gradients are read on another stream, and keeps saved / scratch / outputs / mem_in / the upstream
+ * gradients untouched until aux_stream has drained (mem_in: without an ln projection the products read it in place).  Without the flag (0) everything is ordered on `stream` on return.  Hybrid_VAEModel, which joins
  * the second stream at the end of the backward pass, passes it unless ACVAE_DECODE_DEFER=0 (-0.07 ms per step on the
  * reference configuration). */
 int acvae_decode_bwd_defers(const int* dis_flags_host, int Tc, void* stream, void* aux_stream, int flags);
