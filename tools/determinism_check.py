@@ -1,5 +1,5 @@
 """Is the HIP train step bit-reproducible?  Runs forward + loss + backward of the same batch several times on fresh
-gradients and compares every parameter gradient bit for bit (also: the loss).  usage: python tools/determinism_check.py [B] [T] [reps]"""
+gradients and compares every parameter gradient bit for bit (also: the loss).  usage: python tools/determinism_check.py [B] [T] [reps] [f32|bf16]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -16,6 +16,8 @@ V, L = bench.V, 22
 torch.manual_seed(5)
 model = bench.build_model().cuda().train()
 model.encoder.p_block = model.encoder.p_fc = 0.0          # no dropout: every run sees the same network
+if len(sys.argv) > 4:
+    model.encoder.compute_dtype = sys.argv[4]
 feats, caps, fl, cl = O.synthetic_batch(B, T, V, L, seed=4, ragged=True)
 g = torch.Generator().manual_seed(3)
 E = model.decoder.embed_size
